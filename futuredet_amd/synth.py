@@ -1,0 +1,91 @@
+"""Seeded synthetic inputs: nuScenes-shaped multi-sweep clouds and random-init weights.
+
+There is no dataset or checkpoint in the image, so bench / tests use
+  * ``synthetic_cloud(seed, target_points)``: rows ``[x, y, z, intensity, dt]`` float32 in the layout
+    LoadPointCloudFromFile produces (det3d/datasets/pipelines/loading.py:128-140; points closer
+    than 1 m removed like ``remove_close`` :36-51): 10 sweeps x 32 beams (-30..+10 deg) x A azimuths,
+    ground plane at z = -1.84 m, per-azimuth-sector wall distance U(4, 70) m, 5 % drop-out,
+    per-sweep ego shift;
+  * ``seeded_state_dict(module, seed)``: fills every parameter / BN statistic from a numpy RNG keyed
+    by the tensor's state_dict key, so the same weights can be regenerated on any box for any
+    implementation that keeps the reference's key names.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def synthetic_cloud(seed=0, target_points=300000, n_sweeps=10, n_beams=32):
+    rng = np.random.default_rng(seed)
+    n_az = max(8, int(round(target_points / 0.95 / 0.94 / (n_sweeps * n_beams))))
+    elev = np.deg2rad(np.linspace(-30.0, 10.0, n_beams)).astype(np.float64)
+    n_sectors = 360
+    sweeps = []
+    for s in range(n_sweeps):
+        wall = rng.uniform(4.0, 70.0, n_sectors)
+        az = (np.arange(n_az) + rng.uniform(0, 1)) * (2 * np.pi / n_az)
+        A, E = np.meshgrid(az, elev, indexing="ij")
+        sector = (A / (2 * np.pi) * n_sectors).astype(np.int64) % n_sectors
+        r_wall = wall[sector] / np.maximum(np.cos(E), 1e-3)
+        sensor_h = 1.84
+        with np.errstate(divide="ignore"):
+            r_ground = np.where(E < -1e-3, sensor_h / np.maximum(-np.sin(E), 1e-6), np.inf)
+        r = np.minimum(r_wall, r_ground) + rng.normal(0, 0.02, A.shape)
+        x = r * np.cos(E) * np.cos(A)
+        y = r * np.cos(E) * np.sin(A)
+        z = r * np.sin(E)
+        shift = rng.normal(0, 0.6, 2) * s  # ego motion between sweeps
+        x = x + shift[0]
+        y = y + shift[1]
+        keep = rng.random(A.shape) > 0.05
+        keep &= (np.abs(x) >= 1.0) | (np.abs(y) >= 1.0)
+        inten = rng.uniform(0, 255, A.shape)
+        dt = np.full(A.shape, 0.05 * s)
+        pts = np.stack([x, y, z, inten, dt], axis=-1)[keep]
+        sweeps.append(pts.astype(np.float32))
+    return np.ascontiguousarray(np.concatenate(sweeps, axis=0))
+
+
+def _rng_for(key, seed):
+    return np.random.default_rng([zlib.crc32(key.encode()), seed])
+
+
+def seeded_state_dict(module, seed=0):
+    """Returns {key: tensor} for every entry of ``module.state_dict()`` (except num_batches_tracked)."""
+    out = {}
+    sd = module.state_dict()
+    for key, t in sd.items():
+        if key.endswith("num_batches_tracked"):
+            continue
+        rng = _rng_for(key, seed)
+        shape = tuple(t.shape)
+        leaf = key.rsplit(".", 1)[-1]
+        if leaf == "running_var":
+            v = rng.uniform(0.5, 1.5, shape)
+        elif leaf == "running_mean":
+            v = rng.normal(0, 0.1, shape)
+        elif leaf == "weight" and len(shape) == 1:  # norm scale
+            v = rng.uniform(0.5, 1.5, shape)
+        elif key.endswith("hm.3.bias"):  # heat-map prior, init_bias=-2.19 (center_head.py:145-146)
+            v = np.full(shape, -2.19)
+        elif leaf == "bias":
+            v = rng.normal(0, 0.1, shape)
+        elif leaf == "weight" and len(shape) == 5:  # spconv layout (kD,kH,kW,Cin,Cout)
+            fan_in = shape[0] * shape[1] * shape[2] * shape[3]
+            v = rng.normal(0, np.sqrt(2.0 / fan_in), shape)
+        elif leaf == "weight" and len(shape) == 4:  # Conv2d (Cout,Cin,kh,kw) / ConvT (Cin,Cout,kh,kw)
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = rng.normal(0, np.sqrt(2.0 / fan_in), shape)
+        else:
+            v = rng.normal(0, 0.1, shape)
+        out[key] = torch.from_numpy(np.asarray(v, dtype=np.float32)).to(t.dtype)
+    return out
+
+
+def load_seeded(module, seed=0):
+    sd = seeded_state_dict(module, seed)
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if not m.endswith("num_batches_tracked")]
+    assert not missing and not unexpected, (missing, unexpected)
+    return module

@@ -1,0 +1,407 @@
+/*
+ * fd_oracle.c -- CPU restatement of the FutureDet LiDAR hot path's integer /
+ * geometry arithmetic.  TEST INFRASTRUCTURE ONLY: imported by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker; the
+ * product path (futuredet_amd/) never links or calls anything in this file.
+ *
+ * Every function names the reference lines it follows (paths relative to the
+ * reference checkout).  The sparse-convolution arithmetic of the reference
+ * lives in the un-vendored third-party package spconv 1.0
+ * (github.com/neeharperi/spconv, fork of traveller59/spconv v1.0; named at
+ * README.md:26,31,59 and built by setup.sh:27-34, no commit pin).  Its source
+ * is not in the image, so the rulebook / indice_conv functions below restate
+ * the published spconv-1.0 algorithm and are anchored on the reference's call
+ * sites (det3d/models/backbones/scn.py:13-21,99-165).  PARITY UNPINNED for that
+ * piece: no reference test or vector exists; it is pinned instead against dense
+ * torch F.conv3d identities (tests/test_oracle_spconv.py).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* A1. points_to_voxel                                                        */
+/*     det3d/ops/point_cloud/point_cloud_ops.py:7-55 (reverse-index kernel)   */
+/*     and :112-184 (allocation, slicing).  All arithmetic in float32, true   */
+/*     division, floor; first-come voxel ids; points beyond max_points        */
+/*     dropped; new voxels beyond max_voxels dropped.                         */
+/* ------------------------------------------------------------------------- */
+int64_t fdo_points_to_voxel(const float *points, int64_t n, int ndim_pt,
+                            const float *voxel_size, const float *coors_range,
+                            int max_points, int64_t max_voxels,
+                            float *voxels,          /* [max_voxels,max_points,ndim_pt], zeroed by caller */
+                            int32_t *coors,         /* [max_voxels,3] (z,y,x) */
+                            int32_t *num_points_per_voxel /* [max_voxels], zeroed by caller */)
+{
+    int32_t grid[3];
+    for (int j = 0; j < 3; ++j) {
+        /* :24-29  grid_size = round((hi-lo)/vs) in float32 then int32 */
+        float g = (coors_range[3 + j] - coors_range[j]) / voxel_size[j];
+        grid[j] = (int32_t)rintf(g); /* np.round = half-to-even = rintf */
+    }
+    /* :150 coor_to_voxelidx = -ones(voxelmap_shape[::-1]) */
+    int64_t cells = (int64_t)grid[0] * grid[1] * grid[2];
+    int32_t *lut = (int32_t *)malloc(sizeof(int32_t) * (size_t)cells);
+    if (!lut) return -1;
+    memset(lut, 0xff, sizeof(int32_t) * (size_t)cells);
+    int64_t voxel_num = 0;
+    for (int64_t i = 0; i < n; ++i) {                       /* :33 */
+        int32_t coor[3];
+        int failed = 0;
+        for (int j = 0; j < 3; ++j) {                       /* :35-40 */
+            float c = floorf((points[i * ndim_pt + j] - coors_range[j]) / voxel_size[j]);
+            if (c < 0 || c >= (float)grid[j]) { failed = 1; break; }
+            coor[2 - j] = (int32_t)c;
+        }
+        if (failed) continue;
+        /* lut indexed [z][y][x] with shape (gz,gy,gx) */
+        int64_t cell = ((int64_t)coor[0] * grid[1] + coor[1]) * grid[0] + coor[2];
+        int32_t vid = lut[cell];
+        if (vid == -1) {                                    /* :43-49 */
+            vid = (int32_t)voxel_num;
+            if (voxel_num >= max_voxels) continue;
+            voxel_num += 1;
+            lut[cell] = vid;
+            coors[vid * 3 + 0] = coor[0];
+            coors[vid * 3 + 1] = coor[1];
+            coors[vid * 3 + 2] = coor[2];
+        }
+        int32_t num = num_points_per_voxel[vid];            /* :50-54 */
+        if (num < max_points) {
+            memcpy(voxels + ((int64_t)vid * max_points + num) * ndim_pt,
+                   points + i * ndim_pt, sizeof(float) * (size_t)ndim_pt);
+            num_points_per_voxel[vid] = num + 1;
+        }
+    }
+    free(lut);
+    return voxel_num;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A5. spconv-1.0 rulebook ("indice pairs").                                  */
+/*     Call sites: scn.py:99 (SubM k3, key res0), :110,:120 (k3 s2 p1),       */
+/*     :130 (k3 s2 p[0,1,1]), :141 (k(3,1,1) s(2,1,1) p0), SubM keys          */
+/*     res1..res3 (:115,:125,:135).                                           */
+/*     Published algorithm (spconv v1.0 getValidOutPos / getIndicePairsConv / */
+/*     getIndicePairsSubM): for every active input p and every kernel tap     */
+/*     kappa, the output site is o = (p + pad - kappa) / stride when that is  */
+/*     integral and inside out_shape; kernel offset index is row-major over   */
+/*     (kz,ky,kx).  SubM forces stride 1, pad k/2 and restricts outputs to    */
+/*     the input set (same row numbering).  Non-SubM outputs are numbered in  */
+/*     first-creation order.  indice_pairs[K][2][n_in], indice_pair_num[K].   */
+/* ------------------------------------------------------------------------- */
+typedef struct { int64_t *keys; int32_t *vals; uint64_t mask; } fdo_hash;
+
+static int fdo_hash_init(fdo_hash *h, int64_t n)
+{
+    uint64_t cap = 16;
+    while (cap < (uint64_t)n * 2 + 2) cap <<= 1;
+    h->keys = (int64_t *)malloc(sizeof(int64_t) * cap);
+    h->vals = (int32_t *)malloc(sizeof(int32_t) * cap);
+    if (!h->keys || !h->vals) return -1;
+    for (uint64_t i = 0; i < cap; ++i) h->keys[i] = -1;
+    h->mask = cap - 1;
+    return 0;
+}
+static void fdo_hash_free(fdo_hash *h) { free(h->keys); free(h->vals); }
+static inline uint64_t fdo_mix(int64_t k) { uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull; return x ^ (x >> 29); }
+static inline int32_t fdo_hash_get(const fdo_hash *h, int64_t key)
+{
+    uint64_t s = fdo_mix(key) & h->mask;
+    while (h->keys[s] != -1) { if (h->keys[s] == key) return h->vals[s]; s = (s + 1) & h->mask; }
+    return -1;
+}
+static inline int32_t fdo_hash_put(fdo_hash *h, int64_t key, int32_t val) /* returns existing or val */
+{
+    uint64_t s = fdo_mix(key) & h->mask;
+    while (h->keys[s] != -1) { if (h->keys[s] == key) return h->vals[s]; s = (s + 1) & h->mask; }
+    h->keys[s] = key; h->vals[s] = val; return val;
+}
+
+static inline int64_t fdo_lin(int32_t b, const int32_t *p, const int32_t *shape)
+{
+    return (((int64_t)b * shape[0] + p[0]) * shape[1] + p[1]) * shape[2] + p[2];
+}
+
+/* out_shape_i = (in_i + 2 pad_i - dil*(k_i-1) - 1) / stride_i + 1  (spconv ops.get_conv_output_size) */
+void fdo_conv_out_shape(const int32_t *in_shape, const int32_t *ksize, const int32_t *stride,
+                        const int32_t *pad, int32_t *out_shape)
+{
+    for (int i = 0; i < 3; ++i)
+        out_shape[i] = (in_shape[i] + 2 * pad[i] - (ksize[i] - 1) - 1) / stride[i] + 1;
+}
+
+/* Returns number of active outputs (== n for subm), or <0 on allocation failure. */
+int64_t fdo_rulebook(const int32_t *indices /* [n,4] (b,z,y,x) */, int64_t n,
+                     const int32_t *in_shape, const int32_t *ksize_in, const int32_t *stride_in,
+                     const int32_t *pad_in, int subm,
+                     int32_t *out_indices /* [>=n*K,4] worst case; subm: [n,4] */,
+                     int32_t *pairs /* [K,2,n], filled with -1 */, int32_t *pair_num /* [K] */)
+{
+    int32_t ks[3], st[3], pd[3], out_shape[3];
+    for (int i = 0; i < 3; ++i) {
+        ks[i] = ksize_in[i];
+        st[i] = subm ? 1 : stride_in[i];
+        pd[i] = subm ? ksize_in[i] / 2 : pad_in[i];
+    }
+    if (subm) memcpy(out_shape, in_shape, sizeof(out_shape));
+    else fdo_conv_out_shape(in_shape, ks, st, pd, out_shape);
+    const int K = ks[0] * ks[1] * ks[2];
+    for (int64_t i = 0; i < (int64_t)K * 2 * n; ++i) pairs[i] = -1;
+    for (int k = 0; k < K; ++k) pair_num[k] = 0;
+
+    fdo_hash h;
+    if (fdo_hash_init(&h, subm ? n : n * 8 + 8) != 0) return -1;
+    int64_t n_out = 0;
+    if (subm) {
+        for (int64_t j = 0; j < n; ++j) {
+            fdo_hash_put(&h, fdo_lin(indices[j * 4], indices + j * 4 + 1, out_shape), (int32_t)j);
+            memcpy(out_indices + j * 4, indices + j * 4, 4 * sizeof(int32_t));
+        }
+        n_out = n;
+    }
+    for (int64_t j = 0; j < n; ++j) {
+        const int32_t b = indices[j * 4];
+        const int32_t *p = indices + j * 4 + 1;
+        for (int kz = 0; kz < ks[0]; ++kz)
+        for (int ky = 0; ky < ks[1]; ++ky)
+        for (int kx = 0; kx < ks[2]; ++kx) {
+            const int kap[3] = {kz, ky, kx};
+            int32_t o[3];
+            int ok = 1;
+            for (int a = 0; a < 3 && ok; ++a) {
+                int32_t t = p[a] + pd[a] - kap[a];
+                if (t < 0 || t % st[a] != 0) { ok = 0; break; }
+                o[a] = t / st[a];
+                if (o[a] >= out_shape[a]) ok = 0;
+            }
+            if (!ok) continue;
+            const int kidx = (kz * ks[1] + ky) * ks[2] + kx;
+            const int64_t key = fdo_lin(b, o, out_shape);
+            int32_t row;
+            if (subm) {
+                row = fdo_hash_get(&h, key);
+                if (row < 0) continue;
+            } else {
+                row = fdo_hash_put(&h, key, (int32_t)n_out);
+                if (row == (int32_t)n_out) {
+                    out_indices[n_out * 4 + 0] = b;
+                    out_indices[n_out * 4 + 1] = o[0];
+                    out_indices[n_out * 4 + 2] = o[1];
+                    out_indices[n_out * 4 + 3] = o[2];
+                    n_out += 1;
+                }
+            }
+            const int32_t c = pair_num[kidx]++;
+            pairs[((int64_t)kidx * 2 + 0) * n + c] = (int32_t)j;
+            pairs[((int64_t)kidx * 2 + 1) * n + c] = row;
+        }
+    }
+    fdo_hash_free(&h);
+    return n_out;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A6. indice_conv: out[o,:] += in[i,:] @ W[kappa] over rulebook pairs;       */
+/*     weight layout (kD,kH,kW,Cin,Cout) viewed as [K,Cin,Cout] (spconv 1.0   */
+/*     SparseConvolution: weight = Parameter(*kernel_size, Cin, Cout));       */
+/*     bias added after the scatter.  Call sites scn.py:99-141.               */
+/*     fp32 accumulate, taps visited in kernel-offset order.                  */
+/* ------------------------------------------------------------------------- */
+void fdo_indice_conv(const float *in_feats, int64_t n_in, int cin,
+                     const float *weight /* [K,cin,cout] */, const float *bias /* [cout] or NULL */,
+                     const int32_t *pairs /* [K,2,n_in] */, const int32_t *pair_num, int K,
+                     float *out_feats /* [n_out,cout] */, int64_t n_out, int cout)
+{
+    memset(out_feats, 0, sizeof(float) * (size_t)(n_out * cout));
+    for (int k = 0; k < K; ++k) {
+        const int32_t *pin = pairs + ((int64_t)k * 2 + 0) * n_in;
+        const int32_t *pout = pairs + ((int64_t)k * 2 + 1) * n_in;
+        const float *W = weight + (int64_t)k * cin * cout;
+        const int32_t np = pair_num[k];
+        /* within one tap every output row occurs at most once -> race free */
+#pragma omp parallel for schedule(static)
+        for (int32_t t = 0; t < np; ++t) {
+            const float *x = in_feats + (int64_t)pin[t] * cin;
+            float *y = out_feats + (int64_t)pout[t] * cout;
+            for (int ci = 0; ci < cin; ++ci) {
+                const float xv = x[ci];
+                const float *w = W + (int64_t)ci * cout;
+                for (int co = 0; co < cout; ++co) y[co] += xv * w[co];
+            }
+        }
+    }
+    if (bias) {
+#pragma omp parallel for schedule(static)
+        for (int64_t o = 0; o < n_out; ++o)
+            for (int co = 0; co < cout; ++co) out_feats[o * cout + co] += bias[co];
+    }
+}
+
+/* A8. SparseConvTensor.dense(): scatter rows into zeros [B,D,H,W,C] then permute to [B,C,D,H,W]
+ * (scn.py:165; spconv SparseConvTensor.dense = scatter_nd + permute). */
+void fdo_dense(const float *feats, const int32_t *indices, int64_t n, int c,
+               int B, int D, int H, int W, float *out /* [B,C,D,H,W], zeroed here */)
+{
+    memset(out, 0, sizeof(float) * (size_t)B * c * D * H * W);
+    for (int64_t r = 0; r < n; ++r) {
+        const int32_t *q = indices + r * 4;
+        for (int ch = 0; ch < c; ++ch)
+            out[((((int64_t)q[0] * c + ch) * D + q[1]) * H + q[2]) * W + q[3]] = feats[r * c + ch];
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A14. rotated BEV IoU + NMS.                                                */
+/*      Geometry follows det3d/ops/iou3d_nms/src/iou3d_cpu.cpp:27-229 (the    */
+/*      CPU twin of iou3d_nms_kernel.cu:14-234).  That file is C++: cos/sin/  */
+/*      atan2/fabs on float arguments resolve to the float overloads, hence   */
+/*      cosf/sinf/atan2f/fabsf here; `fabs(area) / 2.0` is a double division. */
+/*      Greedy sweep follows iou3d_nms.cpp:116-132.                           */
+/* ------------------------------------------------------------------------- */
+typedef struct { float x, y; } fdo_pt;
+static const float FDO_EPS = 1e-8f; /* iou3d_cpu.cpp:36 */
+
+static inline float fdo_min(float a, float b) { return a > b ? b : a; }
+static inline float fdo_max(float a, float b) { return a > b ? a : b; }
+static inline float fdo_cross2(fdo_pt a, fdo_pt b) { return a.x * b.y - a.y * b.x; }                 /* :58-60 */
+static inline float fdo_cross3(fdo_pt p1, fdo_pt p2, fdo_pt p0)                                      /* :62-64 */
+{ return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+
+static inline int fdo_check_rect_cross(fdo_pt p1, fdo_pt p2, fdo_pt q1, fdo_pt q2)                  /* :66-72 */
+{
+    return fdo_min(p1.x, p2.x) <= fdo_max(q1.x, q2.x) && fdo_min(q1.x, q2.x) <= fdo_max(p1.x, p2.x) &&
+           fdo_min(p1.y, p2.y) <= fdo_max(q1.y, q2.y) && fdo_min(q1.y, q2.y) <= fdo_max(p1.y, p2.y);
+}
+
+static inline int fdo_check_in_box2d(const float *box, fdo_pt p)                                     /* :74-84 */
+{
+    const float MARGIN = 1e-2f;
+    float center_x = box[0], center_y = box[1];
+    float angle_cos = cosf(-box[6]), angle_sin = sinf(-box[6]);
+    float rot_x = (p.x - center_x) * angle_cos + (p.y - center_y) * (-angle_sin);
+    float rot_y = (p.x - center_x) * angle_sin + (p.y - center_y) * angle_cos;
+    return (fabsf(rot_x) < box[3] / 2 + MARGIN && fabsf(rot_y) < box[4] / 2 + MARGIN);
+}
+
+static inline int fdo_intersection(fdo_pt p1, fdo_pt p0, fdo_pt q1, fdo_pt q0, fdo_pt *ans)          /* :86-115 */
+{
+    if (fdo_check_rect_cross(p0, p1, q0, q1) == 0) return 0;
+    float s1 = fdo_cross3(q0, p1, p0);
+    float s2 = fdo_cross3(p1, q1, p0);
+    float s3 = fdo_cross3(p0, q1, q0);
+    float s4 = fdo_cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+    float s5 = fdo_cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > FDO_EPS) {
+        ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        float D = a0 * b1 - a1 * b0;
+        ans->x = (b0 * c1 - b1 * c0) / D;
+        ans->y = (a1 * c0 - a0 * c1) / D;
+    }
+    return 1;
+}
+
+static inline void fdo_rotate_around_center(fdo_pt c, float ac, float as, fdo_pt *p)                 /* :117-121 */
+{
+    float nx = (p->x - c.x) * ac + (p->y - c.y) * (-as) + c.x;
+    float ny = (p->x - c.x) * as + (p->y - c.y) * ac + c.y;
+    p->x = nx; p->y = ny;
+}
+
+static inline int fdo_point_cmp(fdo_pt a, fdo_pt b, fdo_pt c)                                        /* :123-125 */
+{ return atan2f(a.y - c.y, a.x - c.x) > atan2f(b.y - c.y, b.x - c.x); }
+
+float fdo_box_overlap(const float *box_a, const float *box_b)                                        /* :127-219 */
+{
+    float a_angle = box_a[6], b_angle = box_b[6];
+    float a_dx_half = box_a[3] / 2, b_dx_half = box_b[3] / 2, a_dy_half = box_a[4] / 2, b_dy_half = box_b[4] / 2;
+    float a_x1 = box_a[0] - a_dx_half, a_y1 = box_a[1] - a_dy_half;
+    float a_x2 = box_a[0] + a_dx_half, a_y2 = box_a[1] + a_dy_half;
+    float b_x1 = box_b[0] - b_dx_half, b_y1 = box_b[1] - b_dy_half;
+    float b_x2 = box_b[0] + b_dx_half, b_y2 = box_b[1] + b_dy_half;
+    fdo_pt center_a = {box_a[0], box_a[1]}, center_b = {box_b[0], box_b[1]};
+    fdo_pt ca[5] = {{a_x1, a_y1}, {a_x2, a_y1}, {a_x2, a_y2}, {a_x1, a_y2}, {0, 0}};
+    fdo_pt cb[5] = {{b_x1, b_y1}, {b_x2, b_y1}, {b_x2, b_y2}, {b_x1, b_y2}, {0, 0}};
+    float a_cos = cosf(a_angle), a_sin = sinf(a_angle);
+    float b_cos = cosf(b_angle), b_sin = sinf(b_angle);
+    for (int k = 0; k < 4; ++k) {
+        fdo_rotate_around_center(center_a, a_cos, a_sin, &ca[k]);
+        fdo_rotate_around_center(center_b, b_cos, b_sin, &cb[k]);
+    }
+    ca[4] = ca[0]; cb[4] = cb[0];
+    fdo_pt cross_points[16];
+    fdo_pt poly_center = {0, 0};
+    int cnt = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            int flag = fdo_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], &cross_points[cnt]);
+            if (flag) {
+                poly_center.x = poly_center.x + cross_points[cnt].x;
+                poly_center.y = poly_center.y + cross_points[cnt].y;
+                cnt++;
+            }
+        }
+    for (int k = 0; k < 4; ++k) {
+        if (fdo_check_in_box2d(box_a, cb[k])) {
+            poly_center.x = poly_center.x + cb[k].x; poly_center.y = poly_center.y + cb[k].y;
+            cross_points[cnt] = cb[k]; cnt++;
+        }
+        if (fdo_check_in_box2d(box_b, ca[k])) {
+            poly_center.x = poly_center.x + ca[k].x; poly_center.y = poly_center.y + ca[k].y;
+            cross_points[cnt] = ca[k]; cnt++;
+        }
+    }
+    poly_center.x /= cnt;
+    poly_center.y /= cnt;
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (fdo_point_cmp(cross_points[i], cross_points[i + 1], poly_center)) {
+                fdo_pt t = cross_points[i]; cross_points[i] = cross_points[i + 1]; cross_points[i + 1] = t;
+            }
+    float area = 0;
+    for (int k = 0; k < cnt - 1; ++k) {
+        fdo_pt u = {cross_points[k].x - cross_points[0].x, cross_points[k].y - cross_points[0].y};
+        fdo_pt v = {cross_points[k + 1].x - cross_points[0].x, cross_points[k + 1].y - cross_points[0].y};
+        area += fdo_cross2(u, v);
+    }
+    return (float)(fabsf(area) / 2.0);
+}
+
+float fdo_iou_bev(const float *box_a, const float *box_b)                                            /* :221-229 */
+{
+    float sa = box_a[3] * box_a[4];
+    float sb = box_b[3] * box_b[4];
+    float s_overlap = fdo_box_overlap(box_a, box_b);
+    return s_overlap / fmaxf(sa + sb - s_overlap, FDO_EPS);
+}
+
+void fdo_boxes_iou_bev(const float *a, int na, const float *b, int nb, float *out)                   /* :232-252 */
+{
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) out[(int64_t)i * nb + j] = fdo_iou_bev(a + i * 7, b + j * 7);
+}
+
+/* nms: mask bit (i,j) set iff j>i and iou(i,j) > thresh (iou3d_nms_kernel.cu:267-311), then the
+ * greedy sweep of iou3d_nms.cpp:116-132.  boxes are already score-sorted by the caller. */
+int fdo_nms(const float *boxes /* [n,7] */, int n, float thresh, int64_t *keep)
+{
+    const int cb = (n + 63) / 64;
+    uint64_t *remv = (uint64_t *)calloc((size_t)cb + 1, sizeof(uint64_t));
+    int num = 0;
+    for (int i = 0; i < n; ++i) {
+        if (remv[i / 64] & (1ull << (i % 64))) continue;
+        keep[num++] = i;
+        for (int j = i + 1; j < n; ++j)
+            if (fdo_iou_bev(boxes + i * 7, boxes + j * 7) > thresh) remv[j / 64] |= 1ull << (j % 64);
+    }
+    free(remv);
+    return num;
+}

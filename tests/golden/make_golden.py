@@ -1,0 +1,348 @@
+"""Generates the committed golden fixtures in tests/golden/*.npz|json by IMPORTING the reference
+(/root/reference) in the build container.  Run:  python tests/golden/make_golden.py
+
+Nothing from the reference is copied: fixtures hold inputs + the reference's outputs only.
+Third-party modules the reference imports but the image lacks are given inert import shims so the
+reference's own code runs unmodified:
+  numba (jit = identity decorator -> the reference's voxelizer loop runs as plain Python),
+  addict (minimal Dict), terminaltables, torchvision(.models.resnet), cv2, pycocotools.mask (empty),
+  det3d.ops.iou3d_nms.iou3d_nms_cuda (nms_gpu = the greedy sweep of iou3d_nms.cpp:116-132 over the IoU
+  matrix computed by the reference's OWN iou3d_cpu.cpp compiled into oracle/_ref),
+  spconv (= oracle/spconv_api.py, our restatement of the spconv-1.0 surface; spconv itself is absent,
+  so the sparse-conv arithmetic is NOT pinned by these fixtures, only the backbone topology is).
+"""
+import collections
+import collections.abc
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from oracle import ops as oops  # noqa: E402
+from oracle import spconv_api  # noqa: E402
+from futuredet_amd.synth import seeded_state_dict, synthetic_cloud  # noqa: E402
+
+
+def install_shims():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    mod("numba", jit=jit, njit=jit, cuda=types.SimpleNamespace(jit=jit))
+
+    class Dict(dict):
+        def __init__(self, *a, **k):
+            super().__init__()
+            for kk, v in dict(*a, **k).items():
+                self[kk] = v
+
+        def __setitem__(self, k, v):
+            super().__setitem__(k, self._w(v))
+
+        @classmethod
+        def _w(cls, v):
+            if isinstance(v, dict) and not isinstance(v, cls):
+                return cls(v)
+            if isinstance(v, (list, tuple)):
+                return type(v)(cls._w(x) for x in v)
+            return v
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                return self.__missing__(k)
+
+        def __setattr__(self, k, v):
+            self[k] = v
+
+        def __missing__(self, k):
+            raise KeyError(k)
+
+    mod("addict", Dict=Dict)
+    mod("terminaltables", AsciiTable=object)
+    tv = mod("torchvision")
+    tvm = mod("torchvision.models")
+    tvr = mod("torchvision.models.resnet")
+    tv.models = tvm
+    tvm.resnet = tvr
+    mod("cv2")
+    pc = mod("pycocotools")
+    pc.mask = mod("pycocotools.mask")
+    collections.Iterable = collections.abc.Iterable
+
+    def nms_gpu(boxes, keep, thresh):
+        b = boxes.detach().cpu().numpy().astype(np.float32)
+        iou = oops.ref_boxes_iou_bev(b, b)
+        assert iou is not None, "build oracle/_ref first (python oracle/build_ref.py)"
+        n = len(b)
+        removed = np.zeros(n, bool)
+        k = 0
+        for i in range(n):
+            if removed[i]:
+                continue
+            keep[k] = i
+            k += 1
+            removed[i + 1:] |= iou[i, i + 1:] > thresh
+        return k
+
+    mod("det3d.ops.iou3d_nms.iou3d_nms_cuda", nms_gpu=nms_gpu)
+    sys.modules["spconv"] = spconv_api
+    torch.Tensor.cuda = lambda self, *a, **k: self  # box_torch_ops.py:272 calls keep.cuda()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote", name, os.path.getsize(path) // 1024, "KiB")
+
+
+def gen_voxelizer():
+    from det3d.ops.point_cloud.point_cloud_ops import points_to_voxel
+
+    cases = {}
+    rng = np.random.default_rng(1)
+    # (a) tiny grid: both caps hit, out-of-range points, points exactly on the upper edge
+    pts = rng.uniform(-1.2, 1.2, (600, 5)).astype(np.float32)
+    pts[:7, 0] = 1.0
+    pts[7:12, 2] = 1.0
+    pts[12:15, 1] = -1.0
+    cases["tiny"] = (pts, [0.25, 0.25, 0.5], [-1, -1, -1, 1, 1, 1], 3, 40)
+    # (b) nuScenes grid, values one ulp around cell edges (the f32 true-division hazard)
+    n = 3000
+    pts = np.zeros((n, 5), np.float32)
+    cell = rng.integers(0, 1440, n)
+    edge = (np.float32(-54.0) + cell.astype(np.float32) * np.float32(0.075)).astype(np.float32)
+    pts[:, 0] = np.nextafter(edge, np.float32(np.inf) * rng.choice([-1, 1], n).astype(np.float32))
+    pts[: n // 3, 0] = edge[: n // 3]
+    pts[:, 1] = rng.uniform(-54, 54, n)
+    pts[:, 2] = rng.uniform(-5, 3, n)
+    pts[:, 3] = rng.uniform(0, 255, n)
+    cases["edges"] = (pts, [0.075, 0.075, 0.2], [-54, -54, -5.0, 54, 54, 3.0], 10, 160000)
+    # (c) synthetic 10-sweep cloud, config grid, max_voxels cap hit
+    pts = synthetic_cloud(seed=3, target_points=12000)
+    cases["cloud_cap"] = (pts, [0.075, 0.075, 0.2], [-54, -54, -5.0, 54, 54, 3.0], 10, 6000)
+    # (d) duplicates-heavy: max_points cap hit in many voxels, coarse grid
+    pts = synthetic_cloud(seed=4, target_points=8000)
+    cases["coarse"] = (pts, [0.6, 0.6, 1.0], [-54, -54, -5.0, 54, 54, 3.0], 5, 20000)
+    # (e) empty-after-filter cloud
+    pts = np.full((17, 5), 1e3, np.float32)
+    cases["all_out"] = (pts, [0.075, 0.075, 0.2], [-54, -54, -5.0, 54, 54, 3.0], 10, 100)
+    out = {}
+    for name, (pts, vs, rg, mp, mv) in cases.items():
+        v, c, npv = points_to_voxel(pts, np.array(vs, np.float32), np.array(rg, np.float32), mp, True, mv)
+        ov, oc, onpv = oops.points_to_voxel(pts, vs, rg, mp, True, mv)
+        assert np.array_equal(v, ov) and np.array_equal(c, oc) and np.array_equal(npv, onpv), name
+        print("voxelizer", name, pts.shape, "->", v.shape, "max npv", npv.max() if len(npv) else 0)
+        out[name + "_points"] = pts
+        out[name + "_cfg"] = np.array(list(vs) + list(rg) + [mp, mv], np.float64)
+        out[name + "_voxels"] = v
+        out[name + "_coors"] = c
+        out[name + "_num"] = npv
+    save("voxelizer.npz", **out)
+
+
+def gen_configs():
+    from det3d.torchie import Config
+
+    def plain(v):
+        if isinstance(v, dict):
+            return {k: plain(x) for k, x in v.items() if k != "logger"}
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        if isinstance(v, (np.integer,)):
+            return int(v)
+        if isinstance(v, (np.floating,)):
+            return float(v)
+        if isinstance(v, (str, int, float, bool)) or v is None:
+            return v
+        return repr(type(v))
+
+    out = {}
+    cdir = os.path.join(REF, "configs", "centerpoint")
+    for f in sorted(os.listdir(cdir)):
+        if not f.endswith(".py"):
+            continue
+        cfg = Config.fromfile(os.path.join(cdir, f))
+        keep = {}
+        for k in ("model", "test_cfg", "voxel_generator", "timesteps", "tasks", "class_names", "TWO_STAGE",
+                  "DOUBLE_FLIP", "DENSE", "BEV_MAP", "FORECAST_FEATS", "test_pipeline", "assigner"):
+            keep[k] = plain(cfg[k])
+        out[f] = keep
+    with open(os.path.join(HERE, "configs.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("wrote configs.json", len(out), "configs")
+
+
+def gen_dense_nets():
+    """Reference RPN + CenterHead forward at reduced width / size (same classes, same config surface)."""
+    import logging
+
+    from det3d.models import build_head, build_neck
+
+    torch.manual_seed(0)
+    out = {}
+    neck_cfg = dict(type="RPN", layer_nums=[2, 2], ds_layer_strides=[1, 2], ds_num_filters=[16, 32],
+                    us_layer_strides=[1, 2], us_num_filters=[32, 32], num_input_features=24,
+                    logger=logging.getLogger("RPN"))
+    neck = build_neck(dict(neck_cfg)).eval()
+    neck.load_state_dict(seeded_state_dict(neck, 11), strict=False)
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 24, 16, 20)).astype(np.float32))
+    with torch.no_grad():
+        y = neck(x)
+    out["rpn_x"] = x.numpy()
+    out["rpn_y"] = y.numpy()
+    out["rpn_keys"] = np.array(sorted(neck.state_dict().keys()))
+    for name, T, dense, ff in (("n0", 1, False, False), ("n3", 7, False, False), ("n3dtf", 7, True, True)):
+        head_cfg = dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])],
+                        dataset="nuscenes", weight=0.25, code_weights=[1.0] * 10,
+                        common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
+                        share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=False,
+                        sparse=False, dense=dense, bev_map=False, forecast_feature=ff, classify=False,
+                        wide_head=False)
+        head = build_head(dict(head_cfg)).eval()
+        head.load_state_dict(seeded_state_dict(head, 12), strict=False)
+        with torch.no_grad():
+            preds = head(y)
+        out["head_%s_keys" % name] = np.array(sorted(head.state_dict().keys()))
+        for ti, pd in enumerate(preds):
+            for k, v in pd.items():
+                out["head_%s_t%d_%s" % (name, ti, k)] = v.numpy()
+    save("dense_nets.npz", **out)
+
+
+def gen_predict():
+    """Reference CenterHead.predict (decode + rotated NMS through the compiled reference IoU)."""
+    from det3d.models import build_head
+    from det3d.torchie.utils.config import ConfigDict
+
+    out = {}
+    test_cfg = ConfigDict(
+        post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], max_per_img=500,
+        nms=dict(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=1000, nms_post_max_size=83,
+                 nms_iou_threshold=0.2),
+        score_threshold=0.1, pc_range=[-54, -54], out_size_factor=8, voxel_size=[0.075, 0.075], double_flip=False)
+    for name, T, dense, H, W, B in (("n0", 1, False, 40, 48, 2), ("n3", 7, False, 40, 48, 2),
+                                    ("n3dtf", 7, True, 24, 24, 1), ("n0big", 1, False, 180, 180, 1)):
+        head = build_head(dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])],
+                               dataset="nuscenes", weight=0.25, code_weights=[1.0] * 10,
+                               common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2),
+                                             "vel": (2, 2)},
+                               share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=False,
+                               sparse=False, dense=dense, bev_map=False, forecast_feature=False, classify=False,
+                               wide_head=False)).eval()
+        rng = np.random.default_rng(21 + T + H)
+        ntask = T if dense else 1
+        preds = []
+        for ti in range(ntask):
+            # clustered heat-map so that NMS has real work: smooth blobs + noise, ~5-10 % of cells pass 0.1
+            hm = rng.standard_normal((B, 1, H, W)).astype(np.float32) * 1.2 - 3.6
+            pd = dict(reg=rng.uniform(0, 1, (B, 2, H, W)), height=rng.normal(-1, 0.5, (B, 1, H, W)),
+                      dim=rng.normal([[[0.7]], [[1.5]], [[0.5]]], 0.15, (B, 3, H, W)),
+                      rot=rng.standard_normal((B, 2, H, W)),
+                      vel=rng.standard_normal((B, 2 if dense else 2 * T, H, W)), hm=hm)
+            preds.append({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in pd.items()})
+        for ti, pd in enumerate(preds):
+            for k, v in pd.items():
+                out["%s_in_t%d_%s" % (name, ti, k)] = v.numpy().copy()
+        example = {"metadata": [None] * B}
+        rets = head.predict(example, [dict(p) for p in preds], test_cfg)
+        for b, r in enumerate(rets):
+            out["%s_out_b%d_boxes" % (name, b)] = r["box3d_lidar"].numpy()
+            out["%s_out_b%d_scores" % (name, b)] = r["scores"].numpy()
+            out["%s_out_b%d_labels" % (name, b)] = r["label_preds"].numpy()
+            print("predict", name, b, r["box3d_lidar"].shape, np.bincount(r["label_preds"].numpy()))
+    save("predict.npz", **out)
+
+
+def gen_iou():
+    """IoU matrices from the reference's own compiled iou3d_cpu.cpp (oracle/_ref)."""
+    rng = np.random.default_rng(31)
+    n = 96
+    a = np.zeros((n, 7), np.float32)
+    a[:, 0:2] = rng.uniform(-6, 6, (n, 2))
+    a[:, 2] = rng.uniform(-2, 0, n)
+    a[:, 3] = rng.uniform(1.5, 5, n)
+    a[:, 4] = rng.uniform(1.0, 2.5, n)
+    a[:, 5] = rng.uniform(1, 2, n)
+    a[:, 6] = rng.uniform(-2 * np.pi, 2 * np.pi, n)
+    b = a.copy()
+    rng.shuffle(b)
+    b[:, 0:2] += rng.normal(0, 0.4, (n, 2)).astype(np.float32)
+    b[:, 6] += rng.normal(0, 0.2, n).astype(np.float32)
+    # adversarial: identical, touching edges, nested, axis-aligned, angle wrap
+    adv = np.array([[0, 0, 0, 4, 2, 1.5, 0], [1, 0, 0, 4, 2, 1.5, 0.3], [0, 0, 0, 4, 2, 1.5, 0],
+                    [4, 0, 0, 4, 2, 1.5, 0], [0, 0, 0, 1, 0.5, 1.5, 0.2], [0, 2, 0, 4, 2, 1.5, 0],
+                    [0, 0, 0, 4, 2, 1.5, np.pi], [0, 0, 0, 4, 2, 1.5, 2 * np.pi + 0.1],
+                    [0, 0, 0, 2, 2, 1, np.pi / 4], [0.5, 0.5, 0, 2, 2, 1, -np.pi / 4],
+                    [30, 30, 0, 4, 2, 1.5, 1.0], [0, 0, 0, 4, 2, 1.5, np.pi / 2]], np.float32)
+    a = np.concatenate([a, adv])
+    b = np.concatenate([b, adv[::-1]])
+    iou = oops.ref_boxes_iou_bev(a, b)
+    mine = oops.boxes_iou_bev(a, b)
+    print("iou: ref vs restatement max abs diff", np.abs(iou - mine).max(), "bit-equal:", np.array_equal(iou, mine))
+    ka = oops.ref_boxes_iou_bev(adv[:2], adv[:2])
+    print("known answers", ka[0, 0], ka[0, 1])
+    save("iou.npz", a=a, b=b, iou=iou)
+
+
+def gen_backbone():
+    """The reference's UNMODIFIED scn.py (SpMiddleResNetFHD) driven over oracle/spconv_api.py: pins topology
+    (layer order, which convs carry bias, indice_key reuse, residual wiring, dense() view), not spconv maths."""
+    from det3d.models import build_backbone
+    from det3d.ops.point_cloud.point_cloud_ops import points_to_voxel
+
+    bb = build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5, ds_factor=8)).eval()
+    sd = seeded_state_dict(bb, 41)
+    bb.load_state_dict(sd, strict=False)
+    keys = {k: tuple(v.shape) for k, v in bb.state_dict().items()}
+    grid = [64, 64, 40]
+    rg = [-2.4, -2.4, -5.0, 2.4, 2.4, 3.0]
+    vs = [0.075, 0.075, 0.2]
+    coors, feats = [], []
+    for b in range(2):
+        rng = np.random.default_rng(50 + b)
+        pts = np.zeros((2500, 5), np.float32)
+        pts[:, 0:2] = rng.uniform(-2.4, 2.4, (2500, 2))
+        pts[:, 2] = np.where(rng.random(2500) < 0.6, -1.84 + rng.normal(0, 0.05, 2500), rng.uniform(-5, 3, 2500))
+        pts[:, 3] = rng.uniform(0, 1, 2500)
+        pts[:, 4] = rng.integers(0, 10, 2500) * 0.05
+        v, c, n = points_to_voxel(pts, np.array(vs, np.float32), np.array(rg, np.float32), 10, True, 5000)
+        feats.append(v.sum(1) / n[:, None].astype(np.float32))
+        coors.append(np.pad(c, ((0, 0), (1, 0)), constant_values=b))
+    feats = np.concatenate(feats).astype(np.float32)
+    coors = np.concatenate(coors).astype(np.int32)
+    with torch.no_grad():
+        y, ms = bb(torch.from_numpy(feats), torch.from_numpy(coors), 2, grid)
+    print("backbone", feats.shape, "->", tuple(y.shape), {k: v.features.shape[0] for k, v in ms.items()})
+    out = dict(feats=feats, coors=coors, grid=np.array(grid), y=y.numpy(),
+               keys=np.array(sorted(keys)), shapes=np.array([str(keys[k]) for k in sorted(keys)]))
+    for k, v in ms.items():
+        order = np.lexsort(v.indices.numpy().T[::-1])
+        out["ms_%s_idx" % k] = v.indices.numpy()[order]
+        out["ms_%s_feat_sum" % k] = v.features.numpy()[order].sum(1)
+    save("backbone.npz", **out)
+
+
+if __name__ == "__main__":
+    install_shims()
+    sys.path.insert(0, REF)
+    which = sys.argv[1:] or ["voxelizer", "configs", "dense", "predict", "iou", "backbone"]
+    for w in which:
+        {"voxelizer": gen_voxelizer, "configs": gen_configs, "dense": gen_dense_nets, "predict": gen_predict,
+         "iou": gen_iou, "backbone": gen_backbone}[w]()
