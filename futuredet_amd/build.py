@@ -1,0 +1,52 @@
+"""Builds futuredet_amd/libfuturedet_hip.so (gfx950 only) with hipcc.  In-tree so the .so travels with the repo."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libfuturedet_hip.so")
+SOURCES = ["fd_error.hip", "fd_voxelize.hip", "fd_index.hip", "fd_spconv.hip", "fd_densify.hip", "fd_decode.hip"]
+# geometry / voxel membership follow the reference's operation order: no fma contraction there
+EXTRA = {"fd_decode.hip": ["-ffp-contract=off"], "fd_voxelize.hip": ["-ffp-contract=off"]}
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isfile(c) or c == "hipcc"):
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.isfile(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "futuredet_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    objdir = os.path.join(HERE, "csrc", "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-c",
+               os.path.join(CSRC, src), "-o", obj] + EXTRA.get(src, [])
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + src)
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

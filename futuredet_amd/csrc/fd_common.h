@@ -1,0 +1,70 @@
+// Shared helpers for the gfx950 kernels of libfuturedet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/futuredet_hip.h"
+
+namespace fd {
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return FD_ELAUNCH;
+    }
+    return FD_OK;
+}
+
+#define FD_REQUIRE(cond, ...)           \
+    do {                                \
+        if (!(cond)) {                  \
+            fd::set_error(__VA_ARGS__); \
+            return FD_EINVAL;           \
+        }                               \
+    } while (0)
+
+inline hipStream_t as_stream(fd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- sparse index addressing (see include/futuredet_hip.h) ------------------------------------------
+struct IndexGeom {
+    int B, D, H, W, Ht, Wt;
+    __host__ __device__ int64_t num_cols() const { return (int64_t)B * Ht * Wt * 64; }
+};
+__host__ __device__ inline IndexGeom make_geom(int B, int D, int H, int W) {
+    IndexGeom g;
+    g.B = B; g.D = D; g.H = H; g.W = W;
+    g.Ht = (H + 7) >> 3; g.Wt = (W + 7) >> 3;
+    return g;
+}
+__host__ __device__ inline int64_t col_of(const IndexGeom &g, int b, int y, int x) {
+    return ((((int64_t)b * g.Ht + (y >> 3)) * g.Wt + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7);
+}
+__device__ inline void col_to_byx(const IndexGeom &g, int64_t col, int &b, int &y, int &x) {
+    int in = (int)(col & 63);
+    int64_t t = col >> 6;
+    int tx = (int)(t % g.Wt);
+    t /= g.Wt;
+    int ty = (int)(t % g.Ht);
+    b = (int)(t / g.Ht);
+    y = ty * 8 + (in >> 3);
+    x = tx * 8 + (in & 7);
+}
+
+// XCD-aware block remap (8 XCDs, round-robin dispatch): consecutive logical tiles land on one XCD so
+// spatially adjacent tiles share an L2.  Bijective for any grid size.
+__device__ inline unsigned xcd_swizzle(unsigned bid, unsigned nblocks) {
+    const unsigned nx = 8;
+    unsigned per = nblocks / nx, rem = nblocks % nx;
+    unsigned xcd = bid % nx, loc = bid / nx;
+    // XCD x owns per(+1 if x<rem) logical tiles
+    unsigned start = xcd * per + (xcd < rem ? xcd : rem);
+    return start + loc;
+}
+
+}  // namespace fd

@@ -1,0 +1,67 @@
+// Densify for gfx950: SparseConvTensor.dense() + view(N, C*D, H, W) (det3d/models/backbones/scn.py:165-168).
+// Output-stationary: one wave per (b,y,x) BEV cell reads the cell's occupancy word and writes all C*D output
+// channels exactly once (zeros where inactive), so no memset pass and no scatter; element strides select NCHW
+// or channels-last memory.
+#include "fd_common.h"
+
+namespace {
+
+__device__ inline unsigned short f2bf(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <bool IN_BF16, bool OUT_BF16>
+__global__ void __launch_bounds__(256) densify_kernel(const void *__restrict__ feats, int C, const unsigned long long *__restrict__ words,
+                                                      const int *__restrict__ prefix, fd::IndexGeom g, void *__restrict__ out,
+                                                      int64_t sb, int64_t sc, int64_t sy, int64_t sx) {
+    // thread -> (cell, channel): channel index fastest so channels-last stores coalesce; for NCHW the x index
+    // of neighbouring cells is 8 apart in the tiled column order, writes go through L2 either way.
+    const int CD = C * g.D;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t cell = t / CD;
+    int ch = (int)(t - cell * CD);  // ch = c*D + d
+    if (cell >= g.num_cols()) return;
+    int b, y, x;
+    fd::col_to_byx(g, cell, b, y, x);
+    if (y >= g.H || x >= g.W) return;
+    const int c = ch / g.D, d = ch - c * g.D;
+    const unsigned long long w = words[cell];
+    float v = 0.0f;
+    if ((w >> d) & 1ull) {
+        const int row = prefix[cell] + __popcll(w & ((1ull << d) - 1ull));
+        if (IN_BF16) v = __uint_as_float(((unsigned)reinterpret_cast<const unsigned short *>(feats)[(int64_t)row * C + c]) << 16);
+        else v = reinterpret_cast<const float *>(feats)[(int64_t)row * C + c];
+    }
+    const int64_t o = b * sb + ch * sc + y * sy + x * sx;
+    if (OUT_BF16) reinterpret_cast<unsigned short *>(out)[o] = f2bf(v);
+    else reinterpret_cast<float *>(out)[o] = v;
+}
+
+}  // namespace
+
+extern "C" int fd_densify(const void *feats, int c, int dtype, const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W,
+                          void *out, int out_dtype, int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x,
+                          fd_stream_t stream) {
+    FD_REQUIRE(feats && words && prefix && out, "fd_densify: null argument");
+    FD_REQUIRE(c > 0 && D > 0 && D <= 64, "fd_densify: bad shape");
+    fd::IndexGeom g = fd::make_geom(B, D, H, W);
+    int64_t total = g.num_cols() * c * D;
+    dim3 grid((unsigned)((total + 255) / 256));
+    const unsigned long long *wd = (const unsigned long long *)words;
+    hipStream_t s = fd::as_stream(stream);
+    if (dtype == 0 && out_dtype == 0)
+        hipLaunchKernelGGL((densify_kernel<false, false>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x);
+    else if (dtype == 0 && out_dtype == 1)
+        hipLaunchKernelGGL((densify_kernel<false, true>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x);
+    else if (dtype == 1 && out_dtype == 0)
+        hipLaunchKernelGGL((densify_kernel<true, false>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x);
+    else if (dtype == 1 && out_dtype == 1)
+        hipLaunchKernelGGL((densify_kernel<true, true>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x);
+    else {
+        fd::set_error("fd_densify: bad dtype");
+        return FD_EINVAL;
+    }
+    return fd::check_launch("fd_densify");
+}

@@ -1,0 +1,341 @@
+// Sparse index (column occupancy words + prefix counts) and output-stationary rulebook for gfx950.
+//
+// Replaces spconv 1.0's indice-pair generation (called implicitly from det3d/models/backbones/scn.py:99-141).
+// Instead of a hash table + pair lists, an active set is a bitmap: one 64-bit word per (b,y,x) column, bit z
+// set when the voxel is active.  An exclusive scan of the popcounts gives every active voxel a row number,
+// so rows come out spatially sorted (8x8 column tiles, z fastest) with no sort and no hash probing;
+// lookups are two loads + a popcount; the downsampled set of a strided conv is an OR of shifted bits.
+#include "fd_common.h"
+
+namespace {
+
+using fd::IndexGeom;
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__global__ void __launch_bounds__(256) idx_mark(const int *__restrict__ coords, const int *__restrict__ n_dev, int64_t n_max,
+                                                IndexGeom g, unsigned long long *__restrict__ words) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = n_dev ? (int64_t)n_dev[0] : n_max;
+    if (n > n_max) n = n_max;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];  // (b,z,y,x)
+    if (c.x < 0 || c.x >= g.B || c.y < 0 || c.y >= g.D || c.z < 0 || c.z >= g.H || c.w < 0 || c.w >= g.W) return;
+    atomicOr(&words[fd::col_of(g, c.x, c.z, c.w)], 1ull << c.y);
+}
+
+struct DownParams {
+    int k[3], s[3], p[3];
+};
+
+// one thread per input column
+__global__ void __launch_bounds__(256) idx_down(const unsigned long long *__restrict__ in_words, IndexGeom gi, IndexGeom go,
+                                                DownParams dp, unsigned long long *__restrict__ out_words) {
+    int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= gi.num_cols()) return;
+    unsigned long long w = in_words[col];
+    if (!w) return;
+    int b, y, x;
+    fd::col_to_byx(gi, col, b, y, x);
+    // z axis: out bit oz set iff some active z and tap kz with z + p - kz = oz * s
+    unsigned long long zo = 0;
+    while (w) {
+        int z = __builtin_ctzll(w);
+        w &= w - 1;
+        for (int kz = 0; kz < dp.k[0]; ++kz) {
+            int t = z + dp.p[0] - kz;
+            if (t < 0 || t % dp.s[0]) continue;
+            int oz = t / dp.s[0];
+            if (oz < go.D) zo |= 1ull << oz;
+        }
+    }
+    if (!zo) return;
+    for (int ky = 0; ky < dp.k[1]; ++ky) {
+        int ty = y + dp.p[1] - ky;
+        if (ty < 0 || ty % dp.s[1]) continue;
+        int oy = ty / dp.s[1];
+        if (oy >= go.H) continue;
+        for (int kx = 0; kx < dp.k[2]; ++kx) {
+            int tx = x + dp.p[2] - kx;
+            if (tx < 0 || tx % dp.s[2]) continue;
+            int ox = tx / dp.s[2];
+            if (ox >= go.W) continue;
+            atomicOr(&out_words[fd::col_of(go, b, oy, ox)], zo);
+        }
+    }
+}
+
+__device__ inline int block_excl_scan(int v, int &total, int *sm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int iv = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int u = __shfl_up(iv, off);
+        if (lane >= off) iv += u;
+    }
+    if (lane == 63) sm[wave] = iv;
+    __syncthreads();
+    int wo = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        if (w < wave) wo += sm[w];
+        tot += sm[w];
+    }
+    __syncthreads();
+    total = tot;
+    return wo + iv - v;
+}
+
+__global__ void __launch_bounds__(kScanThreads) idx_scan1(const unsigned long long *__restrict__ words, int64_t ncols,
+                                                          int *__restrict__ bsum) {
+    __shared__ int sm[4];
+    int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < ncols) s += __popcll(words[base + k]);
+    int total;
+    block_excl_scan(s, total, sm);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kScanThreads) idx_scan2(int *__restrict__ bsum, int nblocks, int *__restrict__ n_active) {
+    __shared__ int sm[4];
+    int run = 0;
+    for (int base = 0; base < nblocks; base += kScanThreads) {
+        int j = base + threadIdx.x;
+        int v = j < nblocks ? bsum[j] : 0;
+        int total;
+        int e = block_excl_scan(v, total, sm);
+        if (j < nblocks) bsum[j] = run + e;
+        run += total;
+    }
+    if (threadIdx.x == 0) n_active[0] = run;
+}
+
+__global__ void __launch_bounds__(kScanThreads) idx_scan3(const unsigned long long *__restrict__ words, int64_t ncols,
+                                                          const int *__restrict__ bsum, int *__restrict__ prefix) {
+    __shared__ int sm[4];
+    int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int pc[kScanItems];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        pc[k] = (base + k < ncols) ? __popcll(words[base + k]) : 0;
+        s += pc[k];
+    }
+    int total;
+    int e = block_excl_scan(s, total, sm) + bsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < ncols) prefix[base + k] = e;
+        e += pc[k];
+    }
+}
+
+__global__ void __launch_bounds__(256) idx_coords(const unsigned long long *__restrict__ words, const int *__restrict__ prefix,
+                                                  IndexGeom g, int *__restrict__ coords) {
+    int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= g.num_cols()) return;
+    unsigned long long w = words[col];
+    if (!w) return;
+    int b, y, x;
+    fd::col_to_byx(g, col, b, y, x);
+    int row = prefix[col];
+    while (w) {
+        int z = __builtin_ctzll(w);
+        w &= w - 1;
+        reinterpret_cast<int4 *>(coords)[row++] = make_int4(b, z, y, x);
+    }
+}
+
+__device__ inline int lookup_row(const unsigned long long *words, const int *prefix, const IndexGeom &g, int b, int z, int y,
+                                 int x) {
+    if (z < 0 || z >= g.D || y < 0 || y >= g.H || x < 0 || x >= g.W) return -1;
+    int64_t col = fd::col_of(g, b, y, x);
+    unsigned long long w = words[col];
+    if (!((w >> z) & 1ull)) return -1;
+    return prefix[col] + __popcll(w & ((1ull << z) - 1ull));
+}
+
+__global__ void __launch_bounds__(256) idx_lookup(const unsigned long long *__restrict__ words, const int *__restrict__ prefix,
+                                                  IndexGeom g, const int *__restrict__ coords, const int *__restrict__ n_dev,
+                                                  int64_t n_max, int *__restrict__ row_of) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = n_dev ? (int64_t)n_dev[0] : n_max;
+    if (n > n_max) n = n_max;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    int r = -1;
+    if (c.x >= 0 && c.x < g.B) r = lookup_row(words, prefix, g, c.x, c.y, c.z, c.w);
+    row_of[i] = r;
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(256) rows_permute(const float *__restrict__ src, int c_src, const int *__restrict__ row_of,
+                                                    const int *__restrict__ n_dev, int64_t n_max, void *__restrict__ dst,
+                                                    int c_dst) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = n_dev ? (int64_t)n_dev[0] : n_max;
+    if (n > n_max) n = n_max;
+    int64_t i = t / c_dst;
+    int ch = (int)(t % c_dst);
+    if (i >= n) return;
+    int r = row_of[i];
+    if (r < 0) return;
+    float v = ch < c_src ? src[i * c_src + ch] : 0.0f;
+    if (BF16) {
+        unsigned u = __float_as_uint(v);
+        u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+        reinterpret_cast<unsigned short *>(dst)[(int64_t)r * c_dst + ch] = (unsigned short)(u >> 16);
+    } else {
+        reinterpret_cast<float *>(dst)[(int64_t)r * c_dst + ch] = v;
+    }
+}
+
+// one thread per (output row, (ky,kx) column pair): fills the kz taps of that column from one word load
+__global__ void __launch_bounds__(256) rulebook_kernel(const unsigned long long *__restrict__ in_words, const int *__restrict__ in_prefix,
+                                                       IndexGeom gi, const int *__restrict__ out_coords, const int *__restrict__ n_out_dev,
+                                                       int64_t nbr_stride, DownParams dp, int *__restrict__ nbr) {
+    const int kyx = dp.k[1] * dp.k[2];
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t o = t % nbr_stride;  // rows fastest -> coalesced nbr writes
+    int q = (int)(t / nbr_stride);
+    if (q >= kyx) return;
+    const int ky = q / dp.k[2], kx = q % dp.k[2];
+    const int n_out = n_out_dev[0];
+    if (o >= n_out) {
+        for (int kz = 0; kz < dp.k[0]; ++kz) nbr[((int64_t)(kz * dp.k[1] + ky) * dp.k[2] + kx) * nbr_stride + o] = -1;
+        return;
+    }
+    const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];  // (b,z,y,x)
+    const int iy = c.z * dp.s[1] - dp.p[1] + ky;
+    const int ix = c.w * dp.s[2] - dp.p[2] + kx;
+    unsigned long long w = 0;
+    int base = 0;
+    if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) {
+        int64_t col = fd::col_of(gi, c.x, iy, ix);
+        w = in_words[col];
+        if (w) base = in_prefix[col];
+    }
+    for (int kz = 0; kz < dp.k[0]; ++kz) {
+        int iz = c.y * dp.s[0] - dp.p[0] + kz;
+        int r = -1;
+        if (iz >= 0 && iz < gi.D && ((w >> iz) & 1ull)) r = base + __popcll(w & ((1ull << iz) - 1ull));
+        nbr[((int64_t)(kz * dp.k[1] + ky) * dp.k[2] + kx) * nbr_stride + o] = r;
+    }
+}
+
+int fill_dp(DownParams &dp, const int *k, const int *s, const int *p) {
+    for (int i = 0; i < 3; ++i) {
+        dp.k[i] = k[i]; dp.s[i] = s[i]; dp.p[i] = p[i];
+        if (k[i] < 1 || k[i] > 3 || s[i] < 1 || s[i] > 4 || p[i] < 0 || p[i] > 2) return -1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t fd_index_num_cols(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return fd::make_geom(B, 1, H, W).num_cols();
+}
+
+extern "C" size_t fd_index_workspace_bytes(int64_t num_cols) {
+    return fd::align_up(sizeof(int) * (size_t)((num_cols + kScanTile - 1) / kScanTile + 1), 256);
+}
+
+extern "C" int fd_index_mark(const int32_t *coords, const int32_t *n_dev, int64_t n_max, int B, int D, int H, int W,
+                             uint64_t *words, fd_stream_t stream) {
+    FD_REQUIRE(coords && words, "fd_index_mark: null argument");
+    FD_REQUIRE(B > 0 && D > 0 && D <= 64 && H > 0 && W > 0, "fd_index_mark: bad grid (D must be <= 64)");
+    if (n_max <= 0) return FD_OK;
+    IndexGeom g = fd::make_geom(B, D, H, W);
+    hipLaunchKernelGGL(idx_mark, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, fd::as_stream(stream), coords, n_dev, n_max, g,
+                       (unsigned long long *)words);
+    return fd::check_launch("fd_index_mark");
+}
+
+extern "C" int fd_index_downsample(const uint64_t *in_words, int B, int D, int H, int W, const int *ksize3, const int *stride3,
+                                   const int *pad3, uint64_t *out_words, fd_stream_t stream) {
+    FD_REQUIRE(in_words && out_words && ksize3 && stride3 && pad3, "fd_index_downsample: null argument");
+    DownParams dp;
+    FD_REQUIRE(fill_dp(dp, ksize3, stride3, pad3) == 0, "fd_index_downsample: unsupported kernel/stride/pad");
+    IndexGeom gi = fd::make_geom(B, D, H, W);
+    int od[3];
+    const int in[3] = {D, H, W};
+    for (int i = 0; i < 3; ++i) od[i] = (in[i] + 2 * dp.p[i] - (dp.k[i] - 1) - 1) / dp.s[i] + 1;
+    FD_REQUIRE(od[0] > 0 && od[0] <= 64 && od[1] > 0 && od[2] > 0, "fd_index_downsample: bad output grid");
+    IndexGeom go = fd::make_geom(B, od[0], od[1], od[2]);
+    int64_t ncols = gi.num_cols();
+    hipLaunchKernelGGL(idx_down, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, fd::as_stream(stream),
+                       (const unsigned long long *)in_words, gi, go, dp, (unsigned long long *)out_words);
+    return fd::check_launch("fd_index_downsample");
+}
+
+extern "C" int fd_index_scan(const uint64_t *words, int64_t num_cols, int32_t *prefix, int32_t *n_active_dev, void *workspace,
+                             size_t workspace_bytes, fd_stream_t stream_) {
+    FD_REQUIRE(words && prefix && n_active_dev && workspace, "fd_index_scan: null argument");
+    FD_REQUIRE(num_cols > 0, "fd_index_scan: empty index");
+    if (workspace_bytes < fd_index_workspace_bytes(num_cols)) {
+        fd::set_error("fd_index_scan: workspace too small");
+        return FD_EWORKSPACE;
+    }
+    hipStream_t stream = fd::as_stream(stream_);
+    int nb = (int)((num_cols + kScanTile - 1) / kScanTile);
+    int *bsum = (int *)workspace;
+    hipLaunchKernelGGL(idx_scan1, dim3(nb), dim3(kScanThreads), 0, stream, (const unsigned long long *)words, num_cols, bsum);
+    hipLaunchKernelGGL(idx_scan2, dim3(1), dim3(kScanThreads), 0, stream, bsum, nb, n_active_dev);
+    hipLaunchKernelGGL(idx_scan3, dim3(nb), dim3(kScanThreads), 0, stream, (const unsigned long long *)words, num_cols, bsum, prefix);
+    return fd::check_launch("fd_index_scan");
+}
+
+extern "C" int fd_index_coords(const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W, int32_t *coords,
+                               fd_stream_t stream) {
+    FD_REQUIRE(words && prefix && coords, "fd_index_coords: null argument");
+    IndexGeom g = fd::make_geom(B, D, H, W);
+    int64_t ncols = g.num_cols();
+    hipLaunchKernelGGL(idx_coords, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, fd::as_stream(stream),
+                       (const unsigned long long *)words, prefix, g, coords);
+    return fd::check_launch("fd_index_coords");
+}
+
+extern "C" int fd_index_lookup(const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W, const int32_t *coords_in,
+                               const int32_t *n_dev, int64_t n_max, int32_t *row_of, fd_stream_t stream) {
+    FD_REQUIRE(words && prefix && coords_in && row_of, "fd_index_lookup: null argument");
+    if (n_max <= 0) return FD_OK;
+    IndexGeom g = fd::make_geom(B, D, H, W);
+    hipLaunchKernelGGL(idx_lookup, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, fd::as_stream(stream),
+                       (const unsigned long long *)words, prefix, g, coords_in, n_dev, n_max, row_of);
+    return fd::check_launch("fd_index_lookup");
+}
+
+extern "C" int fd_rows_permute(const float *src, int c_src, const int32_t *row_of, const int32_t *n_dev, int64_t n_max, void *dst,
+                               int c_dst, int dst_bf16, fd_stream_t stream) {
+    FD_REQUIRE(src && row_of && dst, "fd_rows_permute: null argument");
+    FD_REQUIRE(c_src > 0 && c_dst >= c_src, "fd_rows_permute: c_dst < c_src");
+    if (n_max <= 0) return FD_OK;
+    int64_t total = n_max * c_dst;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dst_bf16)
+        hipLaunchKernelGGL(rows_permute<true>, grid, dim3(256), 0, fd::as_stream(stream), src, c_src, row_of, n_dev, n_max, dst, c_dst);
+    else
+        hipLaunchKernelGGL(rows_permute<false>, grid, dim3(256), 0, fd::as_stream(stream), src, c_src, row_of, n_dev, n_max, dst, c_dst);
+    return fd::check_launch("fd_rows_permute");
+}
+
+extern "C" int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int Din, int Hin, int Win,
+                           const int32_t *out_coords, const int32_t *n_out_dev, int64_t nbr_stride, const int *ksize3,
+                           const int *stride3, const int *pad3, int32_t *nbr, fd_stream_t stream) {
+    FD_REQUIRE(in_words && in_prefix && out_coords && n_out_dev && nbr && ksize3 && stride3 && pad3, "fd_rulebook: null argument");
+    DownParams dp;
+    FD_REQUIRE(fill_dp(dp, ksize3, stride3, pad3) == 0, "fd_rulebook: unsupported kernel/stride/pad");
+    if (nbr_stride <= 0) return FD_OK;
+    IndexGeom gi = fd::make_geom(B, Din, Hin, Win);
+    int64_t total = nbr_stride * dp.k[1] * dp.k[2];
+    hipLaunchKernelGGL(rulebook_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, fd::as_stream(stream),
+                       (const unsigned long long *)in_words, in_prefix, gi, out_coords, n_out_dev, nbr_stride, dp, nbr);
+    return fd::check_launch("fd_rulebook");
+}

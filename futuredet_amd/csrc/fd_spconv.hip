@@ -1,0 +1,339 @@
+// Sparse convolution apply for gfx950: output-stationary gather + MFMA GEMM, no scatter, no atomics.
+//
+// Replaces spconv 1.0's indice_conv / indice_subm_conv (gather -> per-tap cuBLAS GEMM -> scatter-add) used by
+// the 21 convolutions of det3d/models/backbones/scn.py:99-141, fused with the folded BatchNorm1d, the residual
+// add and the ReLU that follow them (scn.py:67-78).
+//
+//   out[o,:] = act( sum_k in[nbr[k][o],:] @ W[k] + bias (+ residual[o,:]) )
+//
+// Work decomposition: a wave owns 16*RG consecutive output rows (rows are spatially sorted by the index, so
+// the rows a wave gathers are close in memory) and all COUT columns; accumulators stay in registers for all K
+// taps.  The rulebook tile of the workgroup ([K][64*RG] int32) is staged once through LDS.  Per tap and per
+// 16-row group a wave-wide ballot skips the MFMAs when no row of the group has that neighbour.  A operands are
+// gathered straight into MFMA fragment layout with one 16-byte load per lane (row = lane&15, 16-byte chunk =
+// lane>>4); B operands come from weights pre-packed in fragment order, one coalesced 1 KiB load per wave
+// instruction (L2-resident: at most 1.8 MB per layer).  fp32 uses v_mfma_f32_16x16x4_f32 (exact fp32 fma
+// chain), bf16 uses v_mfma_f32_16x16x32_bf16 / 16x16x16 with fp32 accumulation.
+#include "fd_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline unsigned short f2bf(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ inline float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+constexpr int kMaxTaps = 27;
+
+// ------------------------------------------------------------------------------------------------- fp32
+template <int CIN, int COUT, int RG>
+__global__ void __launch_bounds__(256) spconv_f32(const float *__restrict__ in, const float4 *__restrict__ wp,
+                                                  const float *__restrict__ bias, const float *__restrict__ residual, int relu,
+                                                  const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
+                                                  float *__restrict__ out) {
+    constexpr int ROWS_B = 64 * RG;  // rows per workgroup
+    constexpr int NB = COUT / 16, NC = CIN / 16;
+    __shared__ int s_nbr[kMaxTaps * ROWS_B];
+    const int tile = fd::xcd_swizzle(blockIdx.x, gridDim.x);
+    const int row0 = tile * ROWS_B;
+    for (int t = threadIdx.x; t < K * ROWS_B; t += 256) {
+        int k = t / ROWS_B, r = t - k * ROWS_B;
+        int64_t o = (int64_t)row0 + r;
+        s_nbr[t] = (o < nbr_stride) ? nbr[(int64_t)k * nbr_stride + o] : -1;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int wrow = wave * 16 * RG;
+    if (row0 + wrow >= n_out) return;
+
+    f32x4 acc[RG][NB];
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[g][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k = 0; k < K; ++k) {
+        int idx[RG];
+        bool any[RG];
+        bool any_all = false;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            idx[g] = s_nbr[k * ROWS_B + wrow + g * 16 + lrow];
+            any[g] = __ballot(idx[g] >= 0) != 0ull;
+            any_all = any_all || any[g];
+        }
+        if (!any_all) continue;
+        const float4 *wk = wp + (int64_t)k * NC * NB * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float4 a[RG];
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                a[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx[g] >= 0) a[g] = *reinterpret_cast<const float4 *>(in + (int64_t)idx[g] * CIN + c * 16 + lq * 4);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float4 b = wk[(c * NB + nb) * 64];
+#pragma unroll
+                for (int g = 0; g < RG; ++g) {
+                    if (any[g]) {
+                        acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].x, b.x, acc[g][nb], 0, 0, 0);
+                        acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].y, b.y, acc[g][nb], 0, 0, 0);
+                        acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].z, b.z, acc[g][nb], 0, 0, 0);
+                        acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g].w, b.w, acc[g][nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // epilogue: C/D layout col = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = nb * 16 + lrow;
+            const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wrow + g * 16 + lq * 4 + r;
+                if (row < n_out) {
+                    float v = acc[g][nb][r] + bv;
+                    if (residual) v += residual[(int64_t)row * COUT + col];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    out[(int64_t)row * COUT + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- bf16
+// CIN >= 32: chunks of 32 channels through v_mfma_f32_16x16x32_bf16 (8 bf16 = 16 B per lane).
+// CIN == 16: one chunk of 16 channels through v_mfma_f32_16x16x16_bf16 (4 bf16 = 8 B per lane).
+template <int CIN, int COUT, int RG>
+__global__ void __launch_bounds__(256) spconv_bf16(const unsigned short *__restrict__ in, const void *__restrict__ wp_,
+                                                   const float *__restrict__ bias, const unsigned short *__restrict__ residual,
+                                                   int relu, const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
+                                                   unsigned short *__restrict__ out) {
+    constexpr int ROWS_B = 64 * RG;
+    constexpr int NB = COUT / 16;
+    constexpr bool WIDE = CIN >= 32;
+    constexpr int NC = WIDE ? CIN / 32 : 1;
+    __shared__ int s_nbr[kMaxTaps * ROWS_B];
+    const int tile = fd::xcd_swizzle(blockIdx.x, gridDim.x);
+    const int row0 = tile * ROWS_B;
+    for (int t = threadIdx.x; t < K * ROWS_B; t += 256) {
+        int k = t / ROWS_B, r = t - k * ROWS_B;
+        int64_t o = (int64_t)row0 + r;
+        s_nbr[t] = (o < nbr_stride) ? nbr[(int64_t)k * nbr_stride + o] : -1;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int wrow = wave * 16 * RG;
+    if (row0 + wrow >= n_out) return;
+
+    f32x4 acc[RG][NB];
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[g][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k = 0; k < K; ++k) {
+        int idx[RG];
+        bool any[RG];
+        bool any_all = false;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            idx[g] = s_nbr[k * ROWS_B + wrow + g * 16 + lrow];
+            any[g] = __ballot(idx[g] >= 0) != 0ull;
+            any_all = any_all || any[g];
+        }
+        if (!any_all) continue;
+        if constexpr (WIDE) {
+            const bf16x8 *wk = reinterpret_cast<const bf16x8 *>(wp_) + (int64_t)k * NC * NB * 64 + lane;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                bf16x8 a[RG];
+#pragma unroll
+                for (int g = 0; g < RG; ++g) {
+                    uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+                    if (idx[g] >= 0) raw = *reinterpret_cast<const uint4 *>(in + (int64_t)idx[g] * CIN + c * 32 + lq * 8);
+                    a[g] = __builtin_bit_cast(bf16x8, raw);
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8 b = wk[(c * NB + nb) * 64];
+#pragma unroll
+                    for (int g = 0; g < RG; ++g)
+                        if (any[g]) acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[g], b, acc[g][nb], 0, 0, 0);
+                }
+            }
+        } else {
+            const s16x4 *wk = reinterpret_cast<const s16x4 *>(wp_) + (int64_t)k * NB * 64 + lane;
+            s16x4 a[RG];
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                uint2 raw = make_uint2(0u, 0u);
+                if (idx[g] >= 0) raw = *reinterpret_cast<const uint2 *>(in + (int64_t)idx[g] * CIN + lq * 4);
+                a[g] = __builtin_bit_cast(s16x4, raw);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const s16x4 b = wk[nb * 64];
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+                    if (any[g]) acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[g], b, acc[g][nb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = nb * 16 + lrow;
+            const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wrow + g * 16 + lq * 4 + r;
+                if (row < n_out) {
+                    float v = acc[g][nb][r] + bv;
+                    if (residual) v += bf2f(residual[(int64_t)row * COUT + col]);
+                    if (relu) v = fmaxf(v, 0.0f);
+                    out[(int64_t)row * COUT + col] = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
+struct LaunchArgs {
+    const void *in, *wp;
+    const float *bias;
+    const void *residual;
+    int relu;
+    const int *nbr;
+    int64_t nbr_stride;
+    int K, n_out;
+    void *out;
+    hipStream_t stream;
+};
+
+template <int CIN, int COUT, int RG>
+void launch(const LaunchArgs &a, int dtype) {
+    const int rows_b = 64 * RG;
+    dim3 grid((unsigned)((a.n_out + rows_b - 1) / rows_b));
+    if (dtype == 0)
+        hipLaunchKernelGGL((spconv_f32<CIN, COUT, RG>), grid, dim3(256), 0, a.stream, (const float *)a.in, (const float4 *)a.wp, a.bias,
+                           (const float *)a.residual, a.relu, a.nbr, a.nbr_stride, a.K, a.n_out, (float *)a.out);
+    else
+        hipLaunchKernelGGL((spconv_bf16<CIN, COUT, RG>), grid, dim3(256), 0, a.stream, (const unsigned short *)a.in, a.wp, a.bias,
+                           (const unsigned short *)a.residual, a.relu, a.nbr, a.nbr_stride, a.K, a.n_out, (unsigned short *)a.out);
+}
+
+template <int CIN, int COUT>
+void launch_rg(const LaunchArgs &a, int dtype, int rg) {
+    if (rg >= 4) launch<CIN, COUT, 4>(a, dtype);
+    else if (rg == 2) launch<CIN, COUT, 2>(a, dtype);
+    else launch<CIN, COUT, 1>(a, dtype);
+}
+
+int pick_rg(int64_t n_out, int cin, int cout) {
+    const char *e = getenv("FD_SPCONV_RG");  // tuning / test override
+    const int forced = e ? atoi(e) : 0;
+    if (forced > 0) return forced;
+    // enough waves to fill 256 CUs x 4 SIMDs with >= 2 waves each, otherwise favour B-fragment reuse
+    const int64_t want_waves = 256 * 4 * 2;
+    int rg = 4;
+    while (rg > 1 && (n_out + 16 * rg - 1) / (16 * rg) < want_waves) rg >>= 1;
+    if (cin * cout <= 32 * 32 && rg > 2) rg = 2;  // light layers: latency-bound, keep more waves
+    return rg;
+}
+
+}  // namespace
+
+extern "C" size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype) {
+    if (K <= 0 || cin <= 0 || cout <= 0) return 0;
+    return (size_t)K * cin * cout * (dtype == 0 ? 4 : 2);
+}
+
+extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, int dtype, void *dst) {
+    FD_REQUIRE(w && dst, "fd_spconv_pack_weight: null argument");
+    FD_REQUIRE(K >= 1 && K <= kMaxTaps, "fd_spconv_pack_weight: K must be in [1,27]");
+    FD_REQUIRE(cin % 16 == 0 && cout % 16 == 0 && cin >= 16 && cin <= 128 && cout >= 16 && cout <= 128,
+               "fd_spconv_pack_weight: channels must be multiples of 16 in [16,128] (got %d -> %d)", cin, cout);
+    FD_REQUIRE(dtype == 0 || dtype == 1, "fd_spconv_pack_weight: dtype must be 0 (f32) or 1 (bf16)");
+    const int NB = cout / 16;
+    auto W = [&](int k, int ci, int co) { return w[((int64_t)k * cin + ci) * cout + co]; };
+    auto tobf = [](float v) {
+        union { float f; uint32_t u; } cvt;
+        cvt.f = v;
+        uint32_t u = cvt.u;
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    if (dtype == 0) {
+        const int NC = cin / 16;
+        float *d = (float *)dst;
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < NC; ++c)
+                for (int nb = 0; nb < NB; ++nb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j)
+                            d[((((int64_t)k * NC + c) * NB + nb) * 64 + lane) * 4 + j] =
+                                W(k, 16 * c + 4 * (lane >> 4) + j, 16 * nb + (lane & 15));
+    } else if (cin >= 32) {
+        FD_REQUIRE(cin % 32 == 0, "fd_spconv_pack_weight: bf16 needs cin 16 or a multiple of 32");
+        const int NC = cin / 32;
+        uint16_t *d = (uint16_t *)dst;
+        for (int k = 0; k < K; ++k)
+            for (int c = 0; c < NC; ++c)
+                for (int nb = 0; nb < NB; ++nb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j)
+                            d[((((int64_t)k * NC + c) * NB + nb) * 64 + lane) * 8 + j] =
+                                tobf(W(k, 32 * c + 8 * (lane >> 4) + j, 16 * nb + (lane & 15)));
+    } else {
+        uint16_t *d = (uint16_t *)dst;
+        for (int k = 0; k < K; ++k)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j)
+                        d[(((int64_t)k * NB + nb) * 64 + lane) * 4 + j] = tobf(W(k, 4 * (lane >> 4) + j, 16 * nb + (lane & 15)));
+    }
+    return FD_OK;
+}
+
+extern "C" int fd_spconv_apply(const void *in_feats, const void *wpacked, const float *bias, const void *residual, int relu,
+                               const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int cin, int cout, int dtype,
+                               void *out_feats, fd_stream_t stream) {
+    FD_REQUIRE(in_feats && wpacked && nbr && out_feats, "fd_spconv_apply: null argument");
+    FD_REQUIRE(K >= 1 && K <= kMaxTaps, "fd_spconv_apply: K must be in [1,27]");
+    FD_REQUIRE(dtype == 0 || dtype == 1, "fd_spconv_apply: dtype must be 0 (f32) or 1 (bf16)");
+    FD_REQUIRE(n_out >= 0 && n_out <= nbr_stride && n_out < (1ll << 31), "fd_spconv_apply: n_out out of range");
+    if (n_out == 0) return FD_OK;
+    LaunchArgs a{in_feats, wpacked, bias, residual, relu, nbr, nbr_stride, K, (int)n_out, out_feats, fd::as_stream(stream)};
+    const int rg = pick_rg(n_out, cin, cout);
+    const int key = cin * 1000 + cout;
+    switch (key) {
+        case 16016: launch_rg<16, 16>(a, dtype, rg); break;
+        case 16032: launch_rg<16, 32>(a, dtype, rg); break;
+        case 32032: launch_rg<32, 32>(a, dtype, rg); break;
+        case 32064: launch_rg<32, 64>(a, dtype, rg); break;
+        case 64064: launch_rg<64, 64>(a, dtype, rg); break;
+        case 64128: launch_rg<64, 128>(a, dtype, rg); break;
+        case 128128: launch_rg<128, 128>(a, dtype, rg); break;
+        default:
+            fd::set_error("fd_spconv_apply: unsupported channels %d -> %d", cin, cout);
+            return FD_EINVAL;
+    }
+    return fd::check_launch("fd_spconv_apply");
+}

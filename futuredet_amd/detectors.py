@@ -1,0 +1,155 @@
+"""Detectors (det3d/models/detectors/{base,single_stage,voxelnet}.py).
+
+VoxelNet.forward(example, return_loss) keeps the reference contract (voxelnet.py:33-56).  In addition
+``forward_points`` is the device-resident fast path the benchmark measures: raw point clouds (device tensors)
+-> fused voxelizer/mean -> sparse backbone -> neck -> head -> decode, with one host read of the five
+active-row counts and one of the final detections."""
+import numpy as np
+import torch
+from torch import nn
+
+from . import hip_ops, registry, sparse
+from .registry import DETECTORS
+
+
+class BaseDetector(nn.Module):
+    @property
+    def with_neck(self):
+        return hasattr(self, "neck") and self.neck is not None
+
+    @property
+    def with_reader(self):
+        return hasattr(self, "reader") and self.reader is not None
+
+
+@DETECTORS.register_module
+class SingleStageDetector(BaseDetector):
+    def __init__(self, reader, backbone, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.reader = registry.build_reader(reader)
+        self.backbone = registry.build_backbone(backbone)
+        if neck is not None:
+            self.neck = registry.build_neck(neck)
+        self.bbox_head = registry.build_head(bbox_head)
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.init_weights(pretrained=pretrained)
+
+    def init_weights(self, pretrained=None):
+        if pretrained is None:
+            return
+        try:
+            load_checkpoint(self, pretrained, strict=False)
+            print("init weight from {}".format(pretrained))
+        except Exception:
+            print("no pretrained model at {}".format(pretrained))
+
+
+def load_checkpoint(model, filename, map_location="cpu", strict=False):
+    """det3d/torchie/trainer/checkpoint.py:122-173: accepts {state_dict: ...} or a bare dict, strips "module."."""
+    ckpt = torch.load(filename, map_location=map_location)
+    sd = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    model.load_state_dict(sd, strict=strict)
+    return ckpt
+
+
+@DETECTORS.register_module
+class VoxelNet(SingleStageDetector):
+    def __init__(self, reader, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__(reader, backbone, neck, bbox_head, train_cfg, test_cfg, pretrained)
+
+    def set_precision(self, dtype=torch.float32, channels_last=None):
+        """fp32 (default) or bf16 conv features/weights with fp32 accumulation; voxelizer, indexes, decode and
+        NMS always stay fp32/int."""
+        if channels_last is None:
+            channels_last = dtype != torch.float32
+        self.backbone.compute_dtype = dtype
+        self.backbone.dense_channels_last = channels_last
+        self.neck.compute_dtype = dtype
+        self.neck.channels_last = channels_last
+        self.bbox_head.compute_dtype = dtype
+        self.bbox_head.channels_last = channels_last
+        return self
+
+    def extract_feat(self, data):
+        input_features = self.reader(data["features"], data["num_voxels"])
+        x, voxel_feature = self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
+        if self.with_neck:
+            x = self.neck(x)
+        return x, voxel_feature
+
+    def forward(self, example, return_loss=True, **kwargs):
+        voxels = example["voxels"]
+        coordinates = example["coordinates"]
+        num_points_in_voxel = example["num_points"]
+        num_voxels = example["num_voxels"]
+        batch_size = len(num_voxels)
+        data = dict(features=voxels, num_voxels=num_points_in_voxel, coors=coordinates, batch_size=batch_size,
+                    input_shape=example["shape"][0])
+        bev_map = None
+        if self.bbox_head.bev_map:
+            bev_map = torch.stack(example["bev_map"], dim=1).float()
+        x, _ = self.extract_feat(data)
+        preds = self.bbox_head(x, bev_map)
+        if return_loss:
+            return self.bbox_head.loss(example, preds)
+        return self.bbox_head.predict(example, preds, self.test_cfg)
+
+    # ------------------------------------------------------------------------------------------------ fast path
+    @torch.no_grad()
+    def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True):
+        """clouds: list of device float32 [N_i, 5] tensors (one merged multi-sweep cloud per sample);
+        voxel_cfg: the config's ``voxel_generator`` dict (range, voxel_size, max_points_in_voxel, max_voxel_num).
+        Returns predict_padded()'s tuple (padded=True) or the list of per-sample dicts."""
+        assert not self.training
+        dev = clouds[0].device
+        B = len(clouds)
+        rng, vs = voxel_cfg["range"], voxel_cfg["voxel_size"]
+        mv = voxel_cfg["max_voxel_num"]
+        max_voxels = int(mv[1] if isinstance(mv, (list, tuple)) else mv)  # eval cap (preprocess.py:256-258)
+        max_points = int(voxel_cfg["max_points_in_voxel"])
+        cpad = sparse.pad_channels(clouds[0].shape[1])
+        mean = torch.empty((B * max_voxels, cpad), dtype=torch.float32, device=dev)
+        coors = torch.empty((B * max_voxels, 4), dtype=torch.int32, device=dev)
+        npts = torch.empty((B * max_voxels,), dtype=torch.int32, device=dev)
+        nvox = torch.zeros((B,), dtype=torch.int32, device=dev)
+        for b, pts in enumerate(clouds):
+            sl = slice(b * max_voxels, (b + 1) * max_voxels)
+            hip_ops.voxelize(pts, vs, rng, max_points, max_voxels, batch_idx=b, want_voxels=False, want_mean=True,
+                             out=dict(mean=mean[sl], coors=coors[sl], num_points=npts[sl], num_voxels=nvox[b:b + 1]))
+        grid = np.round((np.array(rng[3:], np.float32) - np.array(rng[:3], np.float32)) / np.array(vs, np.float32)).astype(np.int64)
+
+        def mark(i0):
+            for b in range(B):
+                sl = slice(b * max_voxels, (b + 1) * max_voxels)
+                i0.mark(coors[sl], n_dev=nvox[b:b + 1], n_max=max_voxels)
+
+        bb = self.backbone
+        idx = bb.build_indexes(mark, B, list(grid), dev)
+        feats0 = torch.zeros((max(idx[0].n, 1), cpad), dtype=bb.compute_dtype, device=dev)[: idx[0].n]
+        L = hip_ops._lib.load()
+        for b in range(B):
+            sl = slice(b * max_voxels, (b + 1) * max_voxels)
+            row_of = idx[0].lookup(coors[sl], n_dev=nvox[b:b + 1])
+            hip_ops.check(L.fd_rows_permute(hip_ops._p(mean[sl]), cpad, hip_ops._p(row_of), hip_ops._p(nvox[b:b + 1]), max_voxels,
+                                            hip_ops._p(feats0), cpad, hip_ops._DT[bb.compute_dtype], hip_ops._stream()),
+                          "fd_rows_permute")
+        x, _ = bb.run_fused(idx, feats0)
+        x = self.neck(x)
+        preds = self.bbox_head(x, bev_map)
+        if padded:
+            return self.bbox_head.predict_padded(preds, self.test_cfg)
+        return self.bbox_head.predict({"metadata": [None] * B}, preds, self.test_cfg)
+
+
+@DETECTORS.register_module
+class PointPillars(SingleStageDetector):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("PointPillars is outside the VoxelNet hot path (only its config files load)")
+
+
+@DETECTORS.register_module
+class TwoStageDetector(BaseDetector):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("TWO_STAGE is False in every shipped config")

@@ -1,0 +1,269 @@
+"""CenterHead (det3d/models/bbox_heads/center_head.py:81-174 SepHead, :232-390 CenterHead, :542-747 predict).
+
+Constructor signature and state_dict keys follow the reference (shared_conv.{0,1}.*, tasks.{i}.{reg,height,dim,
+rot,vel,hm}.{0,1,3}.*, tasks.{i}.forecast_conv.*, bev_conv.*).  Only the branches reachable from the shipped
+configs exist: "standard" (n0 / n3: one task, velocity split per timestep) and "dense" (n3dtf / n3dtfm: one task
+per timestep, optional chained forecast features and BEV-map branch).  predict() runs the HIP decode + rotated
+NMS (fd_centerpoint_decode) for all (sample, heat-map) groups in one call; the loss is training-only and out of
+scope of this path.
+"""
+import copy
+import logging
+
+import torch
+from torch import nn
+
+from . import hip_ops
+from .nn_utils import Sequential, fold_stack, kaiming_init
+from .registry import HEADS
+
+
+class SepHead(nn.Module):
+    def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, bn=False, init_bias=-2.19, two_stage=False,
+                 forecast_feature=False, wide_head=False, **kwargs):
+        super().__init__(**kwargs)
+        assert not two_stage and not wide_head, "two_stage / wide_head are False in every shipped config"
+        self.heads = heads
+        self.forecast_feature = forecast_feature
+        if self.forecast_feature:
+            self.forecast_conv = nn.Sequential(
+                nn.Conv2d(in_channels, head_conv, kernel_size=3, padding=1, bias=True), nn.BatchNorm2d(head_conv),
+                nn.ReLU(inplace=True),
+                nn.Conv2d(head_conv, head_conv, kernel_size=3, padding=1, bias=True), nn.BatchNorm2d(head_conv),
+                nn.ReLU(inplace=True))
+        for head in self.heads:
+            classes, num_conv = self.heads[head]
+            fc = Sequential()
+            for _ in range(num_conv - 1):
+                fc.add(nn.Conv2d(head_conv, head_conv, kernel_size=final_kernel, stride=1, padding=final_kernel // 2,
+                                 bias=True))
+                if bn:
+                    fc.add(nn.BatchNorm2d(head_conv))
+                fc.add(nn.ReLU())
+            fc.add(nn.Conv2d(head_conv, classes, kernel_size=final_kernel, stride=1, padding=final_kernel // 2, bias=True))
+            if "hm" in head:
+                fc[-1].bias.data.fill_(init_bias)
+            else:
+                for m in fc.modules():
+                    if isinstance(m, nn.Conv2d):
+                        kaiming_init(m)
+            self.__setattr__(head, fc)
+        self._fused = None
+        self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_fused", None))
+
+    def forward_modules(self, x):
+        ret = {}
+        if self.forecast_feature:
+            x = self.forecast_conv(x)
+            ret["feats"] = x
+        for head in self.heads:
+            ret[head] = self.__getattr__(head)(x)
+        return ret
+
+    def _fuse(self, dtype, channels_last):
+        """All heads read the same map: their first convs become one conv (Cout = 64*nheads, BN folded, ReLU) and
+        their final convs one block-diagonal conv, so a task costs 2 launches instead of 12."""
+        key = (dtype, channels_last, next(self.parameters()).device)
+        if self._fused is not None and self._fused[0] == key:
+            return self._fused[1:]
+        names = list(self.heads)
+        pre = fold_stack(self.forecast_conv, dtype, channels_last) if self.forecast_feature else []
+        firsts, finals = [], []
+        for h in names:
+            mods = list(getattr(self, h)._modules.values())
+            st = fold_stack(mods, torch.float32, False)
+            assert len(st) == 2, "fusion assumes num_conv == 2 (all shipped configs)"
+            firsts.append(st[0])
+            finals.append(st[1])
+        w1 = torch.cat([f.weight for f in firsts], 0)
+        b1 = torch.cat([f.bias for f in firsts], 0)
+        hc = firsts[0].weight.shape[0]
+        couts = [f.weight.shape[0] for f in finals]
+        k = finals[0].weight.shape[-1]
+        w2 = torch.zeros((sum(couts), hc * len(names), k, k), dtype=torch.float32, device=w1.device)
+        o = 0
+        for i, f in enumerate(finals):
+            w2[o:o + couts[i], i * hc:(i + 1) * hc] = f.weight
+            o += couts[i]
+        b2 = torch.cat([f.bias for f in finals], 0)
+        mf = torch.channels_last if channels_last else torch.contiguous_format
+        conv1 = (w1.to(dtype).contiguous(memory_format=mf), b1.to(dtype), firsts[0].padding)
+        conv2 = (w2.to(dtype).contiguous(memory_format=mf), b2.to(dtype), finals[0].padding)
+        self._fused = (key, pre, conv1, conv2, names, couts)
+        return self._fused[1:]
+
+    def forward_fused(self, x, dtype, channels_last):
+        pre, (w1, b1, p1), (w2, b2, p2), names, couts = self._fuse(dtype, channels_last)
+        ret = {}
+        for conv in pre:
+            x = conv(x)
+        if self.forecast_feature:
+            ret["feats"] = x
+        y = torch.nn.functional.relu_(torch.nn.functional.conv2d(x, w1, b1, padding=p1))
+        z = torch.nn.functional.conv2d(y, w2, b2, padding=p2)
+        o = 0
+        for name, c in zip(names, couts):
+            ret[name] = z[:, o:o + c]
+            o += c
+        return ret
+
+    def forward(self, x):
+        return self.forward_modules(x)
+
+
+@HEADS.register_module
+class CenterHead(nn.Module):
+    def __init__(self, in_channels=[128, ], tasks=[], dataset="nuscenes", weight=0.25, code_weights=[], common_heads=dict(),
+                 logger=None, init_bias=-2.19, share_conv_channel=64, num_hm_conv=2, dcn_head=False, timesteps=1,
+                 two_stage=False, reverse=False, sparse=False, dense=False, bev_map=False, forecast_feature=False,
+                 classify=True, wide_head=False):
+        super().__init__()
+        unsupported = dict(dcn_head=dcn_head, two_stage=two_stage, reverse=reverse, sparse=sparse, classify=classify,
+                           wide_head=wide_head)
+        on = [k for k, v in unsupported.items() if v]
+        if on:
+            raise NotImplementedError("CenterHead options %s are False in every shipped centerpoint config and are not "
+                                      "part of the inference hot path" % on)
+        self.two_stage, self.reverse, self.sparse, self.dense = two_stage, reverse, sparse, dense
+        self.bev_map, self.forecast_feature, self.classify, self.wide_head = bev_map, forecast_feature, classify, wide_head
+        self.target_timesteps = 7
+        self.standard = not dense
+        num_classes = [len(t["class_names"]) for t in tasks]
+        self.class_names = [t["class_names"] for t in tasks]
+        self.code_weights = code_weights
+        self.box_n_dim = 9 if ("vel" in common_heads and "rot" in common_heads) else 7
+        self.weight = weight
+        self.dataset = dataset
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.use_direction_classifier = False
+        self.timesteps = timesteps
+        self.logger = logger or logging.getLogger("CenterHead")
+        self.logger.info(f"num_classes: {num_classes}")
+        self.tasks = nn.ModuleList()
+        if self.dense:
+            self.num_classes = self.timesteps * [1]
+        if self.bev_map:
+            c = share_conv_channel
+            self.bev_conv = nn.Sequential(
+                nn.Conv2d(6, 16, kernel_size=3, padding=1, bias=True), nn.BatchNorm2d(16), nn.ReLU(inplace=True),
+                nn.Conv2d(16, 32, kernel_size=3, padding=1, bias=True), nn.BatchNorm2d(32), nn.ReLU(inplace=True),
+                nn.Conv2d(32, c, kernel_size=3, padding=1, bias=True), nn.BatchNorm2d(c), nn.ReLU(inplace=True))
+        self.shared_conv = nn.Sequential(nn.Conv2d(in_channels, share_conv_channel, kernel_size=3, padding=1, bias=True),
+                                         nn.BatchNorm2d(share_conv_channel), nn.ReLU(inplace=True))
+        for i, num_cls in enumerate(self.num_classes):
+            heads = copy.deepcopy(dict(common_heads))
+            for head in heads.keys():
+                if not self.dense and head in ["vel", "rvel"]:
+                    heads[head] = (self.timesteps * heads[head][0], heads[head][1])
+            heads.update(dict(hm=(num_cls, num_hm_conv)))
+            cin = 2 * share_conv_channel if (i != 0 and self.forecast_feature) else share_conv_channel
+            self.tasks.append(SepHead(cin, heads, bn=True, init_bias=init_bias, final_kernel=3, two_stage=self.two_stage,
+                                      forecast_feature=self.forecast_feature, wide_head=self.wide_head))
+        self.compute_dtype = torch.float32
+        self.channels_last = False
+        self._folded = None
+        self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_folded", None))
+        self.logger.info("Finish CenterHead Initialization")
+
+    # ----------------------------------------------------------------------------------------------- forward
+    def forward_modules(self, x, bev_map=None):
+        ret_dicts = []
+        x = self.shared_conv(x)
+        if self.bev_map:
+            x = x + self.bev_conv(bev_map)
+        for i, task in enumerate(self.tasks):
+            if i != 0 and self.forecast_feature:
+                ret_dicts.append(task(torch.cat([x, ret_dicts[i - 1]["feats"]], dim=1)))
+            else:
+                ret_dicts.append(task(x))
+        return ret_dicts
+
+    def forward(self, x, bev_map=None, *kwargs):
+        if self.training:
+            return self.forward_modules(x, bev_map)
+        dt, cl = self.compute_dtype, self.channels_last
+        key = (dt, cl, next(self.parameters()).device)
+        if self._folded is None or self._folded[0] != key:
+            shared = fold_stack(self.shared_conv, dt, cl)
+            bev = fold_stack(self.bev_conv, dt, cl) if self.bev_map else None
+            self._folded = (key, shared, bev)
+        _, shared, bev = self._folded
+        x = x.to(dt)
+        if cl:
+            x = x.contiguous(memory_format=torch.channels_last)
+        for conv in shared:
+            x = conv(x)
+        if self.bev_map:
+            y = bev_map.to(dt)
+            for conv in bev:
+                y = conv(y)
+            x = x + y
+        rets = []
+        for i, task in enumerate(self.tasks):
+            inp = torch.cat([x, rets[i - 1]["feats"]], dim=1) if (i != 0 and self.forecast_feature) else x
+            rets.append(task.forward_fused(inp, dt, cl))
+        return rets
+
+    def loss(self, example, preds_dicts, **kwargs):
+        raise NotImplementedError("training losses (center_head.py:396-539) are outside the inference hot path")
+
+    # ----------------------------------------------------------------------------------------------- predict
+    def _groups(self, preds_dicts):
+        """-> (list of per-group source dicts, vel tensor per output step, step->group map, num_classes per step)."""
+        if self.standard:  # center_head.py:559-570
+            pd = preds_dicts[0]
+            vels = [pd["vel"][:, 2 * i:2 * i + 2] for i in range(self.timesteps)]
+            if len(vels) == 1:
+                vels = self.target_timesteps * vels
+            return [pd], vels, [0] * len(vels), [1] * self.target_timesteps
+        vels = [pd["vel"] for pd in preds_dicts]  # center_head.py:606-607
+        return list(preds_dicts), vels, list(range(len(preds_dicts))), list(self.num_classes)
+
+    @torch.no_grad()
+    def predict_padded(self, preds_dicts, test_cfg):
+        """Device-only decode: (boxes [B,S,post,9], scores [B,S,post], labels [B,S,post] int64, counts [B,S] int32)
+        with S output steps; entries k >= counts[b,s] are padding.  No host synchronisation."""
+        if test_cfg.get("per_class_nms", False) or test_cfg.get("circular_nms", False):
+            raise NotImplementedError("only rotated NMS is configured in the shipped test_cfg")
+        srcs, vels, step_group, num_classes = self._groups(preds_dicts)
+        B, _, H, W = srcs[0]["hm"].shape
+        assert all(s["hm"].shape[1] == 1 for s in srcs), "single-class heat-maps (every shipped task has one class)"
+        f = lambda k: torch.cat([s[k].float() for s in srcs], 0).contiguous() if len(srcs) > 1 else srcs[0][k].float().contiguous()  # noqa: E731
+        cfg = hip_ops.make_decode_cfg(H, W, test_cfg)
+        boxes7, scores, cell, count = hip_ops.centerpoint_decode(f("hm"), f("reg"), f("height"), f("dim"), f("rot"), cfg)
+        post = cfg.nms_post_max
+        G = len(srcs)
+        # group-major [G*B, ...] -> [B, G, ...]
+        boxes7 = boxes7.view(G, B, post, 7).transpose(0, 1)
+        scores = scores.view(G, B, post).transpose(0, 1)
+        cell = cell.view(G, B, post).transpose(0, 1)
+        count = count.view(G, B).transpose(0, 1)
+        out_b, out_s, out_l, out_c = [], [], [], []
+        flag = 0
+        for s, (vel, g) in enumerate(zip(vels, step_group)):
+            idx = cell[:, g].long().clamp_(min=0)  # [B, post]
+            v = vel.float().reshape(B, 2, H * W)
+            vx = torch.gather(v[:, 0], 1, idx)
+            vy = torch.gather(v[:, 1], 1, idx)
+            b7 = boxes7[:, g]
+            out_b.append(torch.cat([b7[..., :6], vx.unsqueeze(-1), vy.unsqueeze(-1), b7[..., 6:7]], dim=-1))
+            out_s.append(scores[:, g])
+            out_l.append(torch.full((B, post), flag, dtype=torch.int64, device=b7.device))
+            out_c.append(count[:, g])
+            flag += num_classes[s]
+        return torch.stack(out_b, 1), torch.stack(out_s, 1), torch.stack(out_l, 1), torch.stack(out_c, 1)
+
+    @torch.no_grad()
+    def predict(self, example, preds_dicts, test_cfg, **kwargs):
+        boxes, scores, labels, counts = self.predict_padded(preds_dicts, test_cfg)
+        B, S, post, _ = boxes.shape
+        valid = torch.arange(post, device=boxes.device).view(1, 1, post) < counts.unsqueeze(-1)
+        metas = example.get("metadata") if isinstance(example, dict) else None
+        ret = []
+        for b in range(B):
+            m = valid[b].reshape(-1)
+            ret.append({"box3d_lidar": boxes[b].reshape(-1, 9)[m], "scores": scores[b].reshape(-1)[m],
+                        "label_preds": labels[b].reshape(-1)[m],
+                        "metadata": metas[b] if metas is not None and len(metas) > b else None})
+        return ret

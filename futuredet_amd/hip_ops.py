@@ -1,0 +1,272 @@
+"""Torch-tensor front end of the C ABI (include/futuredet_hip.h).  Tensors are device memory plumbing only:
+every function passes raw pointers + the current HIP stream to libfuturedet_hip.so.  No CPU fallbacks."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .lib import DecodeCfg, FutureDetHipError, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise FutureDetHipError("%s must be a tensor on the HIP device (got %s); this path has no CPU implementation"
+                                % (name, "cpu tensor" if isinstance(t, torch.Tensor) else type(t)))
+    if dtype is not None and t.dtype != dtype:
+        raise FutureDetHipError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise FutureDetHipError("%s must be contiguous" % name)
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _Workspace(object):
+    """Grow-only per-(device, tag) scratch buffers so steady-state steps do no allocation."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, tag, nbytes, device):
+        key = (tag, device.index)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
+
+
+workspace = _Workspace()
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+# ------------------------------------------------------------------------------------------------ voxelizer
+def voxelize(points, voxel_size, coors_range, max_points, max_voxels, batch_idx=0, want_voxels=True, want_mean=False,
+             mean_stride=None, coor_cols=3, out=None):
+    """Runs fd_voxelize on device points [N, ndim] float32.  Returns a dict of capacity-sized device tensors
+    (voxels / mean / coors / num_points) plus ``num_voxels`` (device int32[1]); nothing is synchronised.
+    ``out`` may supply pre-allocated (sliced) destination tensors with the same keys."""
+    L = _lib.load()
+    points = _dev(points, "points", torch.float32)
+    n, ndim = points.shape
+    dev = points.device
+    rng = (ctypes.c_float * 6)(*[float(np.float32(v)) for v in coors_range])
+    vs = (ctypes.c_float * 3)(*[float(np.float32(v)) for v in voxel_size])
+    out = dict(out or {})
+    if want_voxels and "voxels" not in out:
+        out["voxels"] = torch.empty((max_voxels, max_points, ndim), dtype=torch.float32, device=dev)
+    if want_mean and "mean" not in out:
+        out["mean"] = torch.empty((max_voxels, mean_stride or ndim), dtype=torch.float32, device=dev)
+    if "coors" not in out:
+        out["coors"] = torch.empty((max_voxels, coor_cols), dtype=torch.int32, device=dev)
+    if "num_points" not in out:
+        out["num_points"] = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
+    if "num_voxels" not in out:
+        out["num_voxels"] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    mean = out.get("mean") if want_mean else None
+    voxels = out.get("voxels") if want_voxels else None
+    ws_bytes = L.fd_voxelize_workspace_bytes(n, max_voxels)
+    ws = workspace.get("voxelize", ws_bytes, dev)
+    check(L.fd_voxelize(_p(points), n, ndim, rng, vs, int(max_points), int(max_voxels), int(batch_idx), _p(voxels), _p(mean),
+                        int(mean.shape[1]) if mean is not None else 0, _p(out["coors"]), int(out["coors"].shape[1]),
+                        _p(out["num_points"]), _p(out["num_voxels"]), _p(ws), ws.numel(), _stream()), "fd_voxelize")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ sparse index
+class SparseIndex(object):
+    """Active set on a (B, D, H, W) grid: column occupancy words + prefix counts (+ coords once counted)."""
+
+    def __init__(self, B, D, H, W, device):
+        L = _lib.load()
+        self.B, self.D, self.H, self.W = int(B), int(D), int(H), int(W)
+        self.ncols = L.fd_index_num_cols(self.B, self.H, self.W)
+        self.words = torch.zeros((self.ncols,), dtype=torch.int64, device=device)
+        self.prefix = torch.empty((self.ncols,), dtype=torch.int32, device=device)
+        self.n_dev = None     # device int32[1] view
+        self.n = None         # host int, set by finalize()
+        self.coords = None    # [n,4] int32 (b,z,y,x), rows in index order
+        self.device = device
+
+    @property
+    def spatial_shape(self):
+        return [self.D, self.H, self.W]
+
+    def mark(self, coords, n_dev=None, n_max=None):
+        L = _lib.load()
+        coords = _dev(coords, "coords", torch.int32)
+        n_max = coords.shape[0] if n_max is None else n_max
+        check(L.fd_index_mark(_p(coords), _p(n_dev), n_max, self.B, self.D, self.H, self.W, _p(self.words), _stream()),
+              "fd_index_mark")
+
+    def scan(self, n_dev):
+        L = _lib.load()
+        ws = workspace.get("index_scan", L.fd_index_workspace_bytes(self.ncols), self.device)
+        self.n_dev = n_dev
+        check(L.fd_index_scan(_p(self.words), self.ncols, _p(self.prefix), _p(n_dev), _p(ws), ws.numel(), _stream()),
+              "fd_index_scan")
+
+    def downsample(self, ksize, stride, pad):
+        L = _lib.load()
+        od = [(i + 2 * p - (k - 1) - 1) // s + 1 for i, k, s, p in zip(self.spatial_shape, ksize, stride, pad)]
+        out = SparseIndex(self.B, od[0], od[1], od[2], self.device)
+        check(L.fd_index_downsample(_p(self.words), self.B, self.D, self.H, self.W, (ctypes.c_int * 3)(*ksize),
+                                    (ctypes.c_int * 3)(*stride), (ctypes.c_int * 3)(*pad), _p(out.words), _stream()),
+              "fd_index_downsample")
+        return out
+
+    def finalize(self, n):
+        """Called once the host knows the active count: materialises coords."""
+        L = _lib.load()
+        self.n = int(n)
+        self.coords = torch.empty((max(self.n, 1), 4), dtype=torch.int32, device=self.device)[: self.n]
+        if self.n:
+            check(L.fd_index_coords(_p(self.words), _p(self.prefix), self.B, self.D, self.H, self.W, _p(self.coords),
+                                    _stream()), "fd_index_coords")
+
+    def lookup(self, coords, n_dev=None):
+        L = _lib.load()
+        coords = _dev(coords, "coords", torch.int32)
+        row_of = torch.empty((coords.shape[0],), dtype=torch.int32, device=self.device)
+        check(L.fd_index_lookup(_p(self.words), _p(self.prefix), self.B, self.D, self.H, self.W, _p(coords), _p(n_dev),
+                                coords.shape[0], _p(row_of), _stream()), "fd_index_lookup")
+        return row_of
+
+    def rulebook(self, out_index, ksize, stride, pad):
+        """nbr [K, stride64] int32: input row (in self) feeding each output row of ``out_index`` per tap."""
+        L = _lib.load()
+        assert out_index.n is not None
+        K = int(ksize[0] * ksize[1] * ksize[2])
+        nstride = max(64, (out_index.n + 63) // 64 * 64)
+        nbr = torch.empty((K, nstride), dtype=torch.int32, device=self.device)
+        if out_index.n == 0:
+            nbr.fill_(-1)
+            return nbr
+        check(L.fd_rulebook(_p(self.words), _p(self.prefix), self.B, self.D, self.H, self.W, _p(out_index.coords),
+                            _p(out_index.n_dev), nstride, (ctypes.c_int * 3)(*ksize), (ctypes.c_int * 3)(*stride),
+                            (ctypes.c_int * 3)(*pad), _p(nbr), _stream()), "fd_rulebook")
+        return nbr
+
+
+def rows_permute(src, row_of, c_dst, dtype=torch.float32, n_rows=None, n_dev=None):
+    L = _lib.load()
+    src = _dev(src, "src", torch.float32)
+    row_of = _dev(row_of, "row_of", torch.int32)
+    n_rows = src.shape[0] if n_rows is None else n_rows
+    dst = torch.zeros((max(n_rows, 1), c_dst), dtype=dtype, device=src.device)[:n_rows]
+    if src.shape[0]:
+        check(L.fd_rows_permute(_p(src), src.shape[1], _p(row_of), _p(n_dev), src.shape[0], _p(dst), c_dst,
+                                _DT[dtype], _stream()), "fd_rows_permute")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------ sparse conv
+def pack_spconv_weight(w_kio, dtype=torch.float32):
+    """[K, Cin, Cout] float32 (host or device) -> fragment-ordered packed weights on the same device."""
+    L = _lib.load()
+    dev = w_kio.device
+    w = w_kio.detach().to("cpu", torch.float32).contiguous()
+    K, cin, cout = w.shape
+    nbytes = L.fd_spconv_packed_weight_bytes(K, cin, cout, _DT[dtype])
+    host = torch.empty((nbytes,), dtype=torch.uint8)
+    check(L.fd_spconv_pack_weight(ctypes.c_void_p(w.data_ptr()), K, cin, cout, _DT[dtype], ctypes.c_void_p(host.data_ptr())),
+          "fd_spconv_pack_weight")
+    return host.to(dev)
+
+
+def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=False, out=None):
+    L = _lib.load()
+    feats = _dev(feats, "feats")
+    dt = _DT[feats.dtype]
+    cin = feats.shape[1]
+    K, nstride = nbr.shape
+    if out is None:
+        out = torch.empty((max(n_out, 1), cout), dtype=feats.dtype, device=feats.device)[:n_out]
+    if residual is not None:
+        _dev(residual, "residual", feats.dtype)
+    check(L.fd_spconv_apply(_p(feats), _p(_dev(wpacked, "wpacked")), _p(bias), _p(residual), int(bool(relu)),
+                            _p(_dev(nbr, "nbr", torch.int32)), nstride, K, n_out, cin, cout, dt, _p(out), _stream()),
+          "fd_spconv_apply")
+    return out
+
+
+def densify(feats, index, out_dtype=None, channels_last=False):
+    """SparseConvTensor.dense()+view: [B, C*D, H, W] with channel = c*D + d."""
+    L = _lib.load()
+    feats = _dev(feats, "feats")
+    C = feats.shape[1]
+    out_dtype = out_dtype or feats.dtype
+    shape = (index.B, C * index.D, index.H, index.W)
+    out = torch.empty(shape, dtype=out_dtype, device=feats.device,
+                      memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    sb, sc, sy, sx = out.stride()
+    check(L.fd_densify(_p(feats), C, _DT[feats.dtype], _p(index.words), _p(index.prefix), index.B, index.D, index.H,
+                       index.W, _p(out), _DT[out_dtype], sb, sc, sy, sx, _stream()), "fd_densify")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ decode / NMS
+def make_decode_cfg(H, W, test_cfg):
+    c = DecodeCfg()
+    c.H, c.W = int(H), int(W)
+    c.out_size_factor = float(test_cfg["out_size_factor"])
+    c.voxel_x, c.voxel_y = float(test_cfg["voxel_size"][0]), float(test_cfg["voxel_size"][1])
+    c.pc_x, c.pc_y = float(test_cfg["pc_range"][0]), float(test_cfg["pc_range"][1])
+    c.score_threshold = float(test_cfg["score_threshold"])
+    for i, v in enumerate(test_cfg["post_center_limit_range"]):
+        c.center_range[i] = float(v)
+    nms = test_cfg["nms"]
+    c.nms_iou_threshold = float(nms["nms_iou_threshold"])
+    c.nms_pre_max = int(nms["nms_pre_max_size"])
+    c.nms_post_max = int(nms["nms_post_max_size"])
+    return c
+
+
+def centerpoint_decode(hm, reg, height, dim, rot, cfg):
+    """Inputs are [G, C, H, W] float32 NCHW slices (G groups, C = 1/2/1/3/2).  Returns (boxes7 [G,post,7],
+    scores [G,post], cell [G,post] int32, count [G] int32), all on device."""
+    L = _lib.load()
+    G = hm.shape[0]
+    ts = [_dev(t, n, torch.float32) for t, n in ((hm, "hm"), (reg, "reg"), (height, "height"), (dim, "dim"), (rot, "rot"))]
+    dev = hm.device
+    post = cfg.nms_post_max
+    boxes = torch.empty((G, post, 7), dtype=torch.float32, device=dev)
+    scores = torch.empty((G, post), dtype=torch.float32, device=dev)
+    cell = torch.empty((G, post), dtype=torch.int32, device=dev)
+    count = torch.empty((G,), dtype=torch.int32, device=dev)
+    ws = workspace.get("decode", L.fd_decode_workspace_bytes(G, ctypes.byref(cfg)), dev)
+    args = []
+    for t in ts:
+        args += [_p(t), t.stride(0)]
+    check(L.fd_centerpoint_decode(*args, G, ctypes.byref(cfg), _p(boxes), _p(scores), _p(cell), _p(count), _p(ws),
+                                  ws.numel(), _stream()), "fd_centerpoint_decode")
+    return boxes, scores, cell, count
+
+
+def rotated_nms(boxes7, thresh):
+    """nms_gpu contract on device: boxes [n,7] (pcdet layout, score-sorted) -> (keep int64[n], count int32[1])."""
+    L = _lib.load()
+    boxes7 = _dev(boxes7, "boxes", torch.float32)
+    n = boxes7.shape[0]
+    keep = torch.zeros((max(n, 1),), dtype=torch.int64, device=boxes7.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=boxes7.device)
+    ws = workspace.get("nms", L.fd_nms_workspace_bytes(n), boxes7.device)
+    check(L.fd_rotated_nms(_p(boxes7), n, ctypes.c_float(thresh), _p(keep), _p(count), _p(ws), ws.numel(), _stream()),
+          "fd_rotated_nms")
+    return keep, count
+
+
+def boxes_iou_bev(a, b):
+    L = _lib.load()
+    a = _dev(a, "boxes_a", torch.float32)
+    b = _dev(b, "boxes_b", torch.float32)
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    check(L.fd_boxes_iou_bev(_p(a), a.shape[0], _p(b), b.shape[0], _p(out), _stream()), "fd_boxes_iou_bev")
+    return out

@@ -1,0 +1,83 @@
+"""ctypes binding of libfuturedet_hip.so (the C ABI declared in include/futuredet_hip.h).
+
+There is no CPU fallback: loading fails loudly when the library is missing, and every op raises
+when its tensors are not on a HIP device.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfuturedet_hip.so")
+_lib = None
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_size_t = ctypes.c_size_t
+c_float = ctypes.c_float
+
+
+class DecodeCfg(ctypes.Structure):
+    _fields_ = [("H", c_int), ("W", c_int), ("out_size_factor", c_float), ("voxel_x", c_float), ("voxel_y", c_float),
+                ("pc_x", c_float), ("pc_y", c_float), ("score_threshold", c_float), ("center_range", c_float * 6),
+                ("nms_iou_threshold", c_float), ("nms_pre_max", c_int), ("nms_post_max", c_int)]
+
+
+# name -> (restype, argtypes); this table is checked against include/futuredet_hip.h by the tests
+SIGNATURES = {
+    "fd_abi_version": (c_int, []),
+    "fd_last_error": (ctypes.c_char_p, []),
+    "fd_voxelize_workspace_bytes": (c_size_t, [c_i64, c_i64]),
+    "fd_voxelize": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_int,
+                            c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fd_index_num_cols": (c_i64, [c_int, c_int, c_int]),
+    "fd_index_workspace_bytes": (c_size_t, [c_i64]),
+    "fd_index_mark": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fd_index_downsample": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_index_scan": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fd_index_coords": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "fd_index_lookup": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "fd_rows_permute": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p]),
+    "fd_rulebook": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p,
+                            c_void_p, c_void_p, c_void_p]),
+    "fd_spconv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "fd_spconv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "fd_spconv_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_int, c_i64, c_int, c_int,
+                                c_int, c_void_p, c_void_p]),
+    "fd_densify": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_i64,
+                           c_i64, c_i64, c_i64, c_void_p]),
+    "fd_decode_workspace_bytes": (c_size_t, [c_int, ctypes.POINTER(DecodeCfg)]),
+    "fd_centerpoint_decode": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
+                                      c_int, ctypes.POINTER(DecodeCfg), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
+    "fd_nms_workspace_bytes": (c_size_t, [c_int]),
+    "fd_rotated_nms": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fd_boxes_iou_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+}
+
+
+class FutureDetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise FutureDetHipError(
+                "libfuturedet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python futuredet_amd/build.py`; there is no CPU fallback for this path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError = ABI mismatch, let it propagate
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().fd_last_error()
+        raise FutureDetHipError("%s failed (%d): %s" % (what, status, msg.decode() if msg else "?"))

@@ -1,0 +1,114 @@
+"""RPN neck (det3d/models/necks/rpn.py:22-159).  Same constructor, same state_dict keys
+(blocks.{i}.{1,4,...}.weight, deblocks.{i}.0.weight, ...).  In eval mode the stack runs with BatchNorm folded
+into the convolutions (ZeroPad2d merged into the conv padding), optionally channels-last / bf16, through
+PyTorch-ROCm's MIOpen convolutions (MFMA); training mode keeps the plain module stack."""
+import logging
+
+import numpy as np
+import torch
+from torch import nn
+
+from .nn_utils import Sequential, build_norm_layer, fold_stack
+from .registry import NECKS
+
+
+@NECKS.register_module
+class RPN(nn.Module):
+    def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
+                 num_input_features, norm_cfg=None, name="rpn", logger=None, **kwargs):
+        super().__init__()
+        self._layer_strides = ds_layer_strides
+        self._num_filters = ds_num_filters
+        self._layer_nums = layer_nums
+        self._upsample_strides = us_layer_strides
+        self._num_upsample_filters = us_num_filters
+        self._num_input_features = num_input_features
+        if norm_cfg is None:
+            norm_cfg = dict(type="BN", eps=1e-3, momentum=0.01)
+        self._norm_cfg = norm_cfg
+        assert len(self._layer_strides) == len(self._layer_nums)
+        assert len(self._num_filters) == len(self._layer_nums)
+        assert len(self._num_upsample_filters) == len(self._upsample_strides)
+        self._upsample_start_idx = len(self._layer_nums) - len(self._upsample_strides)
+        must_equal = [self._upsample_strides[i] / np.prod(self._layer_strides[: i + self._upsample_start_idx + 1])
+                      for i in range(len(self._upsample_strides))]
+        for v in must_equal:
+            assert v == must_equal[0]
+        in_filters = [self._num_input_features, *self._num_filters[:-1]]
+        blocks, deblocks = [], []
+        for i, layer_num in enumerate(self._layer_nums):
+            block, num_out = self._make_layer(in_filters[i], self._num_filters[i], layer_num, stride=self._layer_strides[i])
+            blocks.append(block)
+            if i - self._upsample_start_idx >= 0:
+                stride = self._upsample_strides[i - self._upsample_start_idx]
+                cout = self._num_upsample_filters[i - self._upsample_start_idx]
+                if stride > 1:
+                    conv = nn.ConvTranspose2d(num_out, cout, stride, stride=stride, bias=False)
+                else:
+                    stride = int(np.round(1 / stride).astype(np.int64))
+                    conv = nn.Conv2d(num_out, cout, stride, stride=stride, bias=False)
+                deblocks.append(Sequential(conv, build_norm_layer(self._norm_cfg, cout)[1], nn.ReLU()))
+        self.blocks = nn.ModuleList(blocks)
+        self.deblocks = nn.ModuleList(deblocks)
+        self.compute_dtype = torch.float32
+        self.channels_last = False
+        self._folded = None
+        self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_folded", None))
+        (logger or logging.getLogger("RPN")).info("Finish RPN Initialization")
+
+    @property
+    def downsample_factor(self):
+        factor = np.prod(self._layer_strides)
+        if len(self._upsample_strides) > 0:
+            factor /= self._upsample_strides[-1]
+        return factor
+
+    def _make_layer(self, inplanes, planes, num_blocks, stride=1):
+        block = Sequential(nn.ZeroPad2d(1), nn.Conv2d(inplanes, planes, 3, stride=stride, bias=False),
+                           build_norm_layer(self._norm_cfg, planes)[1], nn.ReLU())
+        for _ in range(num_blocks):
+            block.add(nn.Conv2d(planes, planes, 3, padding=1, bias=False))
+            block.add(build_norm_layer(self._norm_cfg, planes)[1])
+            block.add(nn.ReLU())
+        return block, planes
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+
+    def forward_modules(self, x):
+        ups = []
+        for i in range(len(self.blocks)):
+            x = self.blocks[i](x)
+            if i - self._upsample_start_idx >= 0:
+                ups.append(self.deblocks[i - self._upsample_start_idx](x))
+        if len(ups) > 0:
+            x = torch.cat(ups, dim=1)
+        return x
+
+    def _fold(self):
+        key = (self.compute_dtype, self.channels_last, next(self.parameters()).device)
+        if self._folded is None or self._folded[0] != key:
+            blocks = [fold_stack(b._modules.values(), self.compute_dtype, self.channels_last) for b in self.blocks]
+            deblocks = [fold_stack(d._modules.values(), self.compute_dtype, self.channels_last) for d in self.deblocks]
+            self._folded = (key, blocks, deblocks)
+        return self._folded[1], self._folded[2]
+
+    def forward(self, x):
+        if self.training:
+            return self.forward_modules(x)
+        blocks, deblocks = self._fold()
+        x = x.to(self.compute_dtype)
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        ups = []
+        for i, stack in enumerate(blocks):
+            for conv in stack:
+                x = conv(x)
+            if i - self._upsample_start_idx >= 0:
+                y = x
+                for conv in deblocks[i - self._upsample_start_idx]:
+                    y = conv(y)
+                ups.append(y)
+        return torch.cat(ups, dim=1) if ups else x

@@ -1,0 +1,122 @@
+"""Small module helpers that define the reference's state_dict key names, plus BN folding.
+
+build_norm_layer : det3d/models/utils/norm.py:59-108  ("BN"->BatchNorm2d, "BN1d"->BatchNorm1d, default eps 1e-5)
+Sequential.add() : det3d/models/utils/misc.py:22-95   (children named "0","1",...)
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+_NORMS = {"BN": ("bn", nn.BatchNorm2d), "BN1d": ("bn1d", nn.BatchNorm1d), "GN": ("gn", nn.GroupNorm)}
+
+
+def build_norm_layer(cfg, num_features, postfix=""):
+    assert isinstance(cfg, dict) and "type" in cfg
+    cfg_ = dict(cfg)
+    kind = cfg_.pop("type")
+    if kind not in _NORMS:
+        raise KeyError("Unrecognized norm type {}".format(kind))
+    abbr, cls = _NORMS[kind]
+    requires_grad = cfg_.pop("requires_grad", True)
+    cfg_.setdefault("eps", 1e-5)
+    if kind != "GN":
+        layer = cls(num_features, **cfg_)
+    else:
+        layer = cls(num_channels=num_features, **cfg_)
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return abbr + str(postfix), layer
+
+
+class Sequential(nn.Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        for i, m in enumerate(args):
+            self.add_module(str(i), m)
+        for k, m in kwargs.items():
+            if k in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(k, m)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError("index {} is out of range".format(idx))
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, x):
+        for m in self._modules.values():
+            x = m(x)
+        return x
+
+
+def kaiming_init(module, mode="fan_out", nonlinearity="relu", bias=0):
+    nn.init.kaiming_normal_(module.weight, mode=mode, nonlinearity=nonlinearity)
+    if getattr(module, "bias", None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def bn_affine(bn):
+    """Eval-mode BatchNorm as y = x * scale + shift."""
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    return scale, shift
+
+
+class FoldedConv(object):
+    """One conv (+folded BN) (+ReLU) of a dense stack, ready for F.conv2d / F.conv_transpose2d."""
+
+    def __init__(self, weight, bias, stride, padding, relu, transposed=False):
+        self.weight, self.bias, self.stride, self.padding, self.relu, self.transposed = \
+            weight, bias, stride, padding, relu, transposed
+
+    def __call__(self, x):
+        if self.transposed:
+            y = F.conv_transpose2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
+        else:
+            y = F.conv2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
+        return F.relu_(y) if self.relu else y
+
+
+def fold_stack(modules, dtype, channels_last):
+    """[ZeroPad2d?, Conv2d|ConvTranspose2d, BatchNorm2d?, ReLU?]* -> [FoldedConv]; ZeroPad2d(p) becomes conv padding."""
+    out = []
+    mods = list(modules)
+    i = 0
+    pend_pad = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.ZeroPad2d):
+            pend_pad = int(m.padding[0])
+            i += 1
+            continue
+        assert isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)), type(m)
+        transposed = isinstance(m, nn.ConvTranspose2d)
+        w = m.weight.detach().float()
+        b = m.bias.detach().float() if m.bias is not None else None
+        j = i + 1
+        if j < len(mods) and isinstance(mods[j], nn.BatchNorm2d):
+            scale, shift = bn_affine(mods[j])
+            w = w * (scale.view(1, -1, 1, 1) if transposed else scale.view(-1, 1, 1, 1))
+            b = (b * scale if b is not None else torch.zeros_like(scale)) + shift
+            j += 1
+        relu = j < len(mods) and isinstance(mods[j], nn.ReLU)
+        if relu:
+            j += 1
+        pad = int(m.padding[0]) + pend_pad
+        pend_pad = 0
+        w = w.to(dtype)
+        if channels_last:
+            w = w.contiguous(memory_format=torch.channels_last)
+        out.append(FoldedConv(w, b.to(dtype) if b is not None else None, int(m.stride[0]), pad, relu, transposed))
+        i = j
+    return out

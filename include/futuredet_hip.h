@@ -1,0 +1,158 @@
+/*
+ * futuredet_hip.h -- C ABI of libfuturedet_hip.so, the MI355X (gfx950) implementation of the
+ * FutureDet LiDAR inference hot path.  Plain pointers and sizes only (no torch types); every buffer is
+ * caller-owned DEVICE memory unless marked host; every call is asynchronous on `stream` (a hipStream_t
+ * passed as void*), performs no allocation and no device synchronisation, and returns 0 on success or a
+ * negative FD_E* code (never exit()).  fd_last_error() returns a thread-local description of the last
+ * failure.  Sizes that the GPU decides (voxel count, active rows per level, detections) are written to
+ * device int32 counters supplied by the caller; host code reads them when it needs them.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference tree).
+ */
+#ifndef FUTUREDET_HIP_H
+#define FUTUREDET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FD_OK 0
+#define FD_EINVAL (-1)    /* bad argument (null pointer, unsupported channel count, ...) */
+#define FD_EWORKSPACE (-2) /* workspace too small */
+#define FD_ELAUNCH (-3)   /* hipLaunch / runtime error (text in fd_last_error) */
+
+typedef void *fd_stream_t; /* hipStream_t */
+
+int fd_abi_version(void);
+const char *fd_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Voxelizer (+ fused mean reader).
+ * Replaces points_to_voxel(points, voxel_size, coors_range, max_points, reverse_index=True, max_voxels)
+ *   det3d/ops/point_cloud/point_cloud_ops.py:112-184 (kernel :7-55), called from
+ *   det3d/core/input/voxel_generator.py:19-30 <- det3d/datasets/pipelines/preprocess.py:244-271,
+ * and, when out_mean != NULL, VoxelFeatureExtractorV3.forward (det3d/models/readers/voxel_encoder.py:17-24)
+ * and the batch-index prefix of collate_kitti_multi (det3d/torchie/parallel/collate.py:199-206).
+ * Semantics are the reference's sequential ones, computed deterministically in parallel: voxels are numbered
+ * in first-occurrence order of the input points, the first max_voxels voxels survive, each keeps its first
+ * max_points points in input order; c = floor((p - lo) / vs) in float32 with a true division.
+ *   points      [n, ndim] float32 rows (x,y,z,...)          ndim <= 8
+ *   out_voxels  [max_voxels, max_points, ndim] or NULL      (zero padded, as the reference returns)
+ *   out_mean    [max_voxels, mean_stride] or NULL           (sum of kept points / count; cols >= ndim zeroed)
+ *   out_coors   [max_voxels, coor_cols]; coor_cols 3 -> (z,y,x); 4 -> (batch_idx,z,y,x)
+ *   out_num_points [max_voxels] int32, out_num_voxels device int32[1]
+ * ------------------------------------------------------------------------------------------------- */
+size_t fd_voxelize_workspace_bytes(int64_t n_points, int64_t max_voxels);
+int fd_voxelize(const float *points, int64_t n_points, int ndim, const float *range6_host,
+                const float *voxel_size3_host, int max_points, int64_t max_voxels, int batch_idx,
+                float *out_voxels, float *out_mean, int mean_stride, int32_t *out_coors, int coor_cols,
+                int32_t *out_num_points, int32_t *out_num_voxels, void *workspace, size_t workspace_bytes,
+                fd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Sparse index + rulebook.  Replaces spconv 1.0's get_indice_pairs (invoked implicitly by every
+ * SubMConv3d / SparseConv3d with a new indice_key: det3d/models/backbones/scn.py:99,110,115,120,125,130,
+ * 135,141) and SparseConvTensor's coordinate bookkeeping (scn.py:154).
+ *
+ * Native layout (not spconv's pair lists): an active set on a grid (B, D<=64, H, W) is one 64-bit
+ * occupancy word per (b,y,x) column (bit z) plus an exclusive prefix count per column; columns are
+ * linearised in 8x8 tiles, so row numbers are spatially sorted:
+ *     col(b,y,x) = ((b*ceil(H/8) + y/8)*ceil(W/8) + x/8)*64 + (y%8)*8 + x%8
+ *     row(b,z,y,x) = prefix[col] + popcount(words[col] & ((1<<z)-1))
+ * The rulebook is OUTPUT-stationary: nbr[k][o] = input row feeding output row o through kernel tap k
+ * (k row-major over (kz,ky,kx), cross-correlation: input = o*stride - pad + k) or -1.
+ * ------------------------------------------------------------------------------------------------- */
+int64_t fd_index_num_cols(int B, int H, int W);                 /* length of words[] / prefix[] */
+size_t fd_index_workspace_bytes(int64_t num_cols);
+/* words must be zeroed by the caller (hipMemsetAsync) before fd_index_mark. */
+int fd_index_mark(const int32_t *coords /*[n,4] (b,z,y,x)*/, const int32_t *n_dev /*device count, or NULL*/,
+                  int64_t n_max, int B, int D, int H, int W, uint64_t *words, fd_stream_t stream);
+/* marks the output set of a strided conv: o = (p + pad - k)/stride where integral and inside out grid */
+int fd_index_downsample(const uint64_t *in_words, int B, int D, int H, int W, const int *ksize3,
+                        const int *stride3, const int *pad3, uint64_t *out_words, fd_stream_t stream);
+/* exclusive scan of popcounts -> prefix[], total -> n_active_dev[0] */
+int fd_index_scan(const uint64_t *words, int64_t num_cols, int32_t *prefix, int32_t *n_active_dev,
+                  void *workspace, size_t workspace_bytes, fd_stream_t stream);
+/* coords[row] = (b,z,y,x) for every active row */
+int fd_index_coords(const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W,
+                    int32_t *coords /*[n_active,4]*/, fd_stream_t stream);
+/* row_of[j] = row of coords_in[j] in the index (or -1) */
+int fd_index_lookup(const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W,
+                    const int32_t *coords_in, const int32_t *n_dev, int64_t n_max, int32_t *row_of,
+                    fd_stream_t stream);
+/* dst[row_of[j], 0:c_dst] = src[j, 0:c_src] (zero padded to c_dst); rows with row_of<0 skipped */
+int fd_rows_permute(const float *src, int c_src, const int32_t *row_of, const int32_t *n_dev, int64_t n_max,
+                    void *dst, int c_dst, int dst_bf16, fd_stream_t stream);
+/* nbr [K, nbr_stride] int32; rows o >= n_out (device count) are filled with -1 up to nbr_stride */
+int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int Din, int Hin, int Win,
+                const int32_t *out_coords, const int32_t *n_out_dev, int64_t nbr_stride, const int *ksize3,
+                const int *stride3, const int *pad3, int32_t *nbr, fd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Sparse convolution apply (gather - GEMM - no scatter).  Replaces spconv 1.0 indice_conv /
+ * indice_subm_conv as used by the 21 convolutions of SpMiddleResNetFHD (scn.py:99-141) together with the
+ * eval-mode BatchNorm1d / ReLU / residual add that follow them (scn.py:67-78,100-101,...): BN is folded
+ * into weight/bias by the caller.
+ *   out[o,:] = act( sum_k in[nbr[k][o],:] @ W[k] + bias (+ residual[o,:]) )
+ *   in_feats  [n_in, cin]  float32 (dtype 0) or bfloat16 (dtype 1);  cin, cout in {16,32,64,128}
+ *   wpacked   weights in MFMA fragment order, produced by fd_spconv_pack_weight from [K,cin,cout] float32
+ *   bias      [cout] float32 or NULL; residual [n_out,cout] same dtype as out or NULL; relu 0/1
+ * ------------------------------------------------------------------------------------------------- */
+size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype);
+int fd_spconv_pack_weight(const float *w_kio_host, int K, int cin, int cout, int dtype, void *wpacked_host);
+int fd_spconv_apply(const void *in_feats, const void *wpacked, const float *bias, const void *residual,
+                    int relu, const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int cin, int cout,
+                    int dtype, void *out_feats, fd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Densify.  Replaces SparseConvTensor.dense() + view (scn.py:165-168): out[b, c*D + d, y, x] = feats[row, c].
+ * Every output element is written exactly once (zeros where inactive); element strides let the caller
+ * choose NCHW or channels-last memory.  out_dtype 0 float32, 1 bfloat16.
+ * ------------------------------------------------------------------------------------------------- */
+int fd_densify(const void *feats, int c, int dtype, const uint64_t *words, const int32_t *prefix, int B, int D,
+               int H, int W, void *out, int out_dtype, int64_t stride_b, int64_t stride_c, int64_t stride_y,
+               int64_t stride_x, fd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * CenterPoint decode + rotated NMS.  Replaces CenterHead.predict's per-step decode
+ * (det3d/models/bbox_heads/center_head.py:609-673), post_processing (:699-747), rotate_nms_pcdet
+ * (det3d/core/bbox/box_torch_ops.py:248-277) and iou3d_nms_cuda.nms_gpu (det3d/ops/iou3d_nms/src/
+ * iou3d_nms.cpp:90-135, iou3d_nms_kernel.cu:104-311) -- including the greedy sweep, which runs on the device.
+ * One "group" = one (sample, heat-map) pair; G groups are decoded in one call.
+ *   hm     [G, HW] float32 logits (single class)           reg [G,2,HW] height [G,1,HW] dim [G,3,HW] rot [G,2,HW]
+ *   (channel-planar NCHW slices; *_gstride = element stride between groups)
+ *   out_boxes7 [G, post_max, 7]  (x,y,z,w,l,h,yaw as predict emits them, vel excluded)
+ *   out_scores [G, post_max], out_cell [G, post_max] int32 (BEV cell index, for gathering vel), out_count [G]
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct fd_decode_cfg {
+    int H, W;
+    float out_size_factor, voxel_x, voxel_y, pc_x, pc_y; /* test_cfg.out_size_factor / voxel_size / pc_range */
+    float score_threshold;
+    float center_range[6];                               /* post_center_limit_range */
+    float nms_iou_threshold;
+    int nms_pre_max, nms_post_max;
+} fd_decode_cfg;
+
+size_t fd_decode_workspace_bytes(int G, const fd_decode_cfg *cfg);
+int fd_centerpoint_decode(const float *hm, int64_t hm_gstride, const float *reg, int64_t reg_gstride,
+                          const float *height, int64_t height_gstride, const float *dim, int64_t dim_gstride,
+                          const float *rot, int64_t rot_gstride, int G, const fd_decode_cfg *cfg_host,
+                          float *out_boxes7, float *out_scores, int32_t *out_cell, int32_t *out_count,
+                          void *workspace, size_t workspace_bytes, fd_stream_t stream);
+
+/* Stand-alone rotated NMS with nms_gpu's contract (boxes [n,7] pcdet layout, already score-sorted):
+ * keep[0:count] = kept indices (int64), count -> out_count (device int32).  Replaces
+ * iou3d_nms_cuda.nms_gpu (iou3d_nms_api.cpp:11-17, iou3d_nms.cpp:90-135). */
+size_t fd_nms_workspace_bytes(int n);
+int fd_rotated_nms(const float *boxes7, int n, float thresh, int64_t *keep, int32_t *out_count,
+                   void *workspace, size_t workspace_bytes, fd_stream_t stream);
+/* pairwise rotated BEV IoU, replaces boxes_iou_bev_gpu (iou3d_nms.cpp:49-69) */
+int fd_boxes_iou_bev(const float *a7, int na, const float *b7, int nb, float *out, fd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUTUREDET_HIP_H */

