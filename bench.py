@@ -128,6 +128,16 @@ def main():
     if net.bbox_head.bev_map:
         bev = torch.zeros((args.batch, 6, 180, 180), device=dev)
 
+    stage_events = []
+
+    def stage_hook(name):
+        if prof.enabled and args.stage_times:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            stage_events.append((name, e))
+
+    net.stage_hook = stage_hook
+
     def step():
         boxes, scores, labels, counts = net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded=True)
         packed, cnt = dist_infer.pack_results(boxes, scores, labels, counts)
@@ -187,6 +197,11 @@ def main():
                            "pair_gflop_per_step": round(tot_flops / max(args.steps, 1) / 1e9, 2),
                            "spconv_ms_per_step": round(tot_ms / max(args.steps, 1), 3)}
         if args.stage_times:
+            st = {}
+            for (n0, e0), (n1, e1) in zip(stage_events[:-1], stage_events[1:]):
+                if n1 != "start":
+                    st[n1] = st.get(n1, 0.0) + e0.elapsed_time(e1)
+            print("[stage] GPU ms/step: " + ", ".join("%s=%.3f" % (k, v / args.steps) for k, v in st.items()), file=sys.stderr)
             agg = {}
             for i, (tag, info, m) in enumerate(ms):
                 a = agg.setdefault((tag, info["n_out"]), [0.0, 0, 0])

@@ -103,6 +103,8 @@ class VoxelNet(SingleStageDetector):
         voxel_cfg: the config's ``voxel_generator`` dict (range, voxel_size, max_points_in_voxel, max_voxel_num).
         Returns predict_padded()'s tuple (padded=True) or the list of per-sample dicts."""
         assert not self.training
+        mark_stage = getattr(self, "stage_hook", None) or (lambda name: None)
+        mark_stage("start")
         dev = clouds[0].device
         B = len(clouds)
         rng, vs = voxel_cfg["range"], voxel_cfg["voxel_size"]
@@ -125,8 +127,10 @@ class VoxelNet(SingleStageDetector):
                 sl = slice(b * max_voxels, (b + 1) * max_voxels)
                 i0.mark(coors[sl], n_dev=nvox[b:b + 1], n_max=max_voxels)
 
+        mark_stage("voxelize")
         bb = self.backbone
         idx = bb.build_indexes(mark, B, list(grid), dev)
+        mark_stage("index")
         feats0 = torch.zeros((max(idx[0].n, 1), cpad), dtype=bb.compute_dtype, device=dev)[: idx[0].n]
         L = hip_ops._lib.load()
         for b in range(B):
@@ -136,11 +140,17 @@ class VoxelNet(SingleStageDetector):
                                             hip_ops._p(feats0), cpad, hip_ops._DT[bb.compute_dtype], hip_ops._stream()),
                           "fd_rows_permute")
         x, _ = bb.run_fused(idx, feats0)
+        mark_stage("sparse_backbone")
         x = self.neck(x)
+        mark_stage("rpn")
         preds = self.bbox_head(x, bev_map)
+        mark_stage("head")
         if padded:
-            return self.bbox_head.predict_padded(preds, self.test_cfg)
-        return self.bbox_head.predict({"metadata": [None] * B}, preds, self.test_cfg)
+            out = self.bbox_head.predict_padded(preds, self.test_cfg)
+        else:
+            out = self.bbox_head.predict({"metadata": [None] * B}, preds, self.test_cfg)
+        mark_stage("decode")
+        return out
 
 
 @DETECTORS.register_module
