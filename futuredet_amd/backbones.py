@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import hip_ops, sparse as spconv
-from .nn_utils import bn_affine, build_norm_layer
+from .nn_utils import build_norm_layer
 from .registry import BACKBONES
 from .sparse import SparseConv3d, SubMConv3d
 
@@ -143,8 +143,7 @@ class SpMiddleResNetFHD(nn.Module):
             return rb_cache[key]
 
         def run(conv, bn, x, src, dst, relu, residual=None):
-            scale, shift = bn_affine(bn)
-            wpk, bias, cin_p, cout_p = conv.packed_weight(dt, scale, shift)
+            wpk, bias, cin_p, cout_p = conv.packed_weight(dt, bn)
             assert x.shape[1] == cin_p, (x.shape, cin_p)
             nbr = rulebook(src, dst, conv)
             fn = lambda: hip_ops.spconv_apply(x, wpk, bias, nbr, dst.n, cout_p, residual=residual, relu=relu)  # noqa: E731

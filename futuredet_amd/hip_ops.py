@@ -191,7 +191,7 @@ def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=Fal
         out = torch.empty((max(n_out, 1), cout), dtype=feats.dtype, device=feats.device)[:n_out]
     if residual is not None:
         _dev(residual, "residual", feats.dtype)
-    check(L.fd_spconv_apply(_p(feats), _p(_dev(wpacked, "wpacked")), _p(bias), _p(residual), int(bool(relu)),
+    check(L.fd_spconv_apply(_p(feats), feats.shape[0], _p(_dev(wpacked, "wpacked")), _p(bias), _p(residual), int(bool(relu)),
                             _p(_dev(nbr, "nbr", torch.int32)), nstride, K, n_out, cin, cout, dt, _p(out), _stream()),
           "fd_spconv_apply")
     return out

@@ -110,13 +110,18 @@ class SparseConvolution(SparseModule):
             return self.kernel_size, [1, 1, 1], [k // 2 for k in self.kernel_size]
         return self.kernel_size, self.stride, self.padding
 
-    def packed_weight(self, dtype, scale=None, shift=None):
-        """Fragment-ordered weights (+ fp32 bias) with an optional per-output-channel affine (folded BN)
-        applied; channel counts are padded to multiples of 16.  Cached until the next load_state_dict."""
-        key = (dtype, scale is not None, self.weight.device)
+    def packed_weight(self, dtype, bn=None):
+        """Fragment-ordered weights (+ fp32 bias) with the eval-mode BatchNorm ``bn`` that follows the conv folded
+        in; channel counts are padded to multiples of 16.  Cached until the next load_state_dict."""
+        key = (dtype, id(bn), self.weight.device)
         hit = self._packed.get(key)
         if hit is not None:
             return hit
+        scale = shift = None
+        if bn is not None:
+            from .nn_utils import bn_affine
+
+            scale, shift = bn_affine(bn)
         K = int(np.prod(self.kernel_size))
         w = self.weight.detach().float().reshape(K, self.in_channels, self.out_channels)
         b = self.bias.detach().float() if self.bias is not None else None

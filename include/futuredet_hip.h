@@ -103,7 +103,7 @@ int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int D
  * ------------------------------------------------------------------------------------------------- */
 size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype);
 int fd_spconv_pack_weight(const float *w_kio_host, int K, int cin, int cout, int dtype, void *wpacked_host);
-int fd_spconv_apply(const void *in_feats, const void *wpacked, const float *bias, const void *residual,
+int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *wpacked, const float *bias, const void *residual,
                     int relu, const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int cin, int cout,
                     int dtype, void *out_feats, fd_stream_t stream);
 

@@ -1,0 +1,184 @@
+"""-m "not gpu": pins the CPU oracle against the golden vectors generated from the reference (tests/golden/*,
+made by tests/golden/make_golden.py) and against dense-convolution identities for the spconv-1.0 restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import model as omodel
+from oracle import ops as oops
+
+VOX_CASES = ["tiny", "edges", "cloud_cap", "coarse", "all_out"]
+
+
+@pytest.mark.parametrize("case", VOX_CASES)
+def test_oracle_voxelizer_matches_reference_golden(golden, case):
+    g = golden("voxelizer.npz")
+    cfg = g[case + "_cfg"]
+    v, c, n = oops.points_to_voxel(g[case + "_points"], cfg[:3], cfg[3:9], int(cfg[9]), True, int(cfg[10]))
+    assert np.array_equal(v, g[case + "_voxels"]) and np.array_equal(c, g[case + "_coors"]) and np.array_equal(n, g[case + "_num"])
+
+
+def test_oracle_iou_bit_exact_vs_compiled_reference(golden):
+    g = golden("iou.npz")
+    assert np.array_equal(oops.boxes_iou_bev(g["a"], g["b"]), g["iou"])
+    # known answers from the reference's iou3d_cpu.cpp: identical boxes, shifted + rotated box
+    ka = oops.boxes_iou_bev(np.array([[0, 0, 0, 4, 2, 1.5, 0]], np.float32), np.array([[0, 0, 0, 4, 2, 1.5, 0], [1, 0, 0, 4, 2, 1.5, 0.3]], np.float32))
+    assert ka[0, 0] == 1.0 and abs(ka[0, 1] - 0.5037) < 1e-4
+    ref = oops.ref_boxes_iou_bev(g["a"], g["b"])  # oracle/_ref, when built on this box
+    if ref is not None:
+        assert np.array_equal(ref, g["iou"])
+
+
+def test_oracle_iou_vs_independent_polygon_clipping():
+    """Independent check (float64 Sutherland-Hodgman) so the IoU restatement is not only pinned to itself."""
+    def corners(b):
+        x, y, dx, dy, a = b[0], b[1], b[3], b[4], b[6]
+        pts = np.array([[-dx / 2, -dy / 2], [dx / 2, -dy / 2], [dx / 2, dy / 2], [-dx / 2, dy / 2]])
+        R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+        return pts @ R.T + [x, y]
+
+    def clip(poly, p0, p1):
+        out = []
+        for i in range(len(poly)):
+            a, b = poly[i], poly[(i + 1) % len(poly)]
+            sa = (p1[0] - p0[0]) * (a[1] - p0[1]) - (p1[1] - p0[1]) * (a[0] - p0[0])
+            sb = (p1[0] - p0[0]) * (b[1] - p0[1]) - (p1[1] - p0[1]) * (b[0] - p0[0])
+            if sa >= 0:
+                out.append(a)
+            if sa * sb < 0:
+                out.append(a + (b - a) * (sa / (sa - sb)))
+        return out
+
+    def area(poly):
+        p = np.array(poly)
+        return 0.5 * abs(np.dot(p[:, 0], np.roll(p[:, 1], -1)) - np.dot(p[:, 1], np.roll(p[:, 0], -1))) if len(poly) >= 3 else 0.0
+
+    rng = np.random.default_rng(0)
+    n = 60
+    a = np.zeros((n, 7), np.float32)
+    a[:, :2] = rng.uniform(-3, 3, (n, 2))
+    a[:, 3] = rng.uniform(1.5, 5, n)
+    a[:, 4] = rng.uniform(1, 2.5, n)
+    a[:, 6] = rng.uniform(-3, 3, n)
+    b = a[rng.permutation(n)].copy()
+    b[:, :2] += rng.normal(0, 0.7, (n, 2)).astype(np.float32)
+    got = oops.boxes_iou_bev(a, b)
+    for i in range(0, n, 3):
+        for j in range(0, n, 3):
+            poly = list(corners(a[i].astype(np.float64)))
+            cb = corners(b[j].astype(np.float64))
+            for e in range(4):
+                poly = clip(poly, cb[e], cb[(e + 1) % 4])
+                if not poly:
+                    break
+            inter = area(poly) if poly else 0.0
+            iou = inter / (a[i, 3] * a[i, 4] + b[j, 3] * b[j, 4] - inter)
+            # the reference's MARGIN=1e-2 corner test makes it inexact by design near touching configurations
+            assert abs(got[i, j] - iou) < 2e-2, (i, j, got[i, j], iou)
+
+
+GEOMS = [((3, 3, 3), (1, 1, 1), (1, 1, 1), True), ((3, 3, 3), (2, 2, 2), (1, 1, 1), False),
+         ((3, 3, 3), (2, 2, 2), (0, 1, 1), False), ((3, 1, 1), (2, 1, 1), (0, 0, 0), False), ((1, 1, 1), (1, 1, 1), (0, 0, 0), True)]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_oracle_spconv_equals_dense_conv3d(geom):
+    """spconv-1.0 contract (parity unpinned by the reference): weight (kD,kH,kW,Cin,Cout), cross-correlation,
+    SubM = centred kernel restricted to the input set, strided output set = every site with an active input in
+    its receptive field, out_shape formula -- all checked against torch F.conv3d on the densified tensor."""
+    ks, st, pd, subm = geom
+    rng = np.random.default_rng(0)
+    B, D, H, W, cin, cout = 2, 9, 12, 10, 5, 7
+    occ = rng.random((B, D, H, W)) < 0.15
+    idx = np.argwhere(occ).astype(np.int32)
+    rng.shuffle(idx)
+    feats = rng.standard_normal((len(idx), cin)).astype(np.float32)
+    dense_in = np.zeros((B, cin, D, H, W), np.float32)
+    dense_in[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]] = feats
+    w = rng.standard_normal((*ks, cin, cout)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    oi, pairs, pnum, oshape = oops.rulebook(idx, (D, H, W), ks, st, pd, subm)
+    out = oops.indice_conv(feats, w, b, pairs, pnum, len(oi))
+    pad = [k // 2 for k in ks] if subm else pd
+    ref = F.conv3d(torch.from_numpy(dense_in), torch.from_numpy(w).permute(4, 3, 0, 1, 2).contiguous(), torch.from_numpy(b),
+                   stride=(1, 1, 1) if subm else st, padding=tuple(pad)).numpy()
+    assert list(ref.shape[2:]) == list(oshape)
+    assert np.abs(ref[oi[:, 0], :, oi[:, 1], oi[:, 2], oi[:, 3]] - out).max() < 1e-4
+    if subm:
+        assert np.array_equal(oi, idx)
+    else:
+        act = F.conv3d(torch.from_numpy(occ[:, None].astype(np.float32)), torch.ones(1, 1, *ks), stride=st, padding=tuple(pd)).numpy()[:, 0] > 0
+        assert act.sum() == len(oi) and act[oi[:, 0], oi[:, 1], oi[:, 2], oi[:, 3]].all()
+    d = oops.dense(out, oi, B, oshape)
+    full = np.where(np.broadcast_to((np.abs(d).sum(1, keepdims=True) > 0), d.shape), ref, 0)
+    assert np.abs(d - full).max() < 1e-4
+
+
+def test_oracle_empty_inputs():
+    z = np.zeros((0, 4), np.int32)
+    oi, pairs, pnum, _ = oops.rulebook(z, (5, 8, 8), (3, 3, 3), (2, 2, 2), (1, 1, 1), False)
+    assert len(oi) == 0 and pnum.sum() == 0
+    assert len(oops.nms(np.zeros((0, 7), np.float32), 0.2)) == 0
+    v, c, n = oops.points_to_voxel(np.zeros((0, 5), np.float32), [0.1, 0.1, 0.1], [0, 0, 0, 1, 1, 1], 5, True, 10)
+    assert v.shape == (0, 5, 5) and len(c) == 0
+
+
+def test_oracle_backbone_matches_reference_topology_golden(golden):
+    from futuredet_amd.synth import seeded_state_dict
+
+    g = golden("backbone.npz")
+    bb = omodel.SpMiddleResNetFHD(5).eval()
+    assert sorted(bb.state_dict().keys()) == list(g["keys"])
+    bb.load_state_dict(seeded_state_dict(bb, 41), strict=False)
+    with torch.no_grad():
+        y, ms = bb(torch.from_numpy(g["feats"]), torch.from_numpy(g["coors"]), 2, [int(v) for v in g["grid"]])
+    assert np.abs(y.numpy() - g["y"]).max() <= 1e-4 * np.abs(g["y"]).max()
+    for k in ("conv1", "conv2", "conv3", "conv4"):
+        ind = ms[k].indices.numpy()
+        order = np.lexsort(ind.T[::-1])
+        assert np.array_equal(ind[order], g["ms_%s_idx" % k])
+
+
+def test_oracle_dense_nets_match_reference_golden(golden):
+    from futuredet_amd.synth import seeded_state_dict
+
+    g = golden("dense_nets.npz")
+    rpn = omodel.RPN([2, 2], [1, 2], [16, 32], [1, 2], [32, 32], 24).eval()
+    assert sorted(rpn.state_dict().keys()) == list(g["rpn_keys"])
+    rpn.load_state_dict(seeded_state_dict(rpn, 11), strict=False)
+    with torch.no_grad():
+        y = rpn(torch.from_numpy(g["rpn_x"]))
+    np.testing.assert_allclose(y.numpy(), g["rpn_y"], rtol=1e-4, atol=1e-4)
+    for name, T, dense, ff in (("n0", 1, False, False), ("n3", 7, False, False), ("n3dtf", 7, True, True)):
+        head = omodel.CenterHead(64, [dict(num_class=1, class_names=["car"])],
+                                 {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
+                                 timesteps=T, dense=dense, forecast_feature=ff).eval()
+        assert sorted(head.state_dict().keys()) == list(g["head_%s_keys" % name])
+        head.load_state_dict(seeded_state_dict(head, 12), strict=False)
+        with torch.no_grad():
+            preds = head(y)
+        for ti, pd in enumerate(preds):
+            for k, v in pd.items():
+                np.testing.assert_allclose(v.numpy(), g["head_%s_t%d_%s" % (name, ti, k)], rtol=1e-3, atol=1e-4)
+
+
+TEST_CFG = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], max_per_img=500,
+                nms=dict(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=0.2),
+                score_threshold=0.1, pc_range=[-54, -54], out_size_factor=8, voxel_size=[0.075, 0.075], double_flip=False)
+
+
+@pytest.mark.parametrize("name,T,dense", [("n0", 1, False), ("n3", 7, False), ("n3dtf", 7, True), ("n0big", 1, False)])
+def test_oracle_predict_matches_reference_golden(golden, name, T, dense):
+    g = golden("predict.npz")
+    head = omodel.CenterHead(64, [dict(num_class=1, class_names=["car"])],
+                             {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)}, timesteps=T, dense=dense).eval()
+    ntask = T if dense else 1
+    preds = [{k: torch.from_numpy(g["%s_in_t%d_%s" % (name, ti, k)]) for k in ("reg", "height", "dim", "rot", "vel", "hm")} for ti in range(ntask)]
+    rets = head.predict({"metadata": [None] * preds[0]["hm"].shape[0]}, preds, TEST_CFG)
+    for b, r in enumerate(rets):
+        assert np.array_equal(r["label_preds"].numpy(), g["%s_out_b%d_labels" % (name, b)])
+        np.testing.assert_allclose(r["box3d_lidar"].numpy(), g["%s_out_b%d_boxes" % (name, b)], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(r["scores"].numpy(), g["%s_out_b%d_scores" % (name, b)], rtol=1e-6, atol=1e-7)

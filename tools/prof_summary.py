@@ -1,0 +1,29 @@
+"""Summarise a rocprofv3 --kernel-trace CSV for the LAST step of bench.py (a step starts at vox_hash)."""
+import csv
+import sys
+from collections import OrderedDict
+
+
+def main(path, steps_back=1):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(rows) if "vox_hash" in r["Kernel_Name"]]
+    first = starts[-steps_back]
+    sel = rows[first:]
+    agg = OrderedDict()
+    for r in sel:
+        n = r["Kernel_Name"]
+        n = n.replace("void ", "").replace("(anonymous namespace)::", "")[:70]
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        a = agg.setdefault(n, [0.0, 0])
+        a[0] += d
+        a[1] += 1
+    span = (int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) / 1e3
+    busy = sum(a[0] for a in agg.values())
+    print("last %d step(s): %d kernels, span %.1f us, busy %.1f us (%.1f%%)" % (steps_back, len(sel), span, busy, 100 * busy / span))
+    for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+        print("%9.1f us %4d x  %s" % (d, c, n))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1)
