@@ -310,29 +310,36 @@ __global__ void __launch_bounds__(kSelThreads) dec_select(const unsigned *__rest
     }
 }
 
-// ---------------------------------------------------------------- stage 3: IoU mask tiles (upper triangle)
-__global__ void __launch_bounds__(64) nms_mask(const float *__restrict__ boxes_all, const int *__restrict__ counts, int n_max, int col_blocks,
-                                               float thr, unsigned long long *__restrict__ mask_all) {
-    const int g = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
-    if (cb < rb) return;  // the sweep never reads tiles left of the diagonal (iou3d_nms.cpp:127)
+// ---------------------------------------------------------------- stage 3: IoU mask words (upper triangle)
+// One wave per (row, 64-column block): lane = column, so the 64-bit mask word of iou3d_nms_kernel.cu:296-305 is a
+// single wave ballot.  Pairs whose centres are farther apart than the two half-diagonals (+0.1 m, which covers
+// the reference's 1e-2 corner-inside MARGIN) cannot produce an intersection point or an inside corner, so the
+// reference routine returns exactly 0 for them; they skip the geometry.
+__global__ void __launch_bounds__(256) nms_mask(const float *__restrict__ boxes_all, const int *__restrict__ counts, int n_max, int col_blocks,
+                                                float thr, unsigned long long *__restrict__ mask_all) {
+    const int g = blockIdx.z, cb = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = counts ? counts[g] : n_max;
-    if (rb * 64 >= n || cb * 64 >= n) return;
+    if (row >= n) return;
+    const int rb = row >> 6;
+    if (cb < rb || cb * 64 >= n) return;  // the sweep never reads words left of the diagonal (iou3d_nms.cpp:127)
     const float *boxes = boxes_all + (int64_t)g * n_max * 7;
-    __shared__ float s_box[64 * 7];
-    const int col_size = min(n - cb * 64, 64), row_size = min(n - rb * 64, 64);
-    if ((int)threadIdx.x < col_size)
-        for (int d = 0; d < 7; ++d) s_box[threadIdx.x * 7 + d] = boxes[(int64_t)(cb * 64 + threadIdx.x) * 7 + d];
-    __syncthreads();
-    if ((int)threadIdx.x < row_size) {
-        const int row = rb * 64 + threadIdx.x;
-        float cur[7];
-        for (int d = 0; d < 7; ++d) cur[d] = boxes[(int64_t)row * 7 + d];
-        unsigned long long t = 0;
-        const int start = (rb == cb) ? threadIdx.x + 1 : 0;
-        for (int i = start; i < col_size; ++i)
-            if (iou_bev(cur, s_box + i * 7) > thr) t |= 1ull << i;
-        mask_all[((int64_t)g * n_max + row) * col_blocks + cb] = t;
+    float cur[7], oth[7];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) cur[d] = boxes[(int64_t)row * 7 + d];
+    const int col = cb * 64 + lane;
+    bool hit = false;
+    if (col < n && col > row) {
+#pragma unroll
+        for (int d = 0; d < 7; ++d) oth[d] = boxes[(int64_t)col * 7 + d];
+        const float dx = cur[0] - oth[0], dy = cur[1] - oth[1];
+        const float ra = 0.5f * sqrtf(cur[3] * cur[3] + cur[4] * cur[4]), rb2 = 0.5f * sqrtf(oth[3] * oth[3] + oth[4] * oth[4]);
+        const float reach = ra + rb2 + 0.1f;
+        if (dx * dx + dy * dy <= reach * reach) hit = iou_bev(cur, oth) > thr;
     }
+    const unsigned long long t = __ballot(hit);
+    if (lane == 0) mask_all[((int64_t)g * n_max + row) * col_blocks + cb] = t;
 }
 
 // ---------------------------------------------------------------- stage 4: greedy sweep, one wave per group
@@ -465,7 +472,7 @@ extern "C" int fd_centerpoint_decode(const float *hm, int64_t hm_gs, const float
     const size_t lds = (size_t)w.npad * 8 + 4096 * 4 + 32 * 4;
     hipLaunchKernelGGL(dec_select, dim3(G), dim3(kSelThreads), lds, stream, keys, reg, reg_gs, height, h_gs, dim, dim_gs, rot, rot_gs, c, w.npad,
                        sel_boxes, nms_boxes, sel_scores, sel_cell, sel_count);
-    hipLaunchKernelGGL(nms_mask, dim3(w.col_blocks, w.col_blocks, G), dim3(64), 0, stream, nms_boxes, sel_count, c.pre_max, w.col_blocks,
+    hipLaunchKernelGGL(nms_mask, dim3((c.pre_max + 3) / 4, w.col_blocks, G), dim3(256), 0, stream, nms_boxes, sel_count, c.pre_max, w.col_blocks,
                        c.iou_thr, mask);
     hipLaunchKernelGGL(nms_sweep, dim3(G), dim3(64), 0, stream, mask, sel_count, c.pre_max, w.col_blocks, c.post_max, keep, c.post_max, out_count);
     hipLaunchKernelGGL(dec_gather, dim3(G), dim3(128), 0, stream, keep, out_count, c.post_max, c.pre_max, sel_boxes, sel_scores, sel_cell,
@@ -495,7 +502,7 @@ extern "C" int fd_rotated_nms(const float *boxes7, int n, float thresh, int64_t 
     const int cb = (n + 63) / 64;
     unsigned long long *mask = (unsigned long long *)workspace;
     int *keep32 = (int *)((char *)workspace + fd::align_up(sizeof(unsigned long long) * (size_t)n * cb, 256));
-    hipLaunchKernelGGL(nms_mask, dim3(cb, cb, 1), dim3(64), 0, stream, boxes7, (const int *)nullptr, n, cb, thresh, mask);
+    hipLaunchKernelGGL(nms_mask, dim3((n + 3) / 4, cb, 1), dim3(256), 0, stream, boxes7, (const int *)nullptr, n, cb, thresh, mask);
     hipLaunchKernelGGL(nms_sweep, dim3(1), dim3(64), 0, stream, mask, (const int *)nullptr, n, cb, n, keep32, n, out_count);
     hipLaunchKernelGGL(keep_to_i64, dim3((n + 255) / 256), dim3(256), 0, stream, keep32, out_count, n, (long long *)keep);
     return fd::check_launch("fd_rotated_nms");

@@ -7,14 +7,17 @@
 //
 //   * a workgroup owns TM = 128 consecutive output rows (spatially sorted, so their inputs are close);
 //   * the rulebook tile [K][TM] is staged in LDS and compacted IN PLACE per tap with wave ballots /
-//     prefix popcounts into lists of (input row, local output row) pairs -- the "LDS-staged rulebook tile";
-//   * accumulators for the whole tile live in LDS ([TM][COUT] fp32, 64 KB at COUT = 128);
-//   * each wave owns a column slice of the tile (and, for narrow COUT, a row subset); per tap it keeps its
-//     slice of W[k] in registers, walks the compacted list 16 pairs at a time, gathers the 16 input rows
-//     straight into MFMA A-fragment layout (one 16-byte load per lane and 16-channel chunk), reads the 16
-//     accumulator rows from LDS as the MFMA C operand, runs the CIN/4 x NBW MFMAs and writes D back.
-//     A wave never shares an accumulator element with another wave, so there are no atomics, no barriers in
-//     the tap loop, and the summation order per output element is fixed (taps ascending) -> deterministic.
+//     prefix popcounts into lists of (input row << 8 | local output row) entries, tails filled with -1 --
+//     the "LDS-staged rulebook tile";
+//   * accumulators for the whole tile live in LDS ([TM + 1][COUT] fp32, 64 KB at COUT = 128; row TM is a
+//     scratch row that absorbs the padding lanes so the accumulator traffic needs no exec masking);
+//   * each wave owns a column slice of the tile (and, for narrow COUT, a row subset) and walks a flattened
+//     work list of (tap, 16-pair group) items: gather the 16 input rows straight into MFMA A-fragment layout
+//     (one 16-byte bounds-checked buffer load per lane and 16-channel chunk, prefetched DEPTH items ahead with
+//     exact vmcnt accounting), read the 16 accumulator rows from LDS as the MFMA C operand, run the
+//     CIN/4 x NBW MFMAs, write D back.  The wave's slice of W[tap] stays in registers for the whole tap
+//     (double buffered one tap ahead when it is small).  A wave never shares an accumulator element with another
+//     wave: no atomics, no barriers in the main loop, fixed summation order (taps ascending) -> deterministic.
 //   * epilogue: bias (+ residual) (+ ReLU) on the LDS tile, written out with 16-byte row-contiguous stores.
 #include "fd_common.h"
 
@@ -22,6 +25,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxTaps = 27;
 constexpr int kMaxItems = kMaxTaps * 8;  // per wave: taps x (128 rows / 16)
 
@@ -35,12 +39,13 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     constexpr int NBW = NB / WC;          // 16-column blocks per wave
     constexpr int WR = 4 / WC;            // row splits
     constexpr int RW = TM / WR;           // rows in a wave's row set
-    static_assert(TM <= 128 && RW >= 16, "local row must fit 7 bits");
+    constexpr int NACC = NBW == 1 ? 2 : NBW;  // independent MFMA chains (a single column block splits its K chain in two)
+    static_assert(TM == 128 && RW >= 16, "local row uses 8 bits (0..TM, TM = scratch row)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *s_list = reinterpret_cast<int *>(smem);             // [K][TM]  raw nbr, then compacted (in<<7 | row)
-    int *s_cnt = s_list + kMaxTaps * TM;                     // [K][WR]
-    unsigned short *s_items = reinterpret_cast<unsigned short *>(s_cnt + kMaxTaps * 4);  // [4 waves][kMaxItems]
-    float *s_acc = reinterpret_cast<float *>(s_items + 4 * kMaxItems);  // [TM][COUT], 16-byte aligned (15984 B in)
+    int *s_list = reinterpret_cast<int *>(smem);                                            // [K][TM] raw nbr, then compacted entries
+    unsigned short *s_items = reinterpret_cast<unsigned short *>(s_list + kMaxTaps * TM);   // [4 waves][kMaxItems]
+    unsigned char *s_cnt = reinterpret_cast<unsigned char *>(s_items + 4 * kMaxItems);      // [K][4] (<= 128 each)
+    float *s_acc = reinterpret_cast<float *>(s_cnt + 112);                                  // [TM + 1][COUT]; 13824 + 1728 + 112 = 15664 B in
 
     const int tile = fd::xcd_swizzle(blockIdx.x, gridDim.x);
     const int row0 = tile * TM;
@@ -50,24 +55,34 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         int64_t o = (int64_t)row0 + r;
         s_list[t] = (o < nbr_stride) ? nbr[(int64_t)k * nbr_stride + o] : -1;
     }
-    for (int t = tid; t < TM * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = tid; t < (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    // ---- in-place compaction: wave w takes taps w, w+4, ...
+    // ---- in-place compaction: wave w takes taps w, w+4, ...; tails are filled with -1
     for (int k = wave; k < K; k += 4) {
 #pragma unroll
         for (int wr = 0; wr < WR; ++wr) {
             const int base = k * TM + wr * RW;
             int count = 0;
+            int v[(RW + 63) / 64];
 #pragma unroll
             for (int h = 0; h < (RW + 63) / 64; ++h) {
                 const int r = h * 64 + lane;
-                const int v = (r < RW) ? s_list[base + r] : -1;
-                const unsigned long long m = __ballot(v >= 0);
+                v[h] = (r < RW) ? s_list[base + r] : -1;
+            }
+#pragma unroll
+            for (int h = 0; h < (RW + 63) / 64; ++h) {
+                const int r = h * 64 + lane;
+                if (r < RW) s_list[base + r] = -1;
+            }
+#pragma unroll
+            for (int h = 0; h < (RW + 63) / 64; ++h) {
+                const int r = h * 64 + lane;
+                const unsigned long long m = __ballot(v[h] >= 0);
                 const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-                if (v >= 0) s_list[base + pos] = (v << 7) | (wr * RW + r);
+                if (v[h] >= 0) s_list[base + pos] = (v[h] << 8) | (wr * RW + r);
                 count += __popcll(m);
             }
-            if (lane == 0) s_cnt[k * 4 + wr] = count;
+            if (lane == 0) s_cnt[k * 4 + wr] = (unsigned char)count;
         }
     }
     __syncthreads();
@@ -78,8 +93,10 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     // ---- flattened work list of this wave: one item = 16 compacted pairs of one tap, code = (tap << 3) | group
     unsigned short *items = s_items + wave * kMaxItems;
     int n_items;
+    unsigned long long tapmask;
     {
-        const int ng = (lane < K) ? (s_cnt[lane * 4 + wr] + 15) >> 4 : 0;
+        const int ng = (lane < K) ? ((int)s_cnt[lane * 4 + wr] + 15) >> 4 : 0;
+        tapmask = __ballot(ng > 0);
         int inc = ng;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -94,33 +111,49 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    // ring of DEPTH prefetched items: entry (input row << 7 | local row, or -1), tap, gathered A fragments.
-    // The gathers are buffer loads with hardware bounds checking: a padding lane / a slot past the end of the
-    // work list gets an out-of-range offset and reads zeros, so the prefetch is branch-free and the compiler can
-    // keep exact vmcnt(N) counts (exec-masked loads forced vmcnt(0), i.e. no overlap at all).
+    // ring of DEPTH prefetched items.  Gathers are buffer loads with hardware bounds checking: a padding lane / a
+    // slot past the end of the work list gets an out-of-range offset and reads zeros, so prefetch AND compute are
+    // branch-free (exec-masked loads forced vmcnt(0), i.e. no overlap at all; branches around the MFMAs kept the
+    // compiler from interleaving the bookkeeping VALU/LDS work with them).
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
-    int e_r[DEPTH], k_r[DEPTH];
+    int k_r[DEPTH];
+    i32x4 rows_r[DEPTH];  // entries of the 4 accumulator rows this lane touches (group rows 4*lq .. 4*lq+3)
     u32x4 a_r[DEPTH][NC];
-    auto fetch = [&](int it, int &e, int &kk, u32x4(&a)[NC]) {
+#ifdef FD_ABL_NOB
+    int kcur_abl = -1;
+#endif
+    auto fetch = [&](int it, int &kk, i32x4 &rows, u32x4(&a)[NC]) {
         const bool v = it < n_items;
         const int code = items[v ? it : 0];
         const int ks = v ? (code >> 3) : 0;
         kk = v ? ks : -1;
-        const int idx = (((code & 7) << 4) + lrow) & (TM - 1);
-        const int ent = s_list[ks * TM + wr * RW + idx];
-        e = (v && idx < s_cnt[ks * 4 + wr]) ? ent : -1;
-        const unsigned voff = e >= 0 ? (unsigned)(e >> 7) * (unsigned)(CIN * 4) + (unsigned)(lq * 16) : in_bytes;
+        const int *lst = s_list + ks * TM + wr * RW + ((code & 7) << 4);
+        int e = lst[lrow];
+        rows = *reinterpret_cast<const i32x4 *>(lst + lq * 4);
+        if (!v) {
+            e = -1;
+            rows = (i32x4){-1, -1, -1, -1};
+        }
+#ifdef FD_ABL_NOGATHER
+        const unsigned voff = e >= 0 ? (unsigned)(lq * 16) : in_bytes;  // ablation: every pair reads row 0 (L1-resident)
+#else
+        const unsigned voff = e >= 0 ? (unsigned)(e >> 8) * (unsigned)(CIN * 4) + (unsigned)(lq * 16) : in_bytes;
+#endif
 #pragma unroll
         for (int c = 0; c < NC; ++c) a[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + c * 64, 0, 0);
     };
     auto load_b = [&](int k, float4(&dst)[NC][NBW]) {
+#ifdef FD_ABL_NOB
+        k = 0;  // ablation: always the same (cache-resident) weight slice
+        if (kcur_abl >= 0) return;
+        kcur_abl = 0;
+#endif
         const float4 *wk = wp + ((int64_t)k * NC * NB + wc * NBW) * 64 + lane;
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int nw = 0; nw < NBW; ++nw) dst[c][nw] = wk[(c * NB + nw) * 64];
     };
-    const unsigned long long tapmask = __ballot(lane < K && s_cnt[(lane < K ? lane : 0) * 4 + wr] > 0);
     // small weight slices are double buffered a whole tap ahead; the 128x128 slice (64 VGPRs) is loaded at the tap
     // switch instead, which keeps the kernel at two waves per SIMD (the LDS tile allows two workgroups per CU)
     constexpr bool BPF = NC * NBW <= 8;
@@ -129,39 +162,57 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     if constexpr (BPF) {
         if (tapmask) load_b(__builtin_ctzll(tapmask), bn);  // weights of the first non-empty tap
     }
+    static_assert(DEPTH >= 2, "the slot freed by the previous item is refilled during the current item's MFMAs");
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) fetch(d, e_r[d], k_r[d], a_r[d]);
+    for (int d = 0; d < DEPTH - 1; ++d) fetch(d, k_r[d], rows_r[d], a_r[d]);
+    k_r[DEPTH - 1] = -1;
 
     for (int i0 = 0; i0 < n_items; i0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            if (k_r[d] >= 0) {  // wave-uniform; no vector-memory op inside except the weight prefetch at a tap switch
-                if (k_r[d] != kcur) {
-                    kcur = k_r[d];
-                    if constexpr (BPF) {
+            if (k_r[d] >= 0 && k_r[d] != kcur) {  // wave-uniform tap switch (about one item in five)
+                kcur = k_r[d];
+                if constexpr (BPF) {
 #pragma unroll
-                        for (int c = 0; c < NC; ++c)
+                    for (int c = 0; c < NC; ++c)
 #pragma unroll
-                            for (int nw = 0; nw < NBW; ++nw) b[c][nw] = bn[c][nw];
-                        const unsigned long long rest = (kcur + 1 < 64) ? (tapmask >> (kcur + 1)) : 0ull;
-                        if (rest) load_b(kcur + 1 + __builtin_ctzll(rest), bn);  // next tap's weights, a whole tap ahead
-                    } else {
-                        load_b(kcur, b);
-                    }
+                        for (int nw = 0; nw < NBW; ++nw) b[c][nw] = bn[c][nw];
+                    const unsigned long long rest = (kcur + 1 < 64) ? (tapmask >> (kcur + 1)) : 0ull;
+                    if (rest) load_b(kcur + 1 + __builtin_ctzll(rest), bn);  // next tap's weights, a whole tap ahead
+                } else {
+                    load_b(kcur, b);
                 }
-                const int e = e_r[d];
-                int orow[4];
+            }
+            // accumulator rows: padding entries (-1) go to the scratch row TM
+            int aoff[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) orow[r] = __shfl(e, lq * 4 + r);  // entry of group row 4*lq + r (-1 = padding)
-                f32x4 acc[NBW];
+#ifdef FD_ABL_NOACC
+            for (int r = 0; r < 4; ++r) aoff[r] = (lq * 4 + r) * COUT + cb + lrow;  // ablation: conflict-free fixed rows
+#else
+            for (int r = 0; r < 4; ++r) aoff[r] = (rows_r[d][r] >= 0 ? (rows_r[d][r] & 255) : TM) * COUT + cb + lrow;
+#endif
+            f32x4 acc[NACC];
 #pragma unroll
-                for (int nw = 0; nw < NBW; ++nw)
+            for (int nw = 0; nw < NBW; ++nw)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        acc[nw][r] = orow[r] >= 0 ? s_acc[(orow[r] & 127) * COUT + cb + nw * 16 + lrow] : 0.0f;
+                for (int r = 0; r < 4; ++r) acc[nw][r] = s_acc[aoff[r] + nw * 16];
+            if constexpr (NBW == 1) acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // refill the slot freed by the previous item; its LDS reads / address maths / buffer loads are independent
+            // of this item's MFMAs and are interleaved into the MFMA stream by the scheduling hints below
+            {
+                const int dn = (d + DEPTH - 1) % DEPTH;  // compile-time after unrolling
+                fetch(i0 + d + DEPTH - 1, k_r[dn], rows_r[dn], a_r[dn]);
+            }
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const float4 av = __builtin_bit_cast(float4, a_r[d][c]);
+            for (int c = 0; c < NC; ++c) {
+                const float4 av = __builtin_bit_cast(float4, a_r[d][c]);
+                if constexpr (NBW == 1) {
+                    // one column block: alternate two accumulators so consecutive MFMAs are independent
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b[c][0].x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b[c][0].y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b[c][0].z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b[c][0].w, acc[1], 0, 0, 0);
+                } else {
 #pragma unroll
                     for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b[c][nw].x, acc[nw], 0, 0, 0);
 #pragma unroll
@@ -171,13 +222,23 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 #pragma unroll
                     for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b[c][nw].w, acc[nw], 0, 0, 0);
                 }
+            }
+            if constexpr (NBW == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_acc[aoff[r]] = acc[0][r] + acc[1][r];
+            } else {
 #pragma unroll
                 for (int nw = 0; nw < NBW; ++nw)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (orow[r] >= 0) s_acc[(orow[r] & 127) * COUT + cb + nw * 16 + lrow] = acc[nw][r];
+                    for (int r = 0; r < 4; ++r) s_acc[aoff[r] + nw * 16] = acc[nw][r];
             }
-            fetch(i0 + d + DEPTH, e_r[d], k_r[d], a_r[d]);  // refill the slot just consumed (unconditional, branch-free)
+#pragma unroll
+            for (int m = 0; m < NC * 4 * NBW; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);    // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // <= 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);    // <= 3 VALU
+                __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);   // <= 1 VMEM read
+            }
         }
     }
     __syncthreads();
@@ -204,7 +265,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 template <int CIN, int COUT, int TM, int DEPTH>
 int launch_compact(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
                    int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, hipStream_t stream) {
-    const size_t lds = sizeof(int) * (kMaxTaps * TM + kMaxTaps * 4) + sizeof(unsigned short) * 4 * kMaxItems + sizeof(float) * TM * COUT;
+    const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxItems + 112 + sizeof(float) * (TM + 1) * COUT;
     static bool attr_set = false;
     auto kern = spconv_f32_compact<CIN, COUT, TM, DEPTH>;
     if (!attr_set) {
@@ -225,19 +286,26 @@ namespace fd {
 // returns 1 when launched, 0 when this shape is not covered (caller falls back to the register kernel)
 int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
                                 int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, hipStream_t stream) {
-    // (input row << 7 | local row) must fit an int32 and the feature matrix a 31-bit buffer range
-    if (n_in_bound >= (1ll << 24) || n_in_bound * cin * 4 >= (1ll << 31)) return 0;
+    // (input row << 8 | local row) must fit an int32 and the feature matrix a 31-bit buffer range
+    if (n_in_bound >= (1ll << 23) || n_in_bound * cin * 4 >= (1ll << 31)) return 0;
     const unsigned in_bytes = (unsigned)(n_in_bound * cin * 4);
-#define FD_CASE(CI, CO) \
-    if (cin == CI && cout == CO)  \
-        return launch_compact<CI, CO, 128, (CI >= 128 ? 2 : (CI >= 64 ? 3 : 4))>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, stream);
-    FD_CASE(16, 16)
-    FD_CASE(16, 32)
-    FD_CASE(32, 32)
-    FD_CASE(32, 64)
-    FD_CASE(64, 64)
-    FD_CASE(64, 128)
-    FD_CASE(128, 128)
+    const char *env = getenv("FD_V2_DEPTH");  // tuning override
+    const int dsel = env ? atoi(env) : 0;
+#define FD_CASE(CI, CO, DDEF)                                                                                                         \
+    if (cin == CI && cout == CO) {                                                                                                    \
+        const int dd = dsel ? dsel : DDEF;                                                                                            \
+        \
+        if (dd <= 2) return launch_compact<CI, CO, 128, 2>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, stream); \
+        if (dd == 3) return launch_compact<CI, CO, 128, 3>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, stream); \
+        return launch_compact<CI, CO, 128, 4>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, stream);        \
+    }
+    FD_CASE(16, 16, 4)
+    FD_CASE(16, 32, 4)
+    FD_CASE(32, 32, 4)
+    FD_CASE(32, 64, 4)
+    FD_CASE(64, 64, 3)
+    FD_CASE(64, 128, 3)
+    FD_CASE(128, 128, 2)
 #undef FD_CASE
     return 0;
 }

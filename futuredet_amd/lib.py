@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfuturedet_hip.so")
+LIB_PATH = os.environ.get("FD_LIB_PATH") or os.path.join(_HERE, "libfuturedet_hip.so")  # override: tuning builds only
 _lib = None
 
 c_void_p = ctypes.c_void_p

@@ -50,3 +50,19 @@ s = 4 if dt == torch.float32 else 2
 bgs = s * pairs * 2 * C + 8 * pairs + s * 27 * C * C
 print("level %d C=%d n=%d pairs=%d (%.1f/row) %s: %.1f us  pair-GFLOP/s %.0f  B_gs %.0f GB/s" %
       (lvl, C, ix.n, pairs, pairs / ix.n, args.dtype, us, 2.0 * pairs * C * C / us / 1e3, bgs / us / 1e3))
+# ---- work distribution over 128-row tiles (load-balance analysis)
+valid = (nbr[:, :ix.n] >= 0)
+nt = (ix.n + 127) // 128
+pad = nt * 128 - ix.n
+v = torch.nn.functional.pad(valid, (0, pad)).view(27, nt, 128).sum(2)      # [27, nt] pairs per tap per tile
+groups = ((v + 15) // 16).sum(0).cpu().numpy()                              # MFMA groups per tile
+print("tiles %d: groups/tile mean %.1f max %d min %d; padded-slot efficiency %.3f" %
+      (nt, groups.mean(), groups.max(), groups.min(), pairs / (groups.sum() * 16.0)))
+for slots in (256, 512, 768):
+    # blocks resident at once, contiguous chunk per XCD (xcd_swizzle) vs round-robin
+    import numpy as np
+    per = np.zeros(slots)
+    order = np.arange(nt)
+    for name, assign in (("round-robin", order % slots), ("xcd-chunk", (order * slots // nt))):
+        load = np.bincount(assign, weights=groups, minlength=slots)
+        print("  %d slots %-11s: max load %.0f vs mean %.1f -> efficiency %.2f" % (slots, name, load.max(), groups.sum() / slots, groups.sum() / slots / load.max()))
