@@ -74,9 +74,9 @@ def cpu_baseline(cfg, sd, cloud):
     from oracle import model as omodel
     from oracle import ops as oops
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)  # beyond ~64 threads the pair-list loops stop scaling (fork/join per tap)
     torch.set_num_threads(cores)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    oops.set_threads(cores)
     onet = omodel.VoxelNet(cfg.model["reader"], cfg.model["backbone"], cfg.model["neck"], cfg.model["bbox_head"],
                            test_cfg=cfg.test_cfg).eval()
     onet.load_state_dict(sd, strict=False)
@@ -189,8 +189,17 @@ def main():
         tot_flops = sum(2.0 * pair_counts[i % per_step] * info["cin"] * info["cout"] for i, (_, info, _) in enumerate(ms))
         launches = len(ms)
         ach = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs
+        # of this same command, gfx950 x2 read correction applied; see profiles/spconv_traffic.json) -- a profiler
+        # cannot run inside the timed process, so the figure is looked up for the matching workload, else null
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "spconv_traffic.json")))
+            traffic = tj.get("%s/%s/%d/b%d" % (args.variant, args.dtype, args.points, args.batch), {}).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                            "kernel": "spconv_f32/spconv_bf16 (fd_spconv_apply)", "launches_per_step": per_step,
                            "avg_launch_us": round(1e3 * tot_ms / max(launches, 1), 2),
                            "algorithmic_bytes_per_launch": int(tot_bytes / max(launches, 1)),

@@ -211,6 +211,9 @@ int64_t fdo_rulebook(const int32_t *indices /* [n,4] (b,z,y,x) */, int64_t n,
 /*     bias added after the scatter.  Call sites scn.py:99-141.               */
 /*     fp32 accumulate, taps visited in kernel-offset order.                  */
 /* ------------------------------------------------------------------------- */
+#if defined(__x86_64__) && defined(__GNUC__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
 void fdo_indice_conv(const float *in_feats, int64_t n_in, int cin,
                      const float *weight /* [K,cin,cout] */, const float *bias /* [cout] or NULL */,
                      const int32_t *pairs /* [K,2,n_in] */, const int32_t *pair_num, int K,
@@ -225,11 +228,12 @@ void fdo_indice_conv(const float *in_feats, int64_t n_in, int cin,
         /* within one tap every output row occurs at most once -> race free */
 #pragma omp parallel for schedule(static)
         for (int32_t t = 0; t < np; ++t) {
-            const float *x = in_feats + (int64_t)pin[t] * cin;
-            float *y = out_feats + (int64_t)pout[t] * cout;
+            const float *restrict x = in_feats + (int64_t)pin[t] * cin;
+            float *restrict y = out_feats + (int64_t)pout[t] * cout;
             for (int ci = 0; ci < cin; ++ci) {
                 const float xv = x[ci];
-                const float *w = W + (int64_t)ci * cout;
+                const float *restrict w = W + (int64_t)ci * cout;
+#pragma omp simd
                 for (int co = 0; co < cout; ++co) y[co] += xv * w[co];
             }
         }
@@ -387,6 +391,15 @@ void fdo_boxes_iou_bev(const float *a, int na, const float *b, int nb, float *ou
 {
     for (int i = 0; i < na; ++i)
         for (int j = 0; j < nb; ++j) out[(int64_t)i * nb + j] = fdo_iou_bev(a + i * 7, b + j * 7);
+}
+
+void fdo_set_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 /* nms: mask bit (i,j) set iff j>i and iou(i,j) > thresh (iou3d_nms_kernel.cu:267-311), then the

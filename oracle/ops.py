@@ -46,6 +46,8 @@ def lib():
         L.fdo_iou_bev.argtypes = [_f32p, _f32p]
         L.fdo_boxes_iou_bev.restype = None
         L.fdo_boxes_iou_bev.argtypes = [_f32p, ctypes.c_int, _f32p, ctypes.c_int, _f32p]
+        L.fdo_set_threads.restype = None
+        L.fdo_set_threads.argtypes = [ctypes.c_int]
         L.fdo_nms.restype = ctypes.c_int
         L.fdo_nms.argtypes = [_f32p, ctypes.c_int, ctypes.c_float, _i64p]
         _LIB = L
@@ -66,6 +68,10 @@ def ref_iou_lib():
         R.fdref_boxes_iou_bev.argtypes = [_f32p, ctypes.c_int, _f32p, ctypes.c_int, _f32p]
         _REF = R
     return _REF
+
+
+def set_threads(n):
+    lib().fdo_set_threads(int(n))
 
 
 # --------------------------------------------------------------------------------------
