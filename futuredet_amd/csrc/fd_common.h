@@ -10,7 +10,8 @@ namespace fd {
 
 void set_error(const char *fmt, ...);
 int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
-                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, hipStream_t stream);
+                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, const int *tile_order,
+                                hipStream_t stream);
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

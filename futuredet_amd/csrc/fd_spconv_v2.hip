@@ -27,27 +27,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxTaps = 27;
-constexpr int kMaxItems = kMaxTaps * 8;  // per wave: taps x (128 rows / 16)
 
 template <int CIN, int COUT, int TM, int DEPTH>
 __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restrict__ in, const float4 *__restrict__ wp,
                                                           const float *__restrict__ bias, const float *__restrict__ residual, int relu,
                                                           const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
-                                                          float *__restrict__ out, unsigned in_bytes) {
+                                                          float *__restrict__ out, unsigned in_bytes, const int *__restrict__ tile_order) {
     constexpr int NB = COUT / 16, NC = CIN / 16;
     constexpr int WC = NB >= 4 ? 4 : NB;  // column splits across the 4 waves
     constexpr int NBW = NB / WC;          // 16-column blocks per wave
     constexpr int WR = 4 / WC;            // row splits
     constexpr int RW = TM / WR;           // rows in a wave's row set
     constexpr int NACC = NBW == 1 ? 2 : NBW;  // independent MFMA chains (a single column block splits its K chain in two)
-    static_assert(TM == 128 && RW >= 16, "local row uses 8 bits (0..TM, TM = scratch row)");
+    static_assert((TM == 128 || TM == 64) && RW >= 16, "local row uses 8 bits (0..TM, TM = scratch row)");
+    constexpr int kMaxItems = kMaxTaps * (TM / 16);           // per wave: taps x 16-row groups
+    constexpr int kPad = (int)(0xffffff00u | (unsigned)TM);  // list padding: input offset out of range, local row = TM (scratch row)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *s_list = reinterpret_cast<int *>(smem);                                            // [K][TM] raw nbr, then compacted entries
     unsigned short *s_items = reinterpret_cast<unsigned short *>(s_list + kMaxTaps * TM);   // [4 waves][kMaxItems]
     unsigned char *s_cnt = reinterpret_cast<unsigned char *>(s_items + 4 * kMaxItems);      // [K][4] (<= 128 each)
-    float *s_acc = reinterpret_cast<float *>(s_cnt + 112);                                  // [TM + 1][COUT]; 13824 + 1728 + 112 = 15664 B in
+    float *s_acc = reinterpret_cast<float *>(s_cnt + 112);                                  // [TM + 1][COUT], 16-byte aligned for TM = 64 and 128
 
-    const int tile = fd::xcd_swizzle(blockIdx.x, gridDim.x);
+    // tiles differ in work by up to 2x (dense regions near the sensor): the optional order puts heavy tiles first and
+    // pairs them with light ones on a CU (fd_spconv_tile_order); without it tiles run in index order.
+    const int tile = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
     const int row0 = tile * TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int t = tid; t < K * TM; t += 256) {
@@ -57,7 +60,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     }
     for (int t = tid; t < (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    // ---- in-place compaction: wave w takes taps w, w+4, ...; tails are filled with -1
+    // ---- in-place compaction: wave w takes taps w, w+4, ...; tails are filled with kPad
     for (int k = wave; k < K; k += 4) {
 #pragma unroll
         for (int wr = 0; wr < WR; ++wr) {
@@ -72,7 +75,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 #pragma unroll
             for (int h = 0; h < (RW + 63) / 64; ++h) {
                 const int r = h * 64 + lane;
-                if (r < RW) s_list[base + r] = -1;
+                if (r < RW) s_list[base + r] = kPad;
             }
 #pragma unroll
             for (int h = 0; h < (RW + 63) / 64; ++h) {
@@ -119,35 +122,29 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     int k_r[DEPTH];
     i32x4 rows_r[DEPTH];  // entries of the 4 accumulator rows this lane touches (group rows 4*lq .. 4*lq+3)
     u32x4 a_r[DEPTH][NC];
-#ifdef FD_ABL_NOB
-    int kcur_abl = -1;
-#endif
+    // Bookkeeping is kept off the vector ALU (it competes with the MFMAs for issue slots): the item code is
+    // wave-uniform (scalar registers), and a list entry needs no compare/select -- the padding entry kPad has all
+    // high bits set, so its byte offset lands beyond the buffer (hardware returns zeros) and its row field is the
+    // scratch row TM.
     auto fetch = [&](int it, int &kk, i32x4 &rows, u32x4(&a)[NC]) {
-        const bool v = it < n_items;
-        const int code = items[v ? it : 0];
+        const bool v = it < n_items;  // uniform
+        const int code = __builtin_amdgcn_readfirstlane((int)items[v ? it : 0]);
         const int ks = v ? (code >> 3) : 0;
         kk = v ? ks : -1;
         const int *lst = s_list + ks * TM + wr * RW + ((code & 7) << 4);
         int e = lst[lrow];
         rows = *reinterpret_cast<const i32x4 *>(lst + lq * 4);
-        if (!v) {
-            e = -1;
-            rows = (i32x4){-1, -1, -1, -1};
+        if (!v) {  // uniform
+            e = kPad;
+            rows = (i32x4){kPad, kPad, kPad, kPad};
         }
-#ifdef FD_ABL_NOGATHER
-        const unsigned voff = e >= 0 ? (unsigned)(lq * 16) : in_bytes;  // ablation: every pair reads row 0 (L1-resident)
-#else
-        const unsigned voff = e >= 0 ? (unsigned)(e >> 8) * (unsigned)(CIN * 4) + (unsigned)(lq * 16) : in_bytes;
-#endif
+        // byte offset of the input row = (e >> 8) * CIN * 4, computed on the masked entry without a multiply
+        const unsigned hi = (unsigned)e & 0xffffff00u;
+        const unsigned voff = (CIN >= 64 ? hi << (CIN == 128 ? 1 : 0) : hi >> (CIN == 32 ? 1 : 2)) + (unsigned)(lq * 16);
 #pragma unroll
         for (int c = 0; c < NC; ++c) a[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + c * 64, 0, 0);
     };
     auto load_b = [&](int k, float4(&dst)[NC][NBW]) {
-#ifdef FD_ABL_NOB
-        k = 0;  // ablation: always the same (cache-resident) weight slice
-        if (kcur_abl >= 0) return;
-        kcur_abl = 0;
-#endif
         const float4 *wk = wp + ((int64_t)k * NC * NB + wc * NBW) * 64 + lane;
 #pragma unroll
         for (int c = 0; c < NC; ++c)
@@ -183,26 +180,24 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
                     load_b(kcur, b);
                 }
             }
-            // accumulator rows: padding entries (-1) go to the scratch row TM
+            // accumulator rows: the row field of a padding entry is the scratch row TM
             int aoff[4];
 #pragma unroll
-#ifdef FD_ABL_NOACC
-            for (int r = 0; r < 4; ++r) aoff[r] = (lq * 4 + r) * COUT + cb + lrow;  // ablation: conflict-free fixed rows
-#else
-            for (int r = 0; r < 4; ++r) aoff[r] = (rows_r[d][r] >= 0 ? (rows_r[d][r] & 255) : TM) * COUT + cb + lrow;
-#endif
+            for (int r = 0; r < 4; ++r) aoff[r] = (rows_r[d][r] & 255) * COUT + cb + lrow;
             f32x4 acc[NACC];
 #pragma unroll
             for (int nw = 0; nw < NBW; ++nw)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[nw][r] = s_acc[aoff[r] + nw * 16];
             if constexpr (NBW == 1) acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // refill the slot freed by the previous item; its LDS reads / address maths / buffer loads are independent
-            // of this item's MFMAs and are interleaved into the MFMA stream by the scheduling hints below
+            // refill the slot freed by the previous item BEFORE this item's MFMAs.  Left to itself hipcc sinks these
+            // loads below the MFMA block and then waits vmcnt(0) for them at the top of the next item, exposing the whole
+            // gather latency on every item; the scheduling barrier pins them here so they fly under 2048 MFMA cycles.
             {
                 const int dn = (d + DEPTH - 1) % DEPTH;  // compile-time after unrolling
                 fetch(i0 + d + DEPTH - 1, k_r[dn], rows_r[dn], a_r[dn]);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const float4 av = __builtin_bit_cast(float4, a_r[d][c]);
@@ -232,13 +227,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s_acc[aoff[r] + nw * 16] = acc[nw][r];
             }
-#pragma unroll
-            for (int m = 0; m < NC * 4 * NBW; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);    // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // <= 1 DS read
-                __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);    // <= 3 VALU
-                __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);   // <= 1 VMEM read
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
@@ -264,8 +253,8 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 
 template <int CIN, int COUT, int TM, int DEPTH>
 int launch_compact(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
-                   int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, hipStream_t stream) {
-    const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxItems + 112 + sizeof(float) * (TM + 1) * COUT;
+                   int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, const int *tile_order, hipStream_t stream) {
+    const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxTaps * (TM / 16) + 112 + sizeof(float) * (TM + 1) * COUT;
     static bool attr_set = false;
     auto kern = spconv_f32_compact<CIN, COUT, TM, DEPTH>;
     if (!attr_set) {
@@ -276,37 +265,116 @@ int launch_compact(const float *in, const void *wp, const float *bias, const flo
         attr_set = true;
     }
     dim3 grid((unsigned)((n_out + TM - 1) / TM));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, in, (const float4 *)wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, in, (const float4 *)wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, tile_order);
     return 1;
+}
+
+// ---------------------------------------------------------------------------------------------- tile order
+// work of a 128-row tile = number of 16-pair MFMA groups = sum over taps of ceil(valid rows / 16)
+__global__ void __launch_bounds__(128) tile_work_kernel(const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_tiles, unsigned *__restrict__ keys) {
+    const int tile = blockIdx.x, r = threadIdx.x;
+    __shared__ int s_half[2];
+    int work = 0;
+    for (int k = 0; k < K; ++k) {
+        const int64_t o = (int64_t)tile * 128 + r;
+        const bool v = o < nbr_stride && nbr[(int64_t)k * nbr_stride + o] >= 0;
+        const int c = __popcll(__ballot(v));
+        if ((r & 63) == 0) s_half[r >> 6] = c;
+        __syncthreads();
+        work += (s_half[0] + s_half[1] + 15) >> 4;
+        __syncthreads();
+    }
+    if (r == 0) keys[tile] = ((unsigned)work << 20) | (0xfffffu - (unsigned)tile);  // sort key: work desc, tile asc
+}
+
+// single workgroup: bitonic sort (descending) of <= 16384 keys in LDS, then the CU pairing rule
+__global__ void __launch_bounds__(1024) tile_sort_kernel(const unsigned *__restrict__ keys, int n_tiles, int npad, int n_cu, int *__restrict__ order) {
+    extern __shared__ unsigned s_keys[];
+    for (int i = threadIdx.x; i < npad; i += 1024) s_keys[i] = i < n_tiles ? keys[i] : 0u;
+    __syncthreads();
+    for (int k2 = 2; k2 <= npad; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < npad; t += 1024) {
+                const int x = t ^ j;
+                if (x > t) {
+                    const unsigned a = s_keys[t], b = s_keys[x];
+                    const bool desc = (t & k2) == 0;
+                    if (desc ? (a < b) : (a > b)) { s_keys[t] = b; s_keys[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // all tiles resident at once (<= 2 per CU): workgroups b and b + n_cu tend to share a CU, so the heaviest n_cu tiles
+    // go first and are followed by the rest lightest-first; otherwise plain heaviest-first (greedy LPT by the dispatcher)
+    const bool pair = n_tiles <= 2 * n_cu;
+    const int nh = n_tiles < n_cu ? n_tiles : n_cu;
+    for (int i = threadIdx.x; i < n_tiles; i += 1024) {
+        const int src = (!pair || i < nh) ? i : n_tiles - 1 - (i - nh);
+        order[i] = (int)(0xfffffu - (s_keys[src] & 0xfffffu));
+    }
 }
 
 }  // namespace
 
+extern "C" int fd_spconv_tile_order(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int32_t *order, void *workspace,
+                                    size_t workspace_bytes, fd_stream_t stream_) {
+    FD_REQUIRE(nbr && order && workspace, "fd_spconv_tile_order: null argument");
+    const int64_t n_tiles = (n_out + 127) / 128;
+    FD_REQUIRE(n_tiles >= 1 && n_tiles <= 16384, "fd_spconv_tile_order: supports 1..16384 tiles of 128 rows (got %lld)", (long long)n_tiles);
+    FD_REQUIRE(workspace_bytes >= sizeof(unsigned) * (size_t)n_tiles, "fd_spconv_tile_order: workspace too small");
+    hipStream_t stream = fd::as_stream(stream_);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    int npad = 2;
+    while (npad < n_tiles) npad <<= 1;
+    unsigned *keys = (unsigned *)workspace;
+    hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)n_tiles), dim3(128), 0, stream, nbr, nbr_stride, K, (int)n_tiles, keys);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(tile_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+        attr = true;
+    }
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(1024), sizeof(unsigned) * npad, stream, keys, (int)n_tiles, npad, n_cu, order);
+    return fd::check_launch("fd_spconv_tile_order");
+}
+
 namespace fd {
 // returns 1 when launched, 0 when this shape is not covered (caller falls back to the register kernel)
 int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
-                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, hipStream_t stream) {
+                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, const int *tile_order, hipStream_t stream) {
     // (input row << 8 | local row) must fit an int32 and the feature matrix a 31-bit buffer range
     if (n_in_bound >= (1ll << 23) || n_in_bound * cin * 4 >= (1ll << 31)) return 0;
     const unsigned in_bytes = (unsigned)(n_in_bound * cin * 4);
-    const char *env = getenv("FD_V2_DEPTH");  // tuning override
+    const char *env = getenv("FD_V2_DEPTH");  // tuning overrides
     const int dsel = env ? atoi(env) : 0;
-#define FD_CASE(CI, CO, DDEF)                                                                                                         \
-    if (cin == CI && cout == CO) {                                                                                                    \
-        const int dd = dsel ? dsel : DDEF;                                                                                            \
-        \
-        if (dd <= 2) return launch_compact<CI, CO, 128, 2>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, stream); \
-        if (dd == 3) return launch_compact<CI, CO, 128, 3>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, stream); \
-        return launch_compact<CI, CO, 128, 4>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, stream);        \
+    const char *envt = getenv("FD_V2_TM");
+    const int tsel = envt ? atoi(envt) : 0;
+#define FD_LAUNCH(CI, CO, T, D) \
+    launch_compact<CI, CO, T, D>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, (T == 128 ? tile_order : nullptr), stream)
+#define FD_CASE(CI, CO, DDEF, TDEF)                                  \
+    if (cin == CI && cout == CO) {                                   \
+        const int dd = dsel ? dsel : DDEF, tt = tsel ? tsel : TDEF;  \
+        if (tt == 64) {                                              \
+            if (dd <= 2) return FD_LAUNCH(CI, CO, 64, 2);            \
+            if (dd == 3) return FD_LAUNCH(CI, CO, 64, 3);            \
+            return FD_LAUNCH(CI, CO, 64, 4);                         \
+        }                                                            \
+        if (dd <= 2) return FD_LAUNCH(CI, CO, 128, 2);               \
+        if (dd == 3) return FD_LAUNCH(CI, CO, 128, 3);               \
+        return FD_LAUNCH(CI, CO, 128, 4);                            \
     }
-    FD_CASE(16, 16, 4)
-    FD_CASE(16, 32, 4)
-    FD_CASE(32, 32, 4)
-    FD_CASE(32, 64, 4)
-    FD_CASE(64, 64, 3)
-    FD_CASE(64, 128, 3)
-    FD_CASE(128, 128, 2)
+    FD_CASE(16, 16, 4, 128)
+    FD_CASE(16, 32, 4, 128)
+    FD_CASE(32, 32, 4, 128)
+    FD_CASE(32, 64, 4, 128)
+    FD_CASE(64, 64, 3, 128)
+    FD_CASE(64, 128, 3, 128)
+    FD_CASE(128, 128, 2, 128)
 #undef FD_CASE
+#undef FD_LAUNCH
     return 0;
 }
 }  // namespace fd

@@ -152,6 +152,13 @@ class SparseIndex(object):
         check(L.fd_rulebook(_p(self.words), _p(self.prefix), self.B, self.D, self.H, self.W, _p(out_index.coords),
                             _p(out_index.n_dev), nstride, (ctypes.c_int * 3)(*ksize), (ctypes.c_int * 3)(*stride),
                             (ctypes.c_int * 3)(*pad), _p(nbr), _stream()), "fd_rulebook")
+        n_tiles = (out_index.n + 127) // 128
+        if n_tiles <= 16384:  # work-sorted tile order, shared by every conv that reuses this rulebook
+            order = torch.empty((n_tiles,), dtype=torch.int32, device=self.device)
+            ws = workspace.get("tile_order", 4 * n_tiles, self.device)
+            check(L.fd_spconv_tile_order(_p(nbr), nstride, K, out_index.n, _p(order), _p(ws), ws.numel(), _stream()),
+                  "fd_spconv_tile_order")
+            nbr.tile_order = order
         return nbr
 
 
@@ -192,7 +199,8 @@ def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=Fal
     if residual is not None:
         _dev(residual, "residual", feats.dtype)
     check(L.fd_spconv_apply(_p(feats), feats.shape[0], _p(_dev(wpacked, "wpacked")), _p(bias), _p(residual), int(bool(relu)),
-                            _p(_dev(nbr, "nbr", torch.int32)), nstride, K, n_out, cin, cout, dt, _p(out), _stream()),
+                            _p(_dev(nbr, "nbr", torch.int32)), nstride, _p(getattr(nbr, "tile_order", None)), K, n_out, cin, cout,
+                            dt, _p(out), _stream()),
           "fd_spconv_apply")
     return out
 

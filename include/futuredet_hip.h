@@ -104,8 +104,13 @@ int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int D
 size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype);
 int fd_spconv_pack_weight(const float *w_kio_host, int K, int cin, int cout, int dtype, void *wpacked_host);
 int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *wpacked, const float *bias, const void *residual,
-                    int relu, const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int cin, int cout,
-                    int dtype, void *out_feats, fd_stream_t stream);
+                    int relu, const int32_t *nbr, int64_t nbr_stride, const int32_t *tile_order /* or NULL */, int K,
+                    int64_t n_out, int cin, int cout, int dtype, void *out_feats, fd_stream_t stream);
+/* Optional load balancing for fd_spconv_apply (fp32): order[b] = 128-row output tile processed by workgroup b,
+ * heaviest tiles (most rulebook pairs) first and paired with light ones per CU.  One call per rulebook; the order is
+ * reused by every convolution sharing the rulebook.  workspace >= 4 * ceil(n_out/128) bytes; <= 16384 tiles. */
+int fd_spconv_tile_order(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int32_t *order, void *workspace,
+                         size_t workspace_bytes, fd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Densify.  Replaces SparseConvTensor.dense() + view (scn.py:165-168): out[b, c*D + d, y, x] = feats[row, c].
