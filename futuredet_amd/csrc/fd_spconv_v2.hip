@@ -287,30 +287,34 @@ __global__ void __launch_bounds__(128) tile_work_kernel(const int *__restrict__ 
     if (r == 0) keys[tile] = ((unsigned)work << 20) | (0xfffffu - (unsigned)tile);  // sort key: work desc, tile asc
 }
 
-// single workgroup: bitonic sort (descending) of <= 16384 keys in LDS, then the CU pairing rule
-__global__ void __launch_bounds__(1024) tile_sort_kernel(const unsigned *__restrict__ keys, int n_tiles, int npad, int n_cu, int *__restrict__ order) {
-    extern __shared__ unsigned s_keys[];
-    for (int i = threadIdx.x; i < npad; i += 1024) s_keys[i] = i < n_tiles ? keys[i] : 0u;
+// single workgroup: counting sort by work (at most 27 * 8 = 216 distinct values), heaviest first, then the CU
+// pairing rule.  Ties are placed in arrival order of the atomics: the order only steers scheduling, results do not
+// depend on it.
+__global__ void __launch_bounds__(1024) tile_sort_kernel(const unsigned *__restrict__ keys, int n_tiles, int n_cu, int *__restrict__ sorted,
+                                                         int *__restrict__ order) {
+    __shared__ int s_hist[256], s_start[256];
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int k2 = 2; k2 <= npad; k2 <<= 1)
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < npad; t += 1024) {
-                const int x = t ^ j;
-                if (x > t) {
-                    const unsigned a = s_keys[t], b = s_keys[x];
-                    const bool desc = (t & k2) == 0;
-                    if (desc ? (a < b) : (a > b)) { s_keys[t] = b; s_keys[x] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    for (int i = threadIdx.x; i < n_tiles; i += 1024) atomicAdd(&s_hist[min((int)(keys[i] >> 20), 255)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int w = 255; w >= 0; --w) { s_start[w] = acc; acc += s_hist[w]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_tiles; i += 1024) {
+        const int w = min((int)(keys[i] >> 20), 255);
+        sorted[atomicAdd(&s_start[w], 1)] = i;
+    }
+    __syncthreads();
+    __threadfence_block();
     // all tiles resident at once (<= 2 per CU): workgroups b and b + n_cu tend to share a CU, so the heaviest n_cu tiles
     // go first and are followed by the rest lightest-first; otherwise plain heaviest-first (greedy LPT by the dispatcher)
     const bool pair = n_tiles <= 2 * n_cu;
     const int nh = n_tiles < n_cu ? n_tiles : n_cu;
     for (int i = threadIdx.x; i < n_tiles; i += 1024) {
         const int src = (!pair || i < nh) ? i : n_tiles - 1 - (i - nh);
-        order[i] = (int)(0xfffffu - (s_keys[src] & 0xfffffu));
+        order[i] = sorted[src];
     }
 }
 
@@ -320,24 +324,18 @@ extern "C" int fd_spconv_tile_order(const int32_t *nbr, int64_t nbr_stride, int 
                                     size_t workspace_bytes, fd_stream_t stream_) {
     FD_REQUIRE(nbr && order && workspace, "fd_spconv_tile_order: null argument");
     const int64_t n_tiles = (n_out + 127) / 128;
-    FD_REQUIRE(n_tiles >= 1 && n_tiles <= 16384, "fd_spconv_tile_order: supports 1..16384 tiles of 128 rows (got %lld)", (long long)n_tiles);
-    FD_REQUIRE(workspace_bytes >= sizeof(unsigned) * (size_t)n_tiles, "fd_spconv_tile_order: workspace too small");
+    FD_REQUIRE(n_tiles >= 1 && n_tiles < (1 << 20), "fd_spconv_tile_order: supports up to 2^20 tiles of 128 rows (got %lld)", (long long)n_tiles);
+    FD_REQUIRE(workspace_bytes >= 2 * sizeof(unsigned) * (size_t)n_tiles, "fd_spconv_tile_order: workspace too small");
     hipStream_t stream = fd::as_stream(stream_);
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
-    int npad = 2;
-    while (npad < n_tiles) npad <<= 1;
     unsigned *keys = (unsigned *)workspace;
+    int *sorted = (int *)(keys + n_tiles);
     hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)n_tiles), dim3(128), 0, stream, nbr, nbr_stride, K, (int)n_tiles, keys);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(tile_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
-        attr = true;
-    }
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(1024), sizeof(unsigned) * npad, stream, keys, (int)n_tiles, npad, n_cu, order);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(1024), 0, stream, keys, (int)n_tiles, n_cu, sorted, order);
     return fd::check_launch("fd_spconv_tile_order");
 }
 

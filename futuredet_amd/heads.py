@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import hip_ops
-from .nn_utils import Sequential, fold_stack, kaiming_init
+from .nn_utils import FoldedConv, Sequential, fold_stack, kaiming_init
 from .registry import HEADS
 
 
@@ -99,7 +99,10 @@ class SepHead(nn.Module):
             x = conv(x)
         if self.forecast_feature:
             ret["feats"] = x
-        y = torch.nn.functional.relu_(torch.nn.functional.conv2d(x, w1, b1, padding=p1))
+        if x.is_cuda and FoldedConv.fuse_relu:
+            y = torch.miopen_convolution_relu(x, w1, b1, [1, 1], [p1, p1], [1, 1], 1)
+        else:
+            y = torch.nn.functional.relu_(torch.nn.functional.conv2d(x, w1, b1, padding=p1))
         z = torch.nn.functional.conv2d(y, w2, b2, padding=p2)
         o = 0
         for name, c in zip(names, couts):

@@ -153,9 +153,9 @@ class SparseIndex(object):
                             _p(out_index.n_dev), nstride, (ctypes.c_int * 3)(*ksize), (ctypes.c_int * 3)(*stride),
                             (ctypes.c_int * 3)(*pad), _p(nbr), _stream()), "fd_rulebook")
         n_tiles = (out_index.n + 127) // 128
-        if n_tiles <= 16384:  # work-sorted tile order, shared by every conv that reuses this rulebook
+        if n_tiles < (1 << 20):  # work-sorted tile order, shared by every conv that reuses this rulebook
             order = torch.empty((n_tiles,), dtype=torch.int32, device=self.device)
-            ws = workspace.get("tile_order", 4 * n_tiles, self.device)
+            ws = workspace.get("tile_order", 8 * n_tiles, self.device)
             check(L.fd_spconv_tile_order(_p(nbr), nstride, K, out_index.n, _p(order), _p(ws), ws.numel(), _stream()),
                   "fd_spconv_tile_order")
             nbr.tile_order = order

@@ -79,9 +79,13 @@ class FoldedConv(object):
         self.weight, self.bias, self.stride, self.padding, self.relu, self.transposed = \
             weight, bias, stride, padding, relu, transposed
 
+    fuse_relu = True  # MIOpen's fused conv+bias+ReLU (one kernel instead of conv + elementwise pass over the map)
+
     def __call__(self, x):
         if self.transposed:
             y = F.conv_transpose2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
+        elif self.relu and x.is_cuda and FoldedConv.fuse_relu and self.bias is not None:
+            return torch.miopen_convolution_relu(x, self.weight, self.bias, [self.stride] * 2, [self.padding] * 2, [1, 1], 1)
         else:
             y = F.conv2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
         return F.relu_(y) if self.relu else y

@@ -108,7 +108,7 @@ int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *wpacked, con
                     int64_t n_out, int cin, int cout, int dtype, void *out_feats, fd_stream_t stream);
 /* Optional load balancing for fd_spconv_apply (fp32): order[b] = 128-row output tile processed by workgroup b,
  * heaviest tiles (most rulebook pairs) first and paired with light ones per CU.  One call per rulebook; the order is
- * reused by every convolution sharing the rulebook.  workspace >= 4 * ceil(n_out/128) bytes; <= 16384 tiles. */
+ * reused by every convolution sharing the rulebook.  workspace >= 8 * ceil(n_out/128) bytes. */
 int fd_spconv_tile_order(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int32_t *order, void *workspace,
                          size_t workspace_bytes, fd_stream_t stream);
 
