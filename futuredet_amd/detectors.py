@@ -63,7 +63,7 @@ class VoxelNet(SingleStageDetector):
         """fp32 (default) or bf16 conv features/weights with fp32 accumulation; voxelizer, indexes, decode and
         NMS always stay fp32/int."""
         if channels_last is None:
-            channels_last = dtype != torch.float32
+            channels_last = False  # measured on MI355X: MIOpen is as fast or faster on NCHW for these shapes
         self.backbone.compute_dtype = dtype
         self.backbone.dense_channels_last = channels_last
         self.neck.compute_dtype = dtype

@@ -99,7 +99,7 @@ class SepHead(nn.Module):
             x = conv(x)
         if self.forecast_feature:
             ret["feats"] = x
-        if x.is_cuda and FoldedConv.fuse_relu:
+        if x.is_cuda and FoldedConv.fuse_relu and x.is_contiguous():
             y = torch.miopen_convolution_relu(x, w1, b1, [1, 1], [p1, p1], [1, 1], 1)
         else:
             y = torch.nn.functional.relu_(torch.nn.functional.conv2d(x, w1, b1, padding=p1))

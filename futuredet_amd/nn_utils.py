@@ -84,7 +84,8 @@ class FoldedConv(object):
     def __call__(self, x):
         if self.transposed:
             y = F.conv_transpose2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
-        elif self.relu and x.is_cuda and FoldedConv.fuse_relu and self.bias is not None:
+        elif self.relu and x.is_cuda and FoldedConv.fuse_relu and self.bias is not None and x.is_contiguous():
+            # (NCHW only: on channels-last inputs this MIOpen entry falls back to a naive kernel, 200x slower)
             return torch.miopen_convolution_relu(x, self.weight, self.bias, [self.stride] * 2, [self.padding] * 2, [1, 1], 1)
         else:
             y = F.conv2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
