@@ -65,7 +65,8 @@ class VoxelNet(SingleStageDetector):
         if channels_last is None:
             channels_last = False  # measured on MI355X: MIOpen is as fast or faster on NCHW for these shapes
         self.backbone.compute_dtype = dtype
-        self.backbone.dense_channels_last = channels_last
+        # bf16: the neck/head run on the hand-written NHWC MFMA convolution, so the BEV map is written channels-last
+        self.backbone.dense_channels_last = channels_last or dtype == torch.bfloat16
         self.neck.compute_dtype = dtype
         self.neck.channels_last = channels_last
         self.bbox_head.compute_dtype = dtype

@@ -114,6 +114,12 @@ class SepHead(nn.Module):
         return self.forward_modules(x)
 
 
+
+def _drop_caches(module, incompatible_keys):
+    module._folded = None
+    module._plan = None
+
+
 @HEADS.register_module
 class CenterHead(nn.Module):
     def __init__(self, in_channels=[128, ], tasks=[], dataset="nuscenes", weight=0.25, code_weights=[], common_heads=dict(),
@@ -166,7 +172,9 @@ class CenterHead(nn.Module):
         self.compute_dtype = torch.float32
         self.channels_last = False
         self._folded = None
-        self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_folded", None))
+        self._plan = None
+        self.use_hip_conv = True
+        self.register_load_state_dict_post_hook(_drop_caches)
         self.logger.info("Finish CenterHead Initialization")
 
     # ----------------------------------------------------------------------------------------------- forward
@@ -185,6 +193,13 @@ class CenterHead(nn.Module):
     def forward(self, x, bev_map=None, *kwargs):
         if self.training:
             return self.forward_modules(x, bev_map)
+        if (self.compute_dtype == torch.bfloat16 and x.is_cuda and self.use_hip_conv and not self.bev_map
+                and not self.forecast_feature):
+            if self._plan is None:
+                from .dense_bf16 import HeadPlan
+
+                self._plan = HeadPlan(self)
+            return self._plan(x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())
         dt, cl = self.compute_dtype, self.channels_last
         key = (dt, cl, next(self.parameters()).device)
         if self._folded is None or self._folded[0] != key:

@@ -220,6 +220,37 @@ def densify(feats, index, out_dtype=None, channels_last=False):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ dense conv (bf16)
+def pack_conv2d_weight(w_oihw):
+    """[Cout, Cin, k, k] float32 -> MFMA-fragment-ordered bf16 weights on the same device."""
+    L = _lib.load()
+    dev = w_oihw.device
+    w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+    cout, cin, ks, _ = w.shape
+    nbytes = L.fd_conv2d_packed_weight_bytes(cout, cin, ks)
+    if nbytes == 0:
+        raise FutureDetHipError("fd_conv2d: unsupported weight shape %s" % (tuple(w.shape),))
+    host = torch.empty((nbytes,), dtype=torch.uint8)
+    check(L.fd_conv2d_pack_weight(ctypes.c_void_p(w.data_ptr()), cout, cin, ks, ctypes.c_void_p(host.data_ptr())),
+          "fd_conv2d_pack_weight")
+    return host.to(dev)
+
+
+def conv2d_nhwc_bf16(x, wpk, bias, cout, ks, stride=1, relu=True, out=None, co_off=0, osy=1, osx=1, ooy=0, oox=0):
+    """x [B,H,W,Cin] bf16 contiguous -> y [B,Ho*osy,Wo*osx,Ctot] bf16 (allocated when ``out`` is None)."""
+    L = _lib.load()
+    x = _dev(x, "x", torch.bfloat16)
+    B, H, W, cin = x.shape
+    pad = 1 if ks == 3 else 0
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho * osy, Wo * osx, cout), dtype=torch.bfloat16, device=x.device)
+    _dev(out, "out", torch.bfloat16)
+    check(L.fd_conv2d_nhwc_bf16(_p(x), B, H, W, cin, _p(wpk), _p(bias), cout, ks, stride, pad, int(bool(relu)), _p(out),
+                                out.shape[3], co_off, osy, osx, ooy, oox, _stream()), "fd_conv2d_nhwc_bf16")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ decode / NMS
 def make_decode_cfg(H, W, test_cfg):
     c = DecodeCfg()

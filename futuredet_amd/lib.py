@@ -47,6 +47,10 @@ SIGNATURES = {
     "fd_spconv_tile_order": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fd_densify": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_i64,
                            c_i64, c_i64, c_i64, c_void_p]),
+    "fd_conv2d_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fd_conv2d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fd_conv2d_nhwc_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fd_decode_workspace_bytes": (c_size_t, [c_int, ctypes.POINTER(DecodeCfg)]),
     "fd_centerpoint_decode": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
                                       c_int, ctypes.POINTER(DecodeCfg), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -12,6 +12,12 @@ from .nn_utils import Sequential, build_norm_layer, fold_stack
 from .registry import NECKS
 
 
+
+def _drop_caches(module, incompatible_keys):
+    module._folded = None
+    module._plan = None
+
+
 @NECKS.register_module
 class RPN(nn.Module):
     def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
@@ -53,7 +59,9 @@ class RPN(nn.Module):
         self.compute_dtype = torch.float32
         self.channels_last = False
         self._folded = None
-        self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_folded", None))
+        self._plan = None
+        self.use_hip_conv = True
+        self.register_load_state_dict_post_hook(_drop_caches)
         (logger or logging.getLogger("RPN")).info("Finish RPN Initialization")
 
     @property
@@ -98,6 +106,14 @@ class RPN(nn.Module):
     def forward(self, x):
         if self.training:
             return self.forward_modules(x)
+        if self.compute_dtype == torch.bfloat16 and x.is_cuda and self.use_hip_conv:
+            # hand-written MFMA convolutions on NHWC bf16; returned as an NCHW-shaped view of the NHWC buffer
+            if self._plan is None:
+                from .dense_bf16 import RPNPlan
+
+                self._plan = RPNPlan(self)
+            y = self._plan(x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())
+            return y.permute(0, 3, 1, 2)
         blocks, deblocks = self._fold()
         x = x.to(self.compute_dtype)
         if self.channels_last:

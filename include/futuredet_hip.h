@@ -122,6 +122,22 @@ int fd_densify(const void *feats, int c, int dtype, const uint64_t *words, const
                int64_t stride_x, fd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Dense 2-D convolution, bf16 NHWC, fp32 accumulate, fused bias + ReLU (hand-written MFMA implicit GEMM).
+ * Replaces the cuDNN convolutions of the RPN neck and CenterHead in the bf16 configuration
+ * (det3d/models/necks/rpn.py:81-140, det3d/models/bbox_heads/center_head.py:104-143,344-349) with eval-mode
+ * BatchNorm folded into weight/bias by the caller.
+ *   x [B,H,W,cin] bf16; wpacked from fd_conv2d_pack_weight([cout][cin][ks][ks] float32 host); bias [cout] f32 or NULL
+ *   supported: 3x3 stride 1|2 pad 1, 1x1 stride 1 pad 0; cin % 32 == 0
+ *   y element (b, oy*osy+ooy, ox*osx+oox, co_off+co) of a [B, Ho*osy, Wo*osx, cout_total] bf16 tensor -- channel
+ *   offsets express a concat, pixel strides/offsets express a 2x2 stride-2 transposed conv as four 1x1 convs.
+ * ------------------------------------------------------------------------------------------------- */
+size_t fd_conv2d_packed_weight_bytes(int cout, int cin, int ks);
+int fd_conv2d_pack_weight(const float *w_oihw_host, int cout, int cin, int ks, void *wpacked_host);
+int fd_conv2d_nhwc_bf16(const void *x, int B, int H, int W, int cin, const void *wpacked, const float *bias, int cout,
+                        int ks, int stride, int pad, int relu, void *y, int cout_total, int co_off, int osy, int osx,
+                        int ooy, int oox, fd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * CenterPoint decode + rotated NMS.  Replaces CenterHead.predict's per-step decode
  * (det3d/models/bbox_heads/center_head.py:609-673), post_processing (:699-747), rotate_nms_pcdet
  * (det3d/core/bbox/box_torch_ops.py:248-277) and iou3d_nms_cuda.nms_gpu (det3d/ops/iou3d_nms/src/

@@ -345,3 +345,56 @@ def test_voxelnet_end_to_end_vs_oracle(hip, variant):
             gt = torch.cat([res[b]["box3d_lidar"], res[b]["scores"][:, None], res[b]["label_preds"][:, None].float()], 1).cpu().numpy()
             bad = _match_detections(gt, w)
             assert bad <= max(2, 0.02 * (len(gt) + len(w))), (variant, b, bad, len(gt), len(w))
+
+
+# ------------------------------------------------------------------------------------------------ dense conv (bf16)
+@pytest.mark.parametrize("cfg", [(3, 1, 64, 128, 37, 45), (3, 2, 32, 128, 40, 33), (3, 1, 128, 64, 20, 20), (3, 1, 96, 11, 19, 35),
+                                 (1, 1, 128, 256, 23, 18), (3, 1, 256, 256, 16, 16)])
+def test_conv2d_nhwc_bf16_vs_torch(hip, cfg):
+    """Hand-written MFMA conv vs torch conv2d on the same bf16-rounded operands (fp32 reference); partial tiles,
+    stride 2, 1x1, padded Cout, channel-offset (concat) writes.  bf16 output rounding -> 1e-2 of scale."""
+    ks, stride, cin, cout, H, W = cfg
+    rng = np.random.default_rng(cin + cout + H)
+    x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy((rng.standard_normal((cout, cin, ks, ks)) * (2.0 / (cin * ks * ks)) ** 0.5).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    ref = torch.relu(torch.nn.functional.conv2d(x.float(), w.bfloat16().float(), b, stride=stride, padding=1 if ks == 3 else 0))
+    wpk = hip.pack_conv2d_weight(w).cuda()
+    xn = x.cuda().permute(0, 2, 3, 1).contiguous()
+    out = torch.full((2, ref.shape[2], ref.shape[3], cout + 5), 7.0, dtype=torch.bfloat16, device="cuda")
+    hip.conv2d_nhwc_bf16(xn, wpk, b.cuda(), cout, ks, stride, True, out=out, co_off=3)
+    got = out[..., 3:3 + cout].permute(0, 3, 1, 2).float().cpu()
+    assert float((got - ref).abs().max()) <= 1e-2 * max(1.0, float(ref.abs().max()))
+    assert bool((out[..., :3] == 7).all()) and bool((out[..., 3 + cout:] == 7).all()), "writes outside the channel window"
+
+
+def test_dense_bf16_plan_vs_torch_modules(hip):
+    """RPN + CenterHead on the HIP bf16 plan (concat in place, transposed conv as 4 interleaved 1x1, fused heads) vs
+    the plain fp32 torch modules; bf16 tolerance 3e-2 of each tensor's scale."""
+    import logging
+
+    from futuredet_amd import build_head, build_neck
+    from futuredet_amd.synth import seeded_state_dict
+
+    rpn = build_neck(dict(type="RPN", layer_nums=[2, 2], ds_layer_strides=[1, 2], ds_num_filters=[64, 128], us_layer_strides=[1, 2],
+                          us_num_filters=[128, 128], num_input_features=64, logger=logging.getLogger("RPN")))
+    rpn.load_state_dict(seeded_state_dict(rpn, 3), strict=False)
+    head = build_head(dict(type="CenterHead", in_channels=256, tasks=[dict(num_class=1, class_names=["car"])], dataset="nuscenes",
+                           weight=0.25, code_weights=[1.0] * 10,
+                           common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
+                           share_conv_channel=64, dcn_head=False, timesteps=7, two_stage=False, reverse=False, sparse=False, dense=False,
+                           bev_map=False, forecast_feature=False, classify=False, wide_head=False))
+    head.load_state_dict(seeded_state_dict(head, 4), strict=False)
+    rpn, head = rpn.cuda().eval(), head.cuda().eval()
+    x = torch.randn((2, 64, 44, 36), device="cuda")
+    with torch.no_grad():
+        y_ref = rpn.forward_modules(x)
+        p_ref = head.forward_modules(y_ref)
+        rpn.compute_dtype = head.compute_dtype = torch.bfloat16
+        y = rpn(x)
+        p = head(y)
+    assert y.shape == y_ref.shape
+    assert float((y.float() - y_ref).abs().max()) <= 3e-2 * float(y_ref.abs().max())
+    for k in p_ref[0]:
+        assert p[0][k].shape == p_ref[0][k].shape
+        assert float((p[0][k] - p_ref[0][k]).abs().max()) <= 3e-2 * max(1.0, float(p_ref[0][k].abs().max())), k
