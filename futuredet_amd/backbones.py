@@ -128,7 +128,7 @@ class SpMiddleResNetFHD(nn.Module):
             ix.finalize(int(host[i]))
         return idx
 
-    def run_fused(self, idx, feats0):
+    def run_fused(self, idx, feats0, dense_out=None):
         """feats0: [n0, 16] features already in index order (channel padded).  Returns (dense BEV, per-level
         (features, index))."""
         dt = self.compute_dtype
@@ -165,7 +165,7 @@ class SpMiddleResNetFHD(nn.Module):
                 y = run(blk.conv1, blk.bn1, x, dst, dst, relu=True)
                 x = run(blk.conv2, blk.bn2, y, dst, dst, relu=True, residual=x)
             levels[lvl] = (x, dst)
-        bev = hip_ops.densify(x, idx[4], out_dtype=self.dense_dtype or dt, channels_last=self.dense_channels_last)
+        bev = hip_ops.densify(x, idx[4], out_dtype=self.dense_dtype or dt, channels_last=self.dense_channels_last, out=dense_out)
         return bev, levels
 
     def forward(self, voxel_features, coors, batch_size, input_shape):

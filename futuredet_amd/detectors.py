@@ -4,6 +4,8 @@ VoxelNet.forward(example, return_loss) keeps the reference contract (voxelnet.py
 ``forward_points`` is the device-resident fast path the benchmark measures: raw point clouds (device tensors)
 -> fused voxelizer/mean -> sparse backbone -> neck -> head -> decode, with one host read of the five
 active-row counts and one of the final detections."""
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -97,6 +99,33 @@ class VoxelNet(SingleStageDetector):
             return self.bbox_head.loss(example, preds)
         return self.bbox_head.predict(example, preds, self.test_cfg)
 
+    def _dense_graph(self, B, idx4, dev):
+        """hipGraph of neck + head for a given batch size / precision (captured once, after an eager warm-up that lets
+        MIOpen pick its kernels).  Returns (graph, static BEV input, static prediction dicts) or None."""
+        bb = self.backbone
+        dt = bb.dense_dtype or bb.compute_dtype
+        key = (B, dt, bb.dense_channels_last, idx4.D, idx4.H, idx4.W, dev)
+        cache = self.__dict__.setdefault("_graphs", {})
+        if key in cache:
+            return cache[key]
+        try:
+            static_bev = torch.empty((B, 128 * idx4.D, idx4.H, idx4.W), dtype=dt, device=dev,
+                                     memory_format=torch.channels_last if bb.dense_channels_last else torch.contiguous_format).zero_()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.bbox_head(self.neck(static_bev), None)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                preds = self.bbox_head(self.neck(static_bev), None)
+            cache[key] = (g, static_bev, preds)
+        except Exception as e:  # capture is an optimisation; the eager launches are always available
+            print("[futuredet_amd] hipGraph capture of neck+head unavailable (%r); running eagerly" % (e,))
+            cache[key] = None
+        return cache[key]
+
     # ------------------------------------------------------------------------------------------------ fast path
     @torch.no_grad()
     def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True):
@@ -140,12 +169,21 @@ class VoxelNet(SingleStageDetector):
             hip_ops.check(L.fd_rows_permute(hip_ops._p(mean[sl]), cpad, hip_ops._p(row_of), hip_ops._p(nvox[b:b + 1]), max_voxels,
                                             hip_ops._p(feats0), cpad, hip_ops._DT[bb.compute_dtype], hip_ops._stream()),
                           "fd_rows_permute")
-        x, _ = bb.run_fused(idx, feats0)
-        mark_stage("sparse_backbone")
-        x = self.neck(x)
-        mark_stage("rpn")
-        preds = self.bbox_head(x, bev_map)
-        mark_stage("head")
+        graph = None if (bev_map is not None or os.environ.get("FD_NO_GRAPH")) else self._dense_graph(B, idx[4], dev)
+        if graph is not None:
+            # neck + head have static shapes: replay them as one hipGraph (one launch instead of ~25-60)
+            g, static_bev, preds = graph
+            bb.run_fused(idx, feats0, dense_out=static_bev)
+            mark_stage("sparse_backbone")
+            g.replay()
+            mark_stage("rpn+head(graph)")
+        else:
+            x, _ = bb.run_fused(idx, feats0)
+            mark_stage("sparse_backbone")
+            x = self.neck(x)
+            mark_stage("rpn")
+            preds = self.bbox_head(x, bev_map)
+            mark_stage("head")
         if padded:
             out = self.bbox_head.predict_padded(preds, self.test_cfg)
         else:

@@ -152,14 +152,28 @@ class SparseIndex(object):
         check(L.fd_rulebook(_p(self.words), _p(self.prefix), self.B, self.D, self.H, self.W, _p(out_index.coords),
                             _p(out_index.n_dev), nstride, (ctypes.c_int * 3)(*ksize), (ctypes.c_int * 3)(*stride),
                             (ctypes.c_int * 3)(*pad), _p(nbr), _stream()), "fd_rulebook")
-        n_tiles = (out_index.n + 127) // 128
-        if n_tiles < (1 << 20):  # work-sorted tile order, shared by every conv that reuses this rulebook
-            order = torch.empty((n_tiles,), dtype=torch.int32, device=self.device)
-            ws = workspace.get("tile_order", 8 * n_tiles, self.device)
-            check(L.fd_spconv_tile_order(_p(nbr), nstride, K, out_index.n, _p(order), _p(ws), ws.numel(), _stream()),
-                  "fd_spconv_tile_order")
-            nbr.tile_order = order
+        nbr.n_out = out_index.n
         return nbr
+
+
+def tile_order_for(nbr):
+    """Work-sorted 128-row tile order of a rulebook (fp32 kernel only); computed once, shared by every convolution
+    that reuses the rulebook."""
+    order = getattr(nbr, "tile_order", None)
+    if order is None:
+        L = _lib.load()
+        n_out = getattr(nbr, "n_out", None)
+        if n_out is None or n_out == 0:
+            return None
+        K, nstride = nbr.shape
+        n_tiles = (n_out + 127) // 128
+        if n_tiles >= (1 << 20):
+            return None
+        order = torch.empty((n_tiles,), dtype=torch.int32, device=nbr.device)
+        ws = workspace.get("tile_order", 8 * n_tiles, nbr.device)
+        check(L.fd_spconv_tile_order(_p(nbr), nstride, K, n_out, _p(order), _p(ws), ws.numel(), _stream()), "fd_spconv_tile_order")
+        nbr.tile_order = order
+    return order
 
 
 def rows_permute(src, row_of, c_dst, dtype=torch.float32, n_rows=None, n_dev=None):
@@ -198,22 +212,26 @@ def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=Fal
         out = torch.empty((max(n_out, 1), cout), dtype=feats.dtype, device=feats.device)[:n_out]
     if residual is not None:
         _dev(residual, "residual", feats.dtype)
+    order = tile_order_for(nbr) if dt == 0 else None
     check(L.fd_spconv_apply(_p(feats), feats.shape[0], _p(_dev(wpacked, "wpacked")), _p(bias), _p(residual), int(bool(relu)),
-                            _p(_dev(nbr, "nbr", torch.int32)), nstride, _p(getattr(nbr, "tile_order", None)), K, n_out, cin, cout,
-                            dt, _p(out), _stream()),
+                            _p(_dev(nbr, "nbr", torch.int32)), nstride, _p(order), K, n_out, cin, cout, dt, _p(out), _stream()),
           "fd_spconv_apply")
     return out
 
 
-def densify(feats, index, out_dtype=None, channels_last=False):
-    """SparseConvTensor.dense()+view: [B, C*D, H, W] with channel = c*D + d."""
+def densify(feats, index, out_dtype=None, channels_last=False, out=None):
+    """SparseConvTensor.dense()+view: [B, C*D, H, W] with channel = c*D + d (``out``: pre-allocated destination)."""
     L = _lib.load()
     feats = _dev(feats, "feats")
     C = feats.shape[1]
-    out_dtype = out_dtype or feats.dtype
     shape = (index.B, C * index.D, index.H, index.W)
-    out = torch.empty(shape, dtype=out_dtype, device=feats.device,
-                      memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    if out is None:
+        out_dtype = out_dtype or feats.dtype
+        out = torch.empty(shape, dtype=out_dtype, device=feats.device,
+                          memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    else:
+        assert tuple(out.shape) == shape and out.is_cuda
+        out_dtype = out.dtype
     sb, sc, sy, sx = out.stride()
     check(L.fd_densify(_p(feats), C, _DT[feats.dtype], _p(index.words), _p(index.prefix), index.B, index.D, index.H,
                        index.W, _p(out), _DT[out_dtype], sb, sc, sy, sx, _stream()), "fd_densify")
