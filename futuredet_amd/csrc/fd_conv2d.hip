@@ -107,36 +107,98 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
     load_slice(0);
     store_slice(0);
     __syncthreads();
-    for (int s = 0; s < nslices; ++s) {
-        if (s + 1 < nslices) load_slice(s + 1);  // in flight during this slice's MFMAs
-        const unsigned char *src = smem + (s & 1) * (PP * 64);
+    // The weight stream of one 32-channel column block is a linear array over (slice, tap, k-half): a register ring
+    // keeps RING fragments in flight ahead of their MFMAs (an L2 hit costs ~1000 cycles, a (tap, k-half) step has only
+    // WMT*WNT MFMAs), and the ring keeps running across the slice barrier.
+    constexpr int ITERS = KS * KS * 2;
+    constexpr int RING = (ITERS % 6 == 0) ? 6 : 2;
+    const int total_iters = nslices * ITERS;
+    const bf16x8 *wb[WNT];
 #pragma unroll
-        for (int tap = 0; tap < KS * KS; ++tap) {
+    for (int j = 0; j < WNT; ++j) wb[j] = wp + ((n0 >> 5) + j) * w_nt_stride + lane;
+    bf16x8 bw[RING][WNT];
+#pragma unroll
+    for (int r = 0; r < RING; ++r)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) bw[r][j] = wb[j][(int64_t)(r < total_iters ? r : 0) * 64];
+    if (nslices > 1) load_slice(1);  // registers hold slice s+1 while slice s is computed
+    for (int s = 0; s < nslices; ++s) {
+        const unsigned char *src = smem + (s & 1) * (PP * 64);
+        // A fragments are read one step ahead of their MFMAs (LDS latency ~130 cycles vs 128 cycles of MFMA per step)
+        auto read_a = [&](int it, bf16x8(&a)[WMT]) {
+            const int tap = it >> 1, ks = it & 1;
             const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 a[WMT], bw[WNT];
-#pragma unroll
-                for (int i = 0; i < WMT; ++i) {
-                    const int pix = (prow[i] + ky) * PW + pcol[i] + kx;
-                    const int q = ks * 2 + lk;
-                    a[i] = *reinterpret_cast<const bf16x8 *>(src + pix * 64 + ((q ^ ((pix >> 2) & 3)) << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < WNT; ++j) {
-                    const int nt32 = (n0 >> 5) + j;
-                    bw[j] = wp[nt32 * w_nt_stride + (((int64_t)s * KS * KS + tap) * 2 + ks) * 64 + lane];
-                }
-#pragma unroll
-                for (int i = 0; i < WMT; ++i)
-#pragma unroll
-                    for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bw[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < WMT; ++i) {
+                const int pix = (prow[i] + ky) * PW + pcol[i] + kx;
+                const int q = ks * 2 + lk;
+                a[i] = *reinterpret_cast<const bf16x8 *>(src + pix * 64 + ((q ^ ((pix >> 2) & 3)) << 4));
             }
+        };
+        bf16x8 a[2][WMT];
+        read_a(0, a[0]);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int slot = it % RING;  // ITERS % RING == 0, so the slot sequence is the same in every slice
+            if (it + 1 < ITERS) read_a(it + 1, a[(it + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it & 1][i], bw[slot][j], acc[i][j], 0, 0, 0);
+            const int nxt = s * ITERS + it + RING;
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) bw[slot][j] = wb[j][(int64_t)(nxt < total_iters ? nxt : 0) * 64];
         }
+        // Patch loads go at the END of a slice: vector-memory loads return in order, so a patch load issued at the top
+        // would sit in front of this slice's weight-ring loads and stall them for its whole latency; issued here it has a
+        // full slice of MFMAs to land and only the ring loads of the next slice's first steps queue behind it.
         if (s + 1 < nslices) store_slice((s + 1) & 1);
+        if (s + 2 < nslices) load_slice(s + 2);
         __syncthreads();
     }
     // epilogue.  C/D layout of 32x32: col (channel) = lane & 31, row (pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
+    const bool wide = ((p.cout_total | p.co_off) & 7) == 0 && (p.Cout_real & 7) == 0;  // 16-byte aligned channel runs
+    if (wide) {
+        // A lane owns one channel of 16 pixels, i.e. 2-byte stores if written directly (64 store instructions per
+        // wave, issue-bound).  Transpose the tile through LDS instead and store 16 bytes (8 channels) per lane.
+        unsigned short *s_out = reinterpret_cast<unsigned short *>(smem);  // [128 pixels][NT channels] bf16
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+            const int cl = (wn * WNT + j) * 32 + lm;  // channel inside the block
+            const int co = blockIdx.y * NT + cl;
+            const float bv = (bias && co < p.Cout_real) ? bias[co] : 0.0f;
+            const bool odd = lm & 1;
+#pragma unroll
+            for (int i = 0; i < WMT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    // lanes l and l^1 hold adjacent channels of the same 16 pixels: swap one value so that each lane owns
+                    // a (channel pair, pixel) dword -> 4-byte LDS writes, half as many, no sub-dword bank sharing
+                    float v0 = acc[i][j][r] + bv, v1 = acc[i][j][r + 1] + bv;
+                    if (p.relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+                    const unsigned mine0 = f2bf(v0), mine1 = f2bf(v1);
+                    const unsigned got = (unsigned)__shfl_xor((int)(odd ? mine0 : mine1), 1);
+                    const int rr = odd ? r + 1 : r;
+                    const int m = (wm * WMT + i) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lk;
+                    const unsigned packed = odd ? (got | (mine1 << 16)) : (mine0 | (got << 16));
+                    *reinterpret_cast<unsigned *>(s_out + m * NT + (cl & ~1)) = packed;
+                }
+        }
+        __syncthreads();
+        constexpr int C8 = NT / 8;
+        for (int id = tid; id < TH * TW * C8; id += 256) {
+            const int m = id / C8, c8 = id - m * C8;
+            const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+            const int co = blockIdx.y * NT + c8 * 8;
+            if (oy < p.Ho && ox < p.Wo && co < p.Cout_real) {
+                const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
+                *reinterpret_cast<uint4 *>(y + (((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co) =
+                    *reinterpret_cast<const uint4 *>(s_out + m * NT + c8 * 8);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < WNT; ++j) {
         const int co = n0 + j * 32 + lm;
@@ -151,7 +213,6 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
                     float v = acc[i][j][r] + bv;
                     if (p.relu) v = fmaxf(v, 0.0f);
                     const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
-                    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
                     y[(((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co] = f2bf(v);
                 }
             }
@@ -163,7 +224,8 @@ template <int KS, int S, int WMT, int WNT, int WAVES_M, int WAVES_N>
 void launch_conv(const void *x, const void *wp, const float *bias, void *y, const ConvParams &p, hipStream_t stream) {
     constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
     constexpr int NT = WNT * WAVES_N * 32;
-    const size_t lds = 2 * (size_t)PH * PW * 64;
+    size_t lds = 2 * (size_t)PH * PW * 64;
+    if (lds < (size_t)TH * TW * NT * 2) lds = (size_t)TH * TW * NT * 2;  // the epilogue transposes the tile through LDS
     auto kern = conv2d_nhwc_bf16<KS, S, WMT, WNT, WAVES_M, WAVES_N>;
     static bool attr = false;
     if (!attr && lds > 65536) {
@@ -176,8 +238,10 @@ void launch_conv(const void *x, const void *wp, const float *bias, void *y, cons
 
 template <int KS, int S>
 int dispatch_nt(const void *x, const void *wp, const float *bias, void *y, const ConvParams &p, hipStream_t stream) {
-    if (p.Cout_pad % 128 == 0) launch_conv<KS, S, 2, 2, 2, 2>(x, wp, bias, y, p, stream);
-    else if (p.Cout_pad % 64 == 0) launch_conv<KS, S, 1, 2, 4, 1>(x, wp, bias, y, p, stream);
+    const char *e = getenv("FD_CONV_NT");  // tuning override
+    const int force = e ? atoi(e) : 0;
+    if (p.Cout_pad % 128 == 0 && force != 64 && force != 32) launch_conv<KS, S, 2, 2, 2, 2>(x, wp, bias, y, p, stream);
+    else if (p.Cout_pad % 64 == 0 && force != 32) launch_conv<KS, S, 1, 2, 4, 1>(x, wp, bias, y, p, stream);
     else launch_conv<KS, S, 1, 1, 4, 1>(x, wp, bias, y, p, stream);
     return 1;
 }
