@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) spconv_f32(const float *__restrict__ in, 
     constexpr int ROWS_B = 64 * RG;  // rows per workgroup
     constexpr int NB = COUT / 16, NC = CIN / 16;
     __shared__ int s_nbr[kMaxTaps * ROWS_B];
-    const int tile = fd::xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile = blockIdx.x;  // index order: contiguous XCD chunks concentrate the dense regions on a few XCDs (measured -10%)
     const int row0 = tile * ROWS_B;
     for (int t = threadIdx.x; t < K * ROWS_B; t += 256) {
         int k = t / ROWS_B, r = t - k * ROWS_B;
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) spconv_bf16(const unsigned short *__restr
     constexpr bool WIDE = CIN >= 32;
     constexpr int NC = WIDE ? CIN / 32 : 1;
     __shared__ int s_nbr[kMaxTaps * ROWS_B];
-    const int tile = fd::xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile = blockIdx.x;  // index order: contiguous XCD chunks concentrate the dense regions on a few XCDs (measured -10%)
     const int row0 = tile * ROWS_B;
     for (int t = threadIdx.x; t < K * ROWS_B; t += 256) {
         int k = t / ROWS_B, r = t - k * ROWS_B;
@@ -250,11 +250,12 @@ int pick_rg(int64_t n_out, int cin, int cout) {
     const char *e = getenv("FD_SPCONV_RG");  // tuning / test override
     const int forced = e ? atoi(e) : 0;
     if (forced > 0) return forced;
-    // enough waves to fill 256 CUs x 4 SIMDs with >= 2 waves each, otherwise favour B-fragment reuse
-    const int64_t want_waves = 256 * 4 * 2;
-    int rg = 4;
-    while (rg > 1 && (n_out + 16 * rg - 1) / (16 * rg) < want_waves) rg >>= 1;
-    if (cin * cout <= 32 * 32 && rg > 2) rg = 2;  // light layers: latency-bound, keep more waves
+    // Measured on MI355X (tools/spconv_bench.py, 300k-point cloud): the kernel is bound by the L2->L1 weight stream
+    // (every wave reads all of W[k] per tap), so more rows per wave (RG) help until the wave count drops below
+    // ~2 per SIMD, where gather latency is no longer hidden.  128-wide layers have few rows: RG 1; 64-wide: RG 2.
+    const int64_t waves2 = (n_out + 31) / 32;
+    int rg = (cin * cout >= 128 * 128) ? 1 : 2;
+    if (rg == 2 && waves2 < 256 * 4 * 2) rg = 1;
     return rg;
 }
 
