@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--points", type=int, default=300000)
     ap.add_argument("--batch", type=int, default=1, help="clouds per rank per step")
     ap.add_argument("--channels-last", type=int, default=-1)
+    ap.add_argument("--voxel-xy", type=float, default=0.075, help="x/y voxel size (0.05 = the finer grid of BASELINE configs[4])")
+    ap.add_argument("--max-voxels", type=int, default=160000)
+    ap.add_argument("--class-name", default="car")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage GPU times to stderr")
     return ap.parse_args()
@@ -111,7 +114,8 @@ def main():
         torch.distributed.barrier()
     lib.load()
 
-    cfg = centerpoint_config(args.variant)
+    cfg = centerpoint_config(args.variant, args.class_name, voxel_size=(args.voxel_xy, args.voxel_xy, 0.2),
+                             max_voxel_num=(min(120000, args.max_voxels), args.max_voxels))
     net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     sd = seeded_state_dict(net, 7)
     net.load_state_dict(sd, strict=False)
@@ -126,7 +130,8 @@ def main():
     clouds = [torch.from_numpy(c).to(dev) for c in host_clouds]
     bev = None
     if net.bbox_head.bev_map:
-        bev = torch.zeros((args.batch, 6, 180, 180), device=dev)
+        side = int(round(108.0 / args.voxel_xy / 8))
+        bev = torch.zeros((args.batch, 6, side, side), device=dev)
 
     stage_events = []
 

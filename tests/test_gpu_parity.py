@@ -296,7 +296,7 @@ def test_predict_matches_reference_golden(hip, golden, name, T, dense):
 
 
 # ------------------------------------------------------------------------------------------------ end to end
-@pytest.mark.parametrize("variant", ["forecast_n0", "forecast_n3"])
+@pytest.mark.parametrize("variant", ["forecast_n0", "forecast_n3", "pedestrian_n3_fine"])
 def test_voxelnet_end_to_end_vs_oracle(hip, variant):
     """Whole path on a ~30k-point synthetic cloud (BASELINE configs[0] shape): HIP VoxelNet.forward(example) and
     forward_points() vs the CPU oracle model with the same seeded weights.  BEV map 1e-3 of scale; detections
@@ -309,7 +309,10 @@ def test_voxelnet_end_to_end_vs_oracle(hip, variant):
     from oracle import model as omodel
     from oracle import ops as oops
 
-    cfg = centerpoint_config(variant)
+    if variant == "pedestrian_n3_fine":  # BASELINE configs[4]: pedestrian n3 on the finer 0.05 m grid (2160^2, BEV 270^2)
+        cfg = centerpoint_config("forecast_n3", "pedestrian", voxel_size=(0.05, 0.05, 0.2), max_voxel_num=(300000, 400000))
+    else:
+        cfg = centerpoint_config(variant)
     net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     sd = seeded_state_dict(net, 7)
     net.load_state_dict(sd, strict=False)
@@ -324,7 +327,8 @@ def test_voxelnet_end_to_end_vs_oracle(hip, variant):
     for i, pts in enumerate(clouds):
         res, _ = vox({"mode": "val", "lidar": {"points": pts}}, None)
         v = res["lidar"]["voxels"]
-        ov, oc, on = oops.points_to_voxel(pts, cfg.voxel_generator["voxel_size"], cfg.voxel_generator["range"], 10, True, 160000)
+        ov, oc, on = oops.points_to_voxel(pts, cfg.voxel_generator["voxel_size"], cfg.voxel_generator["range"], 10, True,
+                                          cfg.voxel_generator["max_voxel_num"][1])
         assert np.array_equal(v["coordinates"], oc) and np.array_equal(v["voxels"], ov)
         examples.append(dict(voxels=v["voxels"], coordinates=v["coordinates"], num_points=v["num_points"],
                              num_voxels=v["num_voxels"], shape=v["shape"], metadata={"token": i}))
