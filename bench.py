@@ -84,17 +84,24 @@ def cpu_baseline(cfg, sd, cloud):
                            test_cfg=cfg.test_cfg).eval()
     onet.load_state_dict(sd, strict=False)
     vg = cfg.voxel_generator
-    t0 = time.perf_counter()
-    v, c, n = oops.points_to_voxel(cloud, vg["voxel_size"], vg["range"], vg["max_points_in_voxel"], True, vg["max_voxel_num"][1])
-    t_vox = time.perf_counter() - t0
     grid = np.round((np.array(vg["range"][3:], np.float32) - np.array(vg["range"][:3], np.float32)) / np.array(vg["voxel_size"], np.float32))
-    ex = dict(voxels=torch.from_numpy(v), coordinates=torch.from_numpy(np.pad(c, ((0, 0), (1, 0)))), num_points=torch.from_numpy(n),
-              num_voxels=torch.tensor([len(n)]), shape=np.array([grid.astype(np.int64)]), metadata=[None])
-    res = onet(ex)
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "sweeps/s", "cores": cores, "kind": "port",
-            "sample": "1 cloud of the bench workload (%d pts, %d voxels) through oracle/ (voxelizer %.2fs single-thread, total %.2fs); "
-                      "%d detections" % (len(cloud), len(n), t_vox, dt, len(res[0]["scores"]))}
+    t_start = time.perf_counter()
+    t_vox, n_done, n_vox, n_det = 0.0, 0, 0, 0
+    # bounded sample: the bench cloud over and over for ~10 s of CPU work (at least 2, at most 8 sweeps)
+    while n_done < 2 or (time.perf_counter() - t_start < 10.0 and n_done < 8):
+        t0 = time.perf_counter()
+        v, c, n = oops.points_to_voxel(cloud, vg["voxel_size"], vg["range"], vg["max_points_in_voxel"], True, vg["max_voxel_num"][1])
+        t_vox += time.perf_counter() - t0
+        ex = dict(voxels=torch.from_numpy(v), coordinates=torch.from_numpy(np.pad(c, ((0, 0), (1, 0)))), num_points=torch.from_numpy(n),
+                  num_voxels=torch.tensor([len(n)]), shape=np.array([grid.astype(np.int64)]), metadata=[None])
+        res = onet(ex)
+        n_done += 1
+        n_vox, n_det = len(n), len(res[0]["scores"])
+    dt = time.perf_counter() - t_start
+    return {"value": round(n_done / dt, 4), "unit": "sweeps/s", "cores": cores, "kind": "port",
+            "sample": "%d passes over the bench cloud (%d pts, %d voxels, %d detections) through oracle/ in %.1f s "
+                      "(voxelizer %.2f s/sweep single-thread; pair-list sparse conv on OpenMP, dense convs on torch-CPU, %d threads)"
+                      % (n_done, len(cloud), n_vox, n_det, dt, t_vox / n_done, cores)}
 
 
 def main():

@@ -29,15 +29,3 @@ for name, ks, st, cin, cout, hw in shapes:
     ho = y.shape[1]
     gf = 2.0 * ho * ho * cout * cin * ks * ks / 1e9
     print("%-26s %7.1f us  %6.1f GFLOP  %6.1f TFLOP/s" % (name, us, gf, gf / us * 1e3 / 1e3))
-    if os.environ.get("FD_PROF_C2"):
-        import ctypes
-        L = hip_ops._lib.load()
-        L.fd_debug_cprof.restype = None
-        buf = (ctypes.c_ulonglong * 8)()
-        L.fd_debug_cprof(buf, 1)
-        y = hip_ops.conv2d_nhwc_bf16(x, wpk, b, cout, ks, st, True)
-        torch.cuda.synchronize()
-        L.fd_debug_cprof(buf, 0)
-        nw = max(buf[5], 1)
-        print("      per-wave cycles (%d waves): prologue=%.0f mfma-loops=%.0f slice-tails=%.0f epilogue=%.0f total=%.0f" %
-              (nw, buf[0] / nw, buf[1] / nw, buf[2] / nw, buf[3] / nw, buf[4] / nw))

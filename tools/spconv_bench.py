@@ -66,51 +66,3 @@ for slots in (256, 512, 768):
     for name, assign in (("round-robin", order % slots), ("xcd-chunk", (order * slots // nt))):
         load = np.bincount(assign, weights=groups, minlength=slots)
         print("  %d slots %-11s: max load %.0f vs mean %.1f -> efficiency %.2f" % (slots, name, load.max(), groups.sum() / slots, groups.sum() / slots / load.max()))
-if os.environ.get("FD_PROF_V2"):
-    import ctypes
-    L = hip_ops._lib.load()
-    L.fd_debug_prof.restype = None
-    buf = (ctypes.c_ulonglong * 16)()
-    L.fd_debug_prof(buf, 1)
-    y = hip_ops.spconv_apply(x, wpk, bias, nbr, ix.n, C, residual=x, relu=True)
-    torch.cuda.synchronize()
-    L.fd_debug_prof(buf, 0)
-    nw = max(buf[9], 1)
-    names = ["prologue", "tap-switch", "C-read+wait", "fetch-issue", "MFMA", "D-write", "epilogue", "total"]
-    print("per-wave cycles (s_memtime, %d waves, %.1f items/wave): " % (nw, buf[8] / nw) + ", ".join("%s=%.0f" % (n, buf[i] / nw) for i, n in enumerate(names)))
-    print("per-item cycles: " + ", ".join("%s=%.0f" % (n, buf[i] / max(buf[8], 1)) for i, n in enumerate(names[1:6], 1)))
-if os.environ.get("FD_TILE_ORDER"):
-    import ctypes
-    import numpy as np
-    L = hip_ops._lib.load()
-    L.fd_debug_set_tile_order.restype = None
-    L.fd_debug_set_tile_order.argtypes = [ctypes.c_void_p]
-    desc = np.argsort(-groups, kind="stable")
-    for mode in ("identity", "descending", "pair256", "pair256-xcd"):
-        if mode == "identity":
-            order = np.arange(nt)
-        elif mode == "descending":
-            order = desc
-        else:
-            # blocks b and b+256 are expected to share a CU: heaviest with lightest
-            order = np.empty(nt, np.int64)
-            nh = min(256, nt)
-            order[:nh] = desc[:nh]
-            rest = desc[nh:][::-1]            # lightest first
-            order[nh:nh + len(rest)] = rest
-            if nt > 512:
-                order = desc
-            if mode.endswith("xcd"):
-                pass
-        t = torch.from_numpy(order.astype(np.int32)).to(dev)
-        L.fd_debug_set_tile_order(ctypes.c_void_p(t.data_ptr()))
-        for _ in range(2):
-            hip_ops.spconv_apply(x, wpk, bias, nbr, ix.n, C, residual=x, relu=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(args.iters):
-            y2 = hip_ops.spconv_apply(x, wpk, bias, nbr, ix.n, C, residual=x, relu=True)
-        e1.record()
-        torch.cuda.synchronize()
-        print("  tile order %-12s: %.1f us  (same result: %s)" % (mode, 1e3 * e0.elapsed_time(e1) / args.iters, bool(torch.equal(y, y2))))
-    L.fd_debug_set_tile_order(None)
