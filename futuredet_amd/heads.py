@@ -257,20 +257,27 @@ class CenterHead(nn.Module):
         scores = scores.view(G, B, post).transpose(0, 1)
         cell = cell.view(G, B, post).transpose(0, 1)
         count = count.view(G, B).transpose(0, 1)
-        out_b, out_s, out_l, out_c = [], [], [], []
-        flag = 0
-        for s, (vel, g) in enumerate(zip(vels, step_group)):
-            idx = cell[:, g].long().clamp_(min=0)  # [B, post]
-            v = vel.float().reshape(B, 2, H * W)
-            vx = torch.gather(v[:, 0], 1, idx)
-            vy = torch.gather(v[:, 1], 1, idx)
-            b7 = boxes7[:, g]
-            out_b.append(torch.cat([b7[..., :6], vx.unsqueeze(-1), vy.unsqueeze(-1), b7[..., 6:7]], dim=-1))
-            out_s.append(scores[:, g])
-            out_l.append(torch.full((B, post), flag, dtype=torch.int64, device=b7.device))
-            out_c.append(count[:, g])
-            flag += num_classes[s]
-        return torch.stack(out_b, 1), torch.stack(out_s, 1), torch.stack(out_l, 1), torch.stack(out_c, 1)
+        # assemble all S output steps at once (one gather for every step's velocity instead of a Python loop)
+        S = len(vels)
+        dev = boxes7.device
+        ck = (dev, tuple(step_group), tuple(num_classes), B, post)
+        cache = self.__dict__.setdefault("_dec_cache", {})
+        if ck not in cache:  # small index / label tensors, built once (no per-step host->device copies)
+            offs = [0]
+            for ncls in num_classes[:-1]:
+                offs.append(offs[-1] + ncls)
+            cache[ck] = (torch.as_tensor(step_group, device=dev),
+                         torch.as_tensor(offs, dtype=torch.int64, device=dev).view(1, S, 1).expand(B, S, post).contiguous())
+        gsel, labels = cache[ck]
+        b7 = boxes7.index_select(1, gsel)            # [B, S, post, 7]
+        idx = cell.index_select(1, gsel).long().clamp_(min=0)  # [B, S, post]
+        if all(v is vels[0] for v in vels):          # timesteps == 1: the same two channels for every step
+            vstack = vels[0].float().reshape(B, 1, 2, H * W).expand(B, S, 2, H * W)
+        else:
+            vstack = torch.stack([v.float().reshape(B, 2, H * W) for v in vels], 1)  # [B, S, 2, HW]
+        v = torch.gather(vstack, 3, idx.unsqueeze(2).expand(B, S, 2, post)).transpose(2, 3)  # [B, S, post, 2]
+        boxes = torch.cat([b7[..., :6], v, b7[..., 6:7]], dim=-1)
+        return boxes, scores.index_select(1, gsel), labels, count.index_select(1, gsel)
 
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
