@@ -7,6 +7,6 @@ from .config import Config, ConfigDict  # noqa: F401
 from .config_tool import get_downsample_factor  # noqa: F401
 from .registry import (BACKBONES, DETECTORS, HEADS, NECKS, PIPELINES, READERS, build_backbone, build_detector,  # noqa: F401
                        build_from_cfg, build_head, build_neck, build_reader)
-from . import readers, backbones, necks, heads, detectors, voxelize  # noqa: F401,E402  (populate registries)
+from . import readers, backbones, necks, heads, detectors, voxelize, loading  # noqa: F401,E402  (populate registries)
 
 __version__ = "0.1.0"

@@ -327,3 +327,47 @@ def boxes_iou_bev(a, b):
     out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
     check(L.fd_boxes_iou_bev(_p(a), a.shape[0], _p(b), b.shape[0], _p(out), _stream()), "fd_boxes_iou_bev")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ sweep assembly
+SWEEP_DESC = np.dtype([("m", np.float64, (16,)), ("row_begin", np.int64), ("row_end", np.int64), ("time", np.float32),
+                       ("flags", np.int32)])  # == struct fd_sweep_desc (include/futuredet_hip.h)
+SWEEP_HAS_TRANSFORM, SWEEP_REMOVE_CLOSE = 1, 2
+
+
+def sweep_descriptors(rows, transforms, time_lags, remove_close):
+    """Host side of fd_sweep_assemble: per-sweep records in visit order.  ``rows`` are the cumulative raw-row offsets
+    [S+1]; transforms[s] is a 4x4 (any float dtype; promoted to float64 like np.dot with the float64 ones row,
+    loading.py:54-56) or None; time_lags[s] a Python/NumPy float; remove_close[s] a bool."""
+    S = len(rows) - 1
+    d = np.zeros((S,), SWEEP_DESC)
+    for s in range(S):
+        d["row_begin"][s], d["row_end"][s] = int(rows[s]), int(rows[s + 1])
+        flags = 0
+        if transforms[s] is not None:
+            d["m"][s] = np.asarray(transforms[s], np.float64).reshape(16)
+            flags |= SWEEP_HAS_TRANSFORM
+        if remove_close[s]:
+            flags |= SWEEP_REMOVE_CLOSE
+        d["flags"][s] = flags
+        d["time"][s] = np.float32(np.float64(time_lags[s]))  # (time_lag * ones).astype(float32), loading.py:58,134
+    return d
+
+
+def assemble_sweeps(raw, desc, keep_cols=4, min_distance=1.0):
+    """Runs fd_sweep_assemble on device rows ``raw`` [R, raw_cols] float32 with host descriptors ``desc``
+    (sweep_descriptors).  Returns (points [R, keep_cols+1] padded with +inf past the count, count int32[1]); no sync."""
+    L = _lib.load()
+    raw = _dev(raw, "raw", torch.float32)
+    R, raw_cols = raw.shape
+    dev = raw.device
+    desc = np.ascontiguousarray(desc)
+    assert desc.dtype == SWEEP_DESC
+    desc_dev = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev, non_blocking=True)
+    out = torch.empty((R, keep_cols + 1), dtype=torch.float32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws_bytes = L.fd_sweep_assemble_workspace_bytes(R)
+    ws = workspace.get("sweeps", ws_bytes, dev)
+    check(L.fd_sweep_assemble(_p(raw), raw_cols, int(keep_cols), R, _p(desc_dev), len(desc), float(min_distance), _p(out),
+                              _p(count), _p(ws), ws.numel(), _stream()), "fd_sweep_assemble")
+    return out, count

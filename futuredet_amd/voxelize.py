@@ -92,7 +92,7 @@ class Voxelization(object):
 
 
 # names the shipped pipelines reference; they belong to dataset I/O / training and only need to resolve
-for _name in ("LoadPointCloudFromFile", "LoadPointCloudAnnotations", "Preprocess", "AssignLabel", "Reformat", "DoubleFlip",
+for _name in ("LoadPointCloudAnnotations", "Preprocess", "AssignLabel", "Reformat", "DoubleFlip",
               "Empty"):
     def _make(name):
         def __init__(self, **kwargs):

@@ -173,6 +173,33 @@ int fd_rotated_nms(const float *boxes7, int n, float thresh, int64_t *keep, int3
 /* pairwise rotated BEV IoU, replaces boxes_iou_bev_gpu (iou3d_nms.cpp:49-69) */
 int fd_boxes_iou_bev(const float *a7, int na, const float *b7, int nb, float *out, fd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Sweep assembly (the step in front of the voxelizer).  Replaces the NuScenes branch of
+ * LoadPointCloudFromFile.__call__ (det3d/datasets/pipelines/loading.py:107-141) together with read_file's
+ * column cut (:31), remove_close (:36-45) and read_sweep (:47-60): the raw rows of the key frame and of the
+ * sweeps (in the order the reference visits them) are filtered, moved into the key frame's coordinates and
+ * given their time column, in input order.
+ *   raw          [n_rows, raw_cols] float32, the concatenated contents of the .bin files (raw_cols = 5)
+ *   sweeps_dev   [n_sweeps] descriptors IN DEVICE MEMORY, consecutive row ranges covering [0, n_rows)
+ *                m = transform_matrix (row-major 4x4, float64 as the reference's np.dot evaluates it; ignored
+ *                unless FD_SWEEP_HAS_TRANSFORM), time = float32(time_lag) (0 for the key frame)
+ *   out_points   [n_rows, keep_cols + 1] float32; rows [0, *out_count) are the reference's
+ *                res["lidar"]["combined"]; rows [*out_count, n_rows) are filled with +inf (outside any range)
+ *   out_count    device int32[1]
+ * ------------------------------------------------------------------------------------------------- */
+#define FD_SWEEP_HAS_TRANSFORM 1 /* sweep["transform_matrix"] is not None (loading.py:53) */
+#define FD_SWEEP_REMOVE_CLOSE 2  /* read_sweep's remove_close (loading.py:50); not applied to the key frame (:113) */
+typedef struct fd_sweep_desc {
+    double m[16];
+    int64_t row_begin, row_end;
+    float time;
+    int32_t flags;
+} fd_sweep_desc;
+size_t fd_sweep_assemble_workspace_bytes(int64_t n_rows);
+int fd_sweep_assemble(const float *raw, int raw_cols, int keep_cols, int64_t n_rows, const fd_sweep_desc *sweeps_dev,
+                      int n_sweeps, float min_distance, float *out_points, int32_t *out_count, void *workspace,
+                      size_t workspace_bytes, fd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

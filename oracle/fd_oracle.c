@@ -418,3 +418,51 @@ int fdo_nms(const float *boxes /* [n,7] */, int n, float thresh, int64_t *keep)
     free(remv);
     return num;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Sweep assembly.  Follows det3d/datasets/pipelines/loading.py:
+ *   read_file :31 (f32 rows of raw_cols, first keep_cols kept), remove_close :36-45 (|x| < r and |y| < r dropped,
+ *   strict, compared in float32), read_sweep :47-60 (xyz <- (M . [x y z 1]^T)[:3] evaluated in float64 then stored
+ *   to float32; time column = float32(time_lag)), LoadPointCloudFromFile.__call__ :107-141 (key frame first,
+ *   unfiltered, time 0; then the sweeps in the caller's visit order; hstack([points, times])).
+ * flags[s]: bit0 = transform_matrix is not None, bit1 = apply remove_close.
+ * The 4x4 . 4xN product is numpy's dgemm; `chain` selects how its 4-term dot product is rounded (1 = fused
+ * multiply-add chain k=0..3 starting from 0, 0 = separately rounded multiply and add) -- pinned by tests/golden/sweeps.npz.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t fdo_assemble_sweeps(const float *raw, int raw_cols, int keep_cols, const int64_t *rows, int n_sweeps,
+                            const double *mats, const int32_t *flags, const double *lags, float radius,
+                            float *out, int chain)
+{
+    int64_t n_out = 0;
+    const int oc = keep_cols + 1;
+    for (int s = 0; s < n_sweeps; ++s) {
+        const double *m = mats + 16 * s;
+        for (int64_t i = rows[s]; i < rows[s + 1]; ++i) {
+            const float *q = raw + i * raw_cols;
+            if ((flags[s] & 2) && fabsf(q[0]) < radius && fabsf(q[1]) < radius) continue;
+            float *o = out + n_out * oc;
+            for (int c = 0; c < keep_cols; ++c) o[c] = q[c];
+            if (flags[s] & 1) {
+                const double x = q[0], y = q[1], z = q[2];
+                for (int r = 0; r < 3; ++r) {
+                    double acc;
+                    if (chain) {
+                        acc = m[4 * r] * x;
+                        acc = fma(m[4 * r + 1], y, acc);
+                        acc = fma(m[4 * r + 2], z, acc);
+                        acc = fma(m[4 * r + 3], 1.0, acc);
+                    } else {
+                        acc = m[4 * r] * x;
+                        acc = acc + m[4 * r + 1] * y;
+                        acc = acc + m[4 * r + 2] * z;
+                        acc = acc + m[4 * r + 3];
+                    }
+                    o[r] = (float)acc;
+                }
+            }
+            o[keep_cols] = (float)lags[s];
+            ++n_out;
+        }
+    }
+    return n_out;
+}

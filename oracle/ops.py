@@ -50,6 +50,9 @@ def lib():
         L.fdo_set_threads.argtypes = [ctypes.c_int]
         L.fdo_nms.restype = ctypes.c_int
         L.fdo_nms.argtypes = [_f32p, ctypes.c_int, ctypes.c_float, _i64p]
+        L.fdo_assemble_sweeps.restype = ctypes.c_int64
+        L.fdo_assemble_sweeps.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, _i64p, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                          _i32p, ctypes.POINTER(ctypes.c_double), ctypes.c_float, _f32p, ctypes.c_int]
         _LIB = L
     return _LIB
 
@@ -171,3 +174,30 @@ def nms(boxes, thresh):
     keep = np.zeros(max(n, 1), np.int64)
     k = lib().fdo_nms(_ptr(boxes, _f32p), n, ctypes.c_float(thresh), _ptr(keep, _i64p))
     return keep[:k].copy()
+
+
+def assemble_sweeps(key_raw, sweep_raws, transforms, time_lags, nsweeps=None, num_point_feature=4, min_distance=1.0):
+    """LoadPointCloudFromFile (NuScenes branch, loading.py:107-141) on in-memory file contents: key_raw [n,5] and
+    sweep_raws[i] [n_i,5] float32 are what np.fromfile(...).reshape(-1,5) returns for info["lidar_path"] and
+    info["sweeps"][i]["lidar_path"]; transforms[i] is a 4x4 or None; time_lags[i] a float.  -> combined [N,5] f32."""
+    nsweeps = len(sweep_raws) + 1 if nsweeps is None else nsweeps
+    assert nsweeps - 1 == len(sweep_raws)
+    order = np.random.default_rng(0).choice(len(sweep_raws), nsweeps - 1, replace=False) if nsweeps > 1 else []  # :128-129
+    chunks = [np.asarray(key_raw, np.float32)] + [np.asarray(sweep_raws[i], np.float32) for i in order]
+    S = len(chunks)
+    mats = np.zeros((S, 16), np.float64)
+    flags = np.zeros((S,), np.int32)
+    lags = np.zeros((S,), np.float64)
+    for j, i in enumerate(order, start=1):
+        flags[j] = 2
+        if transforms[i] is not None:
+            mats[j] = np.asarray(transforms[i], np.float64).reshape(16)
+            flags[j] |= 1
+        lags[j] = float(time_lags[i])
+    raw = np.ascontiguousarray(np.concatenate(chunks), np.float32)
+    rows = np.cumsum([0] + [len(c) for c in chunks]).astype(np.int64)
+    out = np.empty((max(len(raw), 1), num_point_feature + 1), np.float32)
+    n = lib().fdo_assemble_sweeps(_ptr(raw, _f32p), raw.shape[1], num_point_feature, _ptr(rows, _i64p), S,
+                                  _ptr(mats, ctypes.POINTER(ctypes.c_double)), _ptr(flags, _i32p),
+                                  _ptr(lags, ctypes.POINTER(ctypes.c_double)), ctypes.c_float(min_distance), _ptr(out, _f32p), 1)
+    return out[:n].copy()

@@ -339,10 +339,72 @@ def gen_backbone():
     save("backbone.npz", **out)
 
 
+def _import_ref_pipeline(name):
+    """Imports det3d/datasets/pipelines/<name>.py WITHOUT running det3d/datasets/__init__.py (which hard-imports the
+    nuScenes devkit, shapely, pyquaternion, networkx): the two package nodes are pre-seeded as bare namespace packages
+    so the reference's own file (and its `..registry` import) loads unmodified."""
+    import importlib
+    for pkg in ("det3d.datasets", "det3d.datasets.pipelines"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = [os.path.join(REF, *pkg.split("."))]
+            sys.modules[pkg] = m
+    return importlib.import_module("det3d.datasets.pipelines." + name)
+
+
+def gen_sweeps():
+    """LoadPointCloudFromFile (NuScenesDataset branch, loading.py:107-141) run on seeded .bin files in a temp dir."""
+    import tempfile
+    loading = _import_ref_pipeline("loading")
+    rng = np.random.default_rng(7)
+    cases = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for case, (nsweeps, npts) in {"a": (10, 600), "b": (3, 257), "c": (1, 100)}.items():
+            raws, mats, lags, has = [], [], [], []
+            for s in range(nsweeps):
+                n = npts + 13 * s
+                raw = np.empty((n, 5), np.float32)
+                raw[:, :3] = rng.normal(0, [8.0, 8.0, 1.5], (n, 3))
+                raw[: n // 3, :2] = rng.uniform(-1.6, 1.6, (n // 3, 2))      # many rows around the 1 m remove_close box
+                raw[0, :2] = (1.0, 0.5)                                         # |x| == radius exactly: kept (strict <)
+                raw[1, :2] = (-0.99999994, 0.99999994)                          # one ulp inside: removed
+                raw[2, :2] = (0.2, -1.0)                                        # |y| == radius: kept
+                raw[:, 3] = rng.uniform(0, 255, n)
+                raw[:, 4] = rng.integers(0, 32, n)                              # ring index column, dropped by read_file
+                raw.tofile(os.path.join(tmp, "%s_%d.bin" % (case, s)))
+                raws.append(raw)
+                if s > 0:
+                    ang = rng.uniform(-0.2, 0.2)
+                    m = np.eye(4)
+                    m[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]
+                    m[:3, 3] = rng.normal(0, [3.0, 1.0, 0.05])
+                    m[:3, :3] += rng.normal(0, 1e-3, (3, 3))                    # not exactly orthonormal, like a product of 4
+                    none = (s == 2)                                             # a sweep whose transform_matrix is None
+                    mats.append(np.zeros((4, 4)) if none else m)
+                    has.append(0 if none else 1)
+                    lags.append(0.05 * s + rng.uniform(0, 1e-3))
+            info = {"lidar_path": os.path.join(tmp, "%s_0.bin" % case),
+                    "sweeps": [{"lidar_path": os.path.join(tmp, "%s_%d.bin" % (case, s + 1)),
+                                "transform_matrix": (mats[s] if has[s] else None), "time_lag": lags[s]}
+                               for s in range(nsweeps - 1)]}
+            res = {"lidar": {"nsweeps": nsweeps}, "painted": False}
+            res, _ = loading.LoadPointCloudFromFile(dataset="NuScenesDataset")(res, info)
+            cases[case + "_raw"] = np.concatenate(raws)
+            cases[case + "_rows"] = np.cumsum([0] + [len(r) for r in raws]).astype(np.int64)
+            cases[case + "_mats"] = np.asarray(mats, np.float64).reshape(-1, 4, 4)
+            cases[case + "_has"] = np.asarray(has, np.int32)
+            cases[case + "_lags"] = np.asarray(lags, np.float64)
+            cases[case + "_points"] = res["lidar"]["points"]
+            cases[case + "_times"] = res["lidar"]["times"]
+            cases[case + "_combined"] = res["lidar"]["combined"]
+            print(case, res["lidar"]["combined"].shape, res["lidar"]["combined"].dtype)
+    save("sweeps.npz", **cases)
+
+
 if __name__ == "__main__":
     install_shims()
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["voxelizer", "configs", "dense", "predict", "iou", "backbone"]
+    which = sys.argv[1:] or ["voxelizer", "configs", "dense", "predict", "iou", "backbone", "sweeps"]
     for w in which:
         {"voxelizer": gen_voxelizer, "configs": gen_configs, "dense": gen_dense_nets, "predict": gen_predict,
-         "iou": gen_iou, "backbone": gen_backbone}[w]()
+         "iou": gen_iou, "backbone": gen_backbone, "sweeps": gen_sweeps}[w]()

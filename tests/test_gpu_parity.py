@@ -402,3 +402,83 @@ def test_dense_bf16_plan_vs_torch_modules(hip):
     for k in p_ref[0]:
         assert p[0][k].shape == p_ref[0][k].shape
         assert float((p[0][k] - p_ref[0][k]).abs().max()) <= 3e-2 * max(1.0, float(p_ref[0][k].abs().max())), k
+
+
+# ------------------------------------------------------------------------------------------------ sweep assembly
+def _write_sweep_files(tmp_path, g, case):
+    rows = g[case + "_rows"]
+    paths = []
+    for s in range(len(rows) - 1):
+        p = os.path.join(str(tmp_path), "%s_%d.bin" % (case, s))
+        g[case + "_raw"][rows[s]:rows[s + 1]].tofile(p)
+        paths.append(p)
+    info = {"lidar_path": paths[0],
+            "sweeps": [{"lidar_path": paths[s + 1], "transform_matrix": (g[case + "_mats"][s] if g[case + "_has"][s] else None),
+                        "time_lag": float(g[case + "_lags"][s])} for s in range(len(paths) - 1)]}
+    return info, len(paths)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_sweep_assembly_matches_reference_golden(hip, golden, tmp_path, case):
+    """LoadPointCloudFromFile through the registry on .bin files, bit-exact vs the reference's own output."""
+    from futuredet_amd import PIPELINES, build_from_cfg
+
+    g = golden("sweeps.npz")
+    info, nsweeps = _write_sweep_files(tmp_path, g, case)
+    stage = build_from_cfg(dict(type="LoadPointCloudFromFile", dataset="NuScenesDataset"), PIPELINES)
+    res, _ = stage({"lidar": {"nsweeps": nsweeps}, "painted": False}, info)
+    out = res["lidar"]["combined"].cpu().numpy()
+    ref = g[case + "_combined"]
+    assert out.shape == ref.shape
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(res["lidar"]["points"].cpu().numpy(), g[case + "_points"])
+    assert np.array_equal(res["lidar"]["times"].cpu().numpy(), g[case + "_times"])
+
+
+def test_sweep_assembly_full_size_vs_oracle_and_padded_voxelization(hip):
+    """10 sweeps x ~34k rows: bit-exact vs the oracle; the +inf padded output voxelizes like the trimmed one."""
+    from oracle import ops as oops
+    from futuredet_amd.synth import synthetic_cloud
+
+    rng = np.random.default_rng(3)
+    cloud = synthetic_cloud(seed=5, target_points=300000)
+    S = 10
+    chunks = np.array_split(cloud, S)
+    raws, mats, lags = [], [], []
+    for s, c in enumerate(chunks):
+        raw = np.concatenate([c[:, :4], rng.integers(0, 32, (len(c), 1)).astype(np.float32)], axis=1)
+        raw[: len(raw) // 50, :2] = rng.uniform(-1.2, 1.2, (len(raw) // 50, 2)).astype(np.float32)
+        raws.append(np.ascontiguousarray(raw, np.float32))
+        if s:
+            a = rng.uniform(-0.05, 0.05)
+            m = np.eye(4)
+            m[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+            m[:3, 3] = rng.normal(0, [2.0, 0.5, 0.02])
+            mats.append(None if s == 4 else m)
+            lags.append(0.05 * s)
+    ref = oops.assemble_sweeps(raws[0], raws[1:], mats, lags)
+    order = [0] + [int(i) + 1 for i in np.random.default_rng(0).choice(S - 1, S - 1, replace=False)]
+    rows = np.cumsum([0] + [len(raws[s]) for s in order])
+    desc = hip.sweep_descriptors(rows, [None if s == 0 else mats[s - 1] for s in order], [0.0 if s == 0 else lags[s - 1] for s in order],
+                                 [s != 0 for s in order])
+    out, count = hip.assemble_sweeps(_dev(np.concatenate([raws[s] for s in order])), desc)
+    n = int(count.item())
+    assert n == len(ref) and n < out.shape[0]
+    assert np.array_equal(out[:n].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert bool(torch.isinf(out[n:]).all())
+    vs, rg = [0.075, 0.075, 0.2], [-54, -54, -5.0, 54, 54, 3.0]
+    a = hip.voxelize(out, vs, rg, 10, 160000, want_voxels=False, want_mean=True)
+    b = hip.voxelize(out[:n].contiguous(), vs, rg, 10, 160000, want_voxels=False, want_mean=True)
+    nv = int(a["num_voxels"].item())
+    assert nv == int(b["num_voxels"].item()) and nv > 100000
+    for k in ("coors", "num_points", "mean"):
+        assert torch.equal(a[k][:nv], b[k][:nv])
+
+
+def test_sweep_assembly_empty_and_single(hip):
+    desc = hip.sweep_descriptors([0, 0], [None], [0.0], [False])
+    out, count = hip.assemble_sweeps(torch.zeros((0, 5), device="cuda"), desc)
+    assert out.shape == (0, 5) and int(count.item()) == 0
+    raw = torch.tensor([[0.5, 0.5, 0.0, 1.0, 0.0], [2.0, 0.0, 0.0, 2.0, 0.0]], device="cuda")
+    out, count = hip.assemble_sweeps(raw, hip.sweep_descriptors([0, 2], [None], [0.25], [True]))
+    assert int(count.item()) == 1 and out[0].tolist() == [2.0, 0.0, 0.0, 2.0, 0.25]

@@ -258,3 +258,26 @@ def test_synthetic_cloud_is_deterministic_and_shaped():
     a, b = synthetic_cloud(3, 20000), synthetic_cloud(3, 20000)
     assert np.array_equal(a, b) and a.dtype == np.float32 and a.shape[1] == 5
     assert 15000 < len(a) < 25000 and set(np.round(np.unique(a[:, 4]) / 0.05).astype(int)) == set(range(10))
+
+
+def test_sweep_descriptor_layout_and_visit_order(golden):
+    """struct fd_sweep_desc <-> numpy dtype, and the reference's seeded visit order (loading.py:128-129)."""
+    from futuredet_amd import hip_ops, loading
+
+    assert hip_ops.SWEEP_DESC.itemsize == 16 * 8 + 8 + 8 + 4 + 4
+    assert [hip_ops.SWEEP_DESC.fields[k][1] for k in ("m", "row_begin", "row_end", "time", "flags")] == [0, 128, 136, 144, 148]
+    order = loading.sweep_visit_order(9, 10)
+    assert sorted(order) == list(range(9)) and order == [int(i) for i in np.random.default_rng(0).choice(9, 9, replace=False)]
+    m = np.arange(16.0).reshape(4, 4).astype(np.float32)
+    d = hip_ops.sweep_descriptors([0, 5, 9], [None, m], [0.0, 0.1], [False, True])
+    assert d["flags"].tolist() == [0, 3] and d["row_end"].tolist() == [5, 9]
+    assert d["time"][1] == np.float32(0.1) and np.array_equal(d["m"][1], np.arange(16.0))
+
+
+def test_load_point_cloud_class_resolves_and_rejects_other_datasets():
+    from futuredet_amd import PIPELINES, build_from_cfg
+
+    stage = build_from_cfg(dict(type="LoadPointCloudFromFile", dataset="NuScenesDataset"), PIPELINES)
+    assert stage.type == "NuScenesDataset"
+    with pytest.raises(NotImplementedError):
+        build_from_cfg(dict(type="LoadPointCloudFromFile", dataset="WaymoDataset"), PIPELINES)({"lidar": {}}, {})

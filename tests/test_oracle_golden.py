@@ -182,3 +182,23 @@ def test_oracle_predict_matches_reference_golden(golden, name, T, dense):
         assert np.array_equal(r["label_preds"].numpy(), g["%s_out_b%d_labels" % (name, b)])
         np.testing.assert_allclose(r["box3d_lidar"].numpy(), g["%s_out_b%d_boxes" % (name, b)], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(r["scores"].numpy(), g["%s_out_b%d_scores" % (name, b)], rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------ sweep assembly
+def _sweep_case(g, case):
+    rows = g[case + "_rows"]
+    raws = [g[case + "_raw"][rows[s]:rows[s + 1]] for s in range(len(rows) - 1)]
+    mats = [m if h else None for m, h in zip(g[case + "_mats"], g[case + "_has"])]
+    return raws, mats, list(g[case + "_lags"])
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_oracle_sweep_assembly_matches_reference_golden(golden, case):
+    """Bit-exact against LoadPointCloudFromFile (loading.py:107-141) run on the same files by make_golden.py."""
+    g = golden("sweeps.npz")
+    raws, mats, lags = _sweep_case(g, case)
+    out = oops.assemble_sweeps(raws[0], raws[1:], mats, lags)
+    ref = g[case + "_combined"]
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(out[:, :4], g[case + "_points"]) and np.array_equal(out[:, 4:5], g[case + "_times"])
