@@ -187,6 +187,17 @@ class SpMiddleResNetFHD(nn.Module):
 
 @BACKBONES.register_module
 class PointPillarsScatter(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """det3d/models/readers/pillar_encoder.py:167-221: pillar rows -> [B, C, ny, nx] pseudo image (fd_pillar_scatter:
+    cell = y*nx + x as in :204-214; written NCHW, or channels-last for the bf16 convolution path)."""
+
+    def __init__(self, num_input_features=64, norm_cfg=None, name="PointPillarsScatter", **kwargs):
         super().__init__()
-        raise NotImplementedError("PointPillarsScatter is outside the VoxelNet hot path")
+        self.name = "PointPillarsScatter"
+        self.nchannels = num_input_features
+        self.dense_channels_last = False
+
+    def forward(self, voxel_features, coords, batch_size, input_shape, n_dev=None):
+        self.nx = int(input_shape[0])
+        self.ny = int(input_shape[1])
+        return hip_ops.pillar_scatter(voxel_features, coords.int().contiguous(), n_dev, batch_size, self.ny, self.nx,
+                                      channels_last=self.dense_channels_last)

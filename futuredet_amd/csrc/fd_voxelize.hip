@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int kMaxP = 16;    // compile-time bound on max_points
+constexpr int kMaxP = 64;    // bound on max_points (vox_emit is instantiated for 16 / 32 / 64 slots)
 constexpr int kMaxNd = 8;    // compile-time bound on point width
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 4;
@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(256) vox_fill(const int *__restrict__ pslot, i
     bucket[pos] = i;
 }
 
+template <int MAXP>
 __global__ void __launch_bounds__(256) vox_emit(const float *__restrict__ pts, VoxParams p, const int *__restrict__ num_voxels,
                                                 const int *__restrict__ keys, const int *__restrict__ vslot,
                                                 const int *__restrict__ boff, const int *__restrict__ cursor,
@@ -182,13 +183,13 @@ __global__ void __launch_bounds__(256) vox_emit(const float *__restrict__ pts, V
     if (v >= num_voxels[0]) return;
     const int nv = cursor[v];
     const int *b = bucket + boff[v];
-    int sel[kMaxP];
+    int sel[MAXP];
 #pragma unroll
-    for (int k = 0; k < kMaxP; ++k) sel[k] = 0x7fffffff;
+    for (int k = 0; k < MAXP; ++k) sel[k] = 0x7fffffff;
     for (int t = 0; t < nv; ++t) {
         int x = b[t];
 #pragma unroll
-        for (int k = 0; k < kMaxP; ++k) {  // keep sel[] ascending; x carries the displaced larger value
+        for (int k = 0; k < MAXP; ++k) {  // keep sel[] ascending; x carries the displaced larger value
             int lo = min(sel[k], x), hi = max(sel[k], x);
             sel[k] = lo; x = hi;
         }
@@ -198,7 +199,7 @@ __global__ void __launch_bounds__(256) vox_emit(const float *__restrict__ pts, V
 #pragma unroll
     for (int d = 0; d < kMaxNd; ++d) sum[d] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kMaxP; ++k) {
+    for (int k = 0; k < MAXP; ++k) {
         if (k < p.max_points) {
             const bool live = k < np;
             const float *q = pts + (int64_t)(live ? sel[k] : 0) * p.ndim;
@@ -319,8 +320,13 @@ extern "C" int fd_voxelize(const float *points, int64_t n_points, int ndim, cons
                        vid, boff, vslot, out_num_voxels);
     hipLaunchKernelGGL(vox_fill, dim3(nb), dim3(256), 0, stream, pslot, n, vid, boff, cursor, bucket);
     const int64_t vmax = n_points < max_voxels ? n_points : max_voxels;
-    hipLaunchKernelGGL(vox_emit, dim3((unsigned)((vmax + 255) / 256)), dim3(256), 0, stream, points, p, out_num_voxels, keys,
-                       vslot, boff, cursor, bucket, batch_idx, out_voxels, out_mean, mean_stride, out_coors, coor_cols,
-                       out_num_points);
+#define FD_EMIT(MP)                                                                                                        \
+    hipLaunchKernelGGL(vox_emit<MP>, dim3((unsigned)((vmax + 255) / 256)), dim3(256), 0, stream, points, p, out_num_voxels, keys, \
+                       vslot, boff, cursor, bucket, batch_idx, out_voxels, out_mean, mean_stride, out_coors, coor_cols,           \
+                       out_num_points)
+    if (max_points <= 16) FD_EMIT(16);       // VoxelNet configs: 10
+    else if (max_points <= 32) FD_EMIT(32);  // PointPillars configs: 20
+    else FD_EMIT(64);                        // points_to_voxel's default of 35
+#undef FD_EMIT
     return fd::check_launch("fd_voxelize");
 }

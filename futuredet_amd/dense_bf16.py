@@ -48,9 +48,15 @@ class RPNPlan(object):
                 subs = [(_Conv(f.weight[:, :, dy, dx].t().contiguous()[:, :, None, None], f.bias, 1, f.relu), dy, dx)
                         for dy in range(k) for dx in range(k)]
                 self.deblocks.append(("up", k, subs, f.weight.shape[1]))
-            else:
-                assert f.stride == 1, "strided down-sampling deblocks do not occur in the shipped configs"
+            elif f.weight.shape[-1] == 1:
+                assert f.stride == 1 and f.padding == 0
                 self.deblocks.append(("conv", 1, _Conv(f.weight, f.bias, 1, f.relu), f.weight.shape[0]))
+            else:
+                # Conv2d(k = s, stride s) of an `us stride` 1/s (rpn.py:95-110, the pp configs): space-to-depth + 1x1 conv
+                k = f.weight.shape[-1]
+                assert f.stride == k and f.padding == 0
+                w = f.weight.permute(0, 2, 3, 1).reshape(f.weight.shape[0], -1)[:, :, None, None].contiguous()
+                self.deblocks.append(("down", k, _Conv(w, f.bias, 1, f.relu), f.weight.shape[0]))
         self.cout_total = sum(d[3] for d in self.deblocks)
 
     def __call__(self, x):  # x [B,H,W,C] bf16
@@ -62,12 +68,16 @@ class RPNPlan(object):
             j = i - self.start
             if j >= 0:
                 kind, k, op, cout = self.deblocks[j]
-                B, H, W, _ = x.shape
+                B, H, W, C = x.shape
+                Ho, Wo = (H // k, W // k) if kind == "down" else (H * k, W * k)
                 if ups is None:
-                    ups = torch.empty((B, H * k, W * k, self.cout_total), dtype=torch.bfloat16, device=x.device)
-                assert ups.shape[1] == H * k and ups.shape[2] == W * k
+                    ups = torch.empty((B, Ho, Wo, self.cout_total), dtype=torch.bfloat16, device=x.device)
+                assert ups.shape[1] == Ho and ups.shape[2] == Wo
                 if kind == "conv":
                     op(x, out=ups, co_off=co)
+                elif kind == "down":
+                    xs = x.view(B, Ho, k, Wo, k, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Ho, Wo, k * k * C)
+                    op(xs, out=ups, co_off=co)
                 else:
                     for sub, dy, dx in op:
                         sub(x, out=ups, co_off=co, osy=k, osx=k, ooy=dy, oox=dx)
@@ -76,14 +86,26 @@ class RPNPlan(object):
 
 
 class HeadPlan(object):
-    """Standard CenterHead (no bev_map / forecast_feature): shared conv, then per task one fused first conv and one
-    block-diagonal final conv."""
+    """CenterHead without bev_map: shared conv, then per task one fused first conv and one block-diagonal final conv.
+    With forecast_feature (n3dtf, center_head.py:119-124,383-386) each task first runs its two forecast convs; task
+    i > 0 reads cat[x, feats_{i-1}], which is laid out in place: two ping-pong [B,H,W,2c] buffers hold x in channels
+    [0,c) and receive the previous task's feats in [c,2c) (task 0 reads the same buffer through zero weights)."""
 
     def __init__(self, head):
-        assert not head.bev_map and not head.forecast_feature
+        assert not head.bev_map
         self.shared = _convs_from_stack(head.shared_conv)
+        self.ff = bool(head.forecast_feature)
         self.tasks = []
-        for task in head.tasks:
+        self.pre = []
+        self._cat = None
+        for ti, task in enumerate(head.tasks):
+            if self.ff:
+                st = fold_stack(task.forecast_conv, torch.float32, False)
+                assert len(st) == 2
+                w0 = st[0].weight
+                if ti == 0:  # reads [x | stale feats]: zero weights on the second half
+                    w0 = torch.cat([w0, torch.zeros_like(w0)], dim=1)
+                self.pre.append((_Conv(w0, st[0].bias, 1, True), _Conv(st[1].weight, st[1].bias, 1, True)))
             names = list(task.heads)
             firsts, finals = [], []
             for h in names:
@@ -104,14 +126,30 @@ class HeadPlan(object):
             self.tasks.append((_Conv(w1, b1, 1, True), _Conv(w2, b2, 1, False), names, couts))
 
     def __call__(self, x):  # x [B,H,W,C] bf16 -> list of dicts of NCHW float32 tensors
-        for conv in self.shared:
+        for conv in self.shared[:-1]:
             x = conv(x)
+        last = self.shared[-1]
+        hc = last.cout
+        if self.ff:
+            B, H, W, _ = x.shape
+            if self._cat is None or self._cat[0].shape[:3] != (B, H, W) or self._cat[0].device != x.device:
+                self._cat = [torch.zeros((B, H, W, 2 * hc), dtype=torch.bfloat16, device=x.device) for _ in range(2)]
+            last(x, out=self._cat[0], co_off=0)
+            self._cat[1][..., :hc].copy_(self._cat[0][..., :hc])
+        else:
+            x = last(x)
         rets = []
-        for c1, c2, names, couts in self.tasks:
+        for ti, (c1, c2, names, couts) in enumerate(self.tasks):
+            d = {}
+            if self.ff:
+                p0, p1 = self.pre[ti]
+                x = p1(p0(self._cat[ti & 1]))                       # feats_i, contiguous for this task's heads
+                self._cat[(ti + 1) & 1][..., hc:].copy_(x)          # and behind x for the next task's concat
+                d["feats"] = x.permute(0, 3, 1, 2)
             z = c2(c1(x)).permute(0, 3, 1, 2).float()  # [B, sum(couts), H, W]
-            d, o = {}, 0
-            for name, c in zip(names, couts):
-                d[name] = z[:, o:o + c]
-                o += c
+            o = 0
+            for name, cn in zip(names, couts):
+                d[name] = z[:, o:o + cn]
+                o += cn
             rets.append(d)
         return rets

@@ -194,8 +194,82 @@ class VoxelNet(SingleStageDetector):
 
 @DETECTORS.register_module
 class PointPillars(SingleStageDetector):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("PointPillars is outside the VoxelNet hot path (only its config files load)")
+    """det3d/models/detectors/point_pillars.py:5-50 (the two *_pp_* configs).  Same contract as VoxelNet: forward(example)
+    mirrors the reference; forward_points is the device-resident path (voxelizer with point slots -> fused pillar
+    reader -> scatter -> RPN -> CenterHead -> decode)."""
+
+    def __init__(self, reader, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__(reader, backbone, neck, bbox_head, train_cfg, test_cfg, pretrained)
+
+    def set_precision(self, dtype=torch.float32, channels_last=None):
+        channels_last = bool(channels_last)
+        self.reader.compute_dtype = dtype
+        self.backbone.dense_channels_last = channels_last or dtype == torch.bfloat16
+        self.neck.compute_dtype = dtype
+        self.neck.channels_last = channels_last
+        self.bbox_head.compute_dtype = dtype
+        self.bbox_head.channels_last = channels_last
+        return self
+
+    def extract_feat(self, data):
+        input_features = self.reader(data["features"], data["num_voxels"], data["coors"])
+        x = self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
+        if self.with_neck:
+            x = self.neck(x)
+        return x
+
+    def forward(self, example, return_loss=True, **kwargs):
+        num_voxels = example["num_voxels"]
+        data = dict(features=example["voxels"], num_voxels=example["num_points"], coors=example["coordinates"],
+                    batch_size=len(num_voxels), input_shape=example["shape"][0])
+        x = self.extract_feat(data)
+        preds = self.bbox_head(x)
+        if return_loss:
+            return self.bbox_head.loss(example, preds)
+        return self.bbox_head.predict(example, preds, self.test_cfg)
+
+    @torch.no_grad()
+    def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True):
+        assert not self.training
+        mark_stage = getattr(self, "stage_hook", None) or (lambda name: None)
+        mark_stage("start")
+        dev = clouds[0].device
+        B = len(clouds)
+        rng, vs = voxel_cfg["range"], voxel_cfg["voxel_size"]
+        mv = voxel_cfg["max_voxel_num"]
+        max_voxels = int(mv[1] if isinstance(mv, (list, tuple)) else mv)
+        max_points = int(voxel_cfg["max_points_in_voxel"])
+        ndim = clouds[0].shape[1]
+        voxels = torch.empty((B * max_voxels, max_points, ndim), dtype=torch.float32, device=dev)
+        coors = torch.empty((B * max_voxels, 4), dtype=torch.int32, device=dev)
+        npts = torch.empty((B * max_voxels,), dtype=torch.int32, device=dev)
+        nvox = torch.zeros((B,), dtype=torch.int32, device=dev)
+        grid = np.round((np.array(rng[3:], np.float32) - np.array(rng[:3], np.float32)) / np.array(vs, np.float32)).astype(np.int64)
+        canvas = None
+        for b, pts in enumerate(clouds):
+            sl = slice(b * max_voxels, (b + 1) * max_voxels)
+            hip_ops.voxelize(pts, vs, rng, max_points, max_voxels, batch_idx=b, want_voxels=True, coor_cols=4,
+                             out=dict(voxels=voxels[sl], coors=coors[sl], num_points=npts[sl], num_voxels=nvox[b:b + 1]))
+        mark_stage("voxelize")
+        for b in range(B):
+            sl = slice(b * max_voxels, (b + 1) * max_voxels)
+            feats = self.reader(voxels[sl], npts[sl], coors[sl], n_dev=nvox[b:b + 1])
+            if canvas is None:
+                canvas = torch.empty((B, feats.shape[1], int(grid[1]), int(grid[0])), dtype=feats.dtype, device=dev,
+                                     memory_format=torch.channels_last if self.backbone.dense_channels_last
+                                     else torch.contiguous_format)
+            hip_ops.pillar_scatter(feats, coors[sl], nvox[b:b + 1], B, int(grid[1]), int(grid[0]), out=canvas, zero_first=(b == 0))
+        mark_stage("pillars")
+        x = self.neck(canvas)
+        mark_stage("rpn")
+        preds = self.bbox_head(x, bev_map)
+        mark_stage("head")
+        if padded:
+            out = self.bbox_head.predict_padded(preds, self.test_cfg)
+        else:
+            out = self.bbox_head.predict({"metadata": [None] * B}, preds, self.test_cfg)
+        mark_stage("decode")
+        return out
 
 
 @DETECTORS.register_module

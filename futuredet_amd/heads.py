@@ -193,8 +193,7 @@ class CenterHead(nn.Module):
     def forward(self, x, bev_map=None, *kwargs):
         if self.training:
             return self.forward_modules(x, bev_map)
-        if (self.compute_dtype == torch.bfloat16 and x.is_cuda and self.use_hip_conv and not self.bev_map
-                and not self.forecast_feature):
+        if self.compute_dtype == torch.bfloat16 and x.is_cuda and self.use_hip_conv and not self.bev_map:
             if self._plan is None:
                 from .dense_bf16 import HeadPlan
 

@@ -371,3 +371,37 @@ def assemble_sweeps(raw, desc, keep_cols=4, min_distance=1.0):
     check(L.fd_sweep_assemble(_p(raw), raw_cols, int(keep_cols), R, _p(desc_dev), len(desc), float(min_distance), _p(out),
                               _p(count), _p(ws), ws.numel(), _stream()), "fd_sweep_assemble")
     return out, count
+
+
+# ------------------------------------------------------------------------------------------------ PointPillars reader
+def pillar_encode(voxels, num_points, coors4, n_dev, geom, layers, with_distance=False, out_dtype=torch.float32):
+    """fd_pillar_encode: voxels [M,P,ndim] f32, num_points [M] i32, coors4 [M,4] i32 (b,z,y,x), n_dev device int32[1] or
+    None; geom = (vx, vy, x_offset, y_offset); layers = [(weight [U,Fin] f32, scale [U], shift [U])] (1 or 2 entries).
+    Returns [M, U_last] (rows past the count are left untouched: zero-initialised here)."""
+    L = _lib.load()
+    voxels = _dev(voxels, "voxels", torch.float32)
+    M, P, ndim = voxels.shape
+    (w1, s1, b1) = layers[0]
+    (w2, s2, b2) = layers[1] if len(layers) > 1 else (None, None, None)
+    assert len(layers) in (1, 2)
+    U = (w2 if w2 is not None else w1).shape[0]
+    out = torch.zeros((M, U), dtype=out_dtype, device=voxels.device)
+    check(L.fd_pillar_encode(_p(voxels), _p(num_points), _p(coors4), _p(n_dev), M, P, ndim, int(bool(with_distance)),
+                             float(geom[0]), float(geom[1]), float(geom[2]), float(geom[3]), _p(w1), _p(s1), _p(b1), w1.shape[0],
+                             _p(w2), _p(s2), _p(b2), (w2.shape[0] if w2 is not None else 0), _DT[out_dtype], _p(out), U, _stream()),
+          "fd_pillar_encode")
+    return out
+
+
+def pillar_scatter(feats, coors4, n_dev, batch_size, ny, nx, out_dtype=None, channels_last=False, out=None, zero_first=True):
+    """fd_pillar_scatter -> [B, C, ny, nx] canvas (NCHW, or channels-last memory when asked)."""
+    L = _lib.load()
+    feats = _dev(feats, "feats")
+    M, C = feats.shape
+    if out is None:
+        out = torch.empty((batch_size, C, ny, nx), dtype=out_dtype or feats.dtype, device=feats.device,
+                          memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    sb, sc, sy, sx = out.stride()
+    check(L.fd_pillar_scatter(_p(feats), C, feats.stride(0), _DT[feats.dtype], _p(coors4), _p(n_dev), M, batch_size, ny, nx,
+                              _p(out), _DT[out.dtype], sb, sc, sy, sx, int(bool(zero_first)), _stream()), "fd_pillar_scatter")
+    return out

@@ -58,6 +58,11 @@ SIGNATURES = {
     "fd_nms_workspace_bytes": (c_size_t, [c_int]),
     "fd_rotated_nms": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fd_boxes_iou_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "fd_pillar_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_float, c_float, c_float,
+                                 c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_void_p, c_int, c_void_p]),
+    "fd_pillar_scatter": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_int,
+                                  c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "fd_sweep_assemble_workspace_bytes": (c_size_t, [c_i64]),
     "fd_sweep_assemble": (c_int, [c_void_p, c_int, c_int, c_i64, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

@@ -200,6 +200,30 @@ int fd_sweep_assemble(const float *raw, int raw_cols, int keep_cols, int64_t n_r
                       int n_sweeps, float min_distance, float *out_points, int32_t *out_count, void *workspace,
                       size_t workspace_bytes, fd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * PointPillars reader.  Replaces PillarFeatureNet.forward (det3d/models/readers/pillar_encoder.py:113-164) and
+ * its PFNLayers (:38-55: Linear(bias=False) -> eval BatchNorm1d -> ReLU -> max over the pillar's points
+ * [-> concat with the repeated max]) in one launch; nothing of shape [M, P, C] is written to memory.
+ *   voxels      [m_max, max_points, ndim] float32 zero padded (fd_voxelize's out_voxels)
+ *   num_points  [m_max] int32;  coors4 [m_max, 4] int32 (b,z,y,x);  n_dev: device pillar count or NULL (= m_max)
+ *   vx, vy, x_offset, y_offset : PillarFeatureNet.vx/.vy/.x_offset/.y_offset (:107-110)
+ *   w1 [units1, ndim+5(+1)] = pfn_layers[0].linear.weight; scale/shift = the eval BatchNorm1d as y = x*scale+shift
+ *   w2 [units2, 2*units1]   = pfn_layers[1].linear.weight or NULL for a single layer (num_filters=(64,))
+ *   out         [m_max, out_stride] float32 (out_dtype 0) or bf16 (1); rows >= the pillar count are not written
+ * ------------------------------------------------------------------------------------------------- */
+int fd_pillar_encode(const float *voxels, const int32_t *num_points, const int32_t *coors4, const int32_t *n_dev,
+                     int64_t m_max, int max_points, int ndim, int with_distance, float vx, float vy, float x_offset,
+                     float y_offset, const float *w1, const float *scale1, const float *shift1, int units1,
+                     const float *w2, const float *scale2, const float *shift2, int units2, int out_dtype, void *out,
+                     int out_stride, fd_stream_t stream);
+
+/* PointPillarsScatter.forward (pillar_encoder.py:186-221): out[b, c, y, x] = feats[row, c] for coors4[row] = (b,_,y,x),
+ * zero elsewhere (zero_first != 0 clears the dense B*c*H*W canvas first).  Strides are in elements, so the same call
+ * writes an NCHW float32 canvas (reference layout) or an NHWC bf16 one (hand-written conv path). */
+int fd_pillar_scatter(const void *feats, int c, int feat_stride, int dtype, const int32_t *coors4, const int32_t *n_dev,
+                      int64_t m_max, int B, int H, int W, void *out, int out_dtype, int64_t stride_b, int64_t stride_c,
+                      int64_t stride_y, int64_t stride_x, int zero_first, fd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

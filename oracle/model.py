@@ -325,3 +325,77 @@ class VoxelNet(nn.Module):  # voxelnet.py:23-56, single_stage.py:23-27
             bev = torch.stack(example["bev_map"], dim=1).float()
         preds = self.bbox_head(x, bev)
         return self.bbox_head.predict(example, preds, self.test_cfg)
+
+
+# ------------------------------------------------------------------------------------------------ PointPillars
+class PFNLayer(nn.Module):  # pillar_encoder.py:15-55
+    def __init__(self, cin, cout, last_layer):
+        super().__init__()
+        self.last_vfe = last_layer
+        self.units = cout if last_layer else cout // 2
+        self.linear = nn.Linear(cin, self.units, bias=False)
+        self.norm = _bn1d(self.units)
+
+    def forward(self, x):
+        x = self.linear(x)
+        x = torch.relu(self.norm(x.permute(0, 2, 1)).permute(0, 2, 1))
+        x_max = x.max(dim=1, keepdim=True)[0]
+        if self.last_vfe:
+            return x_max
+        return torch.cat([x, x_max.expand(-1, x.shape[1], -1)], dim=2)
+
+
+class PillarFeatureNet(nn.Module):  # pillar_encoder.py:58-164
+    def __init__(self, num_input_features=4, num_filters=(64,), with_distance=False, voxel_size=(0.2, 0.2, 4),
+                 pc_range=(0, -40, -3, 70.4, 40, 1), **kw):
+        super().__init__()
+        fin = num_input_features + 5 + (1 if with_distance else 0)
+        nf = [fin] + list(num_filters)
+        self.pfn_layers = nn.ModuleList([PFNLayer(nf[i], nf[i + 1], i >= len(nf) - 2) for i in range(len(nf) - 1)])
+        self.with_distance = with_distance
+        self.vx, self.vy = voxel_size[0], voxel_size[1]
+        self.x_offset = self.vx / 2 + pc_range[0]
+        self.y_offset = self.vy / 2 + pc_range[1]
+
+    def forward(self, features, num_voxels, coors):
+        mean = features[:, :, :3].sum(dim=1, keepdim=True) / num_voxels.type_as(features).view(-1, 1, 1)   # :120-122
+        f_cluster = features[:, :, :3] - mean
+        cx = coors[:, 3].to(features.dtype).unsqueeze(1) * self.vx + self.x_offset                          # :128-133
+        cy = coors[:, 2].to(features.dtype).unsqueeze(1) * self.vy + self.y_offset
+        f_center = torch.stack([features[:, :, 0] - cx, features[:, :, 1] - cy], dim=-1)
+        parts = [features, f_cluster, f_center]
+        if self.with_distance:
+            parts.append(torch.norm(features[:, :, :3], 2, 2, keepdim=True))
+        x = torch.cat(parts, dim=-1)
+        mask = torch.arange(x.shape[1]).view(1, -1) < num_voxels.view(-1, 1)                                # :146-149
+        x = x * mask.unsqueeze(-1).type_as(x)
+        for pfn in self.pfn_layers:
+            x = pfn(x)
+        return x.squeeze()
+
+
+def pillars_scatter(voxel_features, coords, batch_size, input_shape):  # pillar_encoder.py:186-221
+    nx, ny = int(input_shape[0]), int(input_shape[1])
+    C = voxel_features.shape[1]
+    out = torch.zeros((batch_size, C, ny * nx), dtype=voxel_features.dtype)
+    for b in range(batch_size):
+        m = coords[:, 0] == b
+        idx = (coords[m, 2] * nx + coords[m, 3]).long()
+        out[b][:, idx] = voxel_features[m].t()
+    return out.view(batch_size, C, ny, nx)
+
+
+class PointPillars(nn.Module):  # point_pillars.py:5-50
+    def __init__(self, reader, backbone, neck, bbox_head, test_cfg=None, **kw):
+        super().__init__()
+        self.reader = PillarFeatureNet(**{k: v for k, v in reader.items() if k != "type"})
+        self.neck = RPN(**{k: v for k, v in neck.items() if k not in ("type", "logger")})
+        self.bbox_head = CenterHead(**{k: v for k, v in bbox_head.items() if k not in ("type", "logger")})
+        self.test_cfg = test_cfg
+
+    @torch.no_grad()
+    def forward(self, example, return_loss=False):
+        feats = self.reader(example["voxels"], example["num_points"], example["coordinates"])
+        x = pillars_scatter(feats, example["coordinates"], len(example["num_voxels"]), example["shape"][0])
+        preds = self.bbox_head(self.neck(x))
+        return self.bbox_head.predict(example, preds, self.test_cfg)

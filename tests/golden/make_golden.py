@@ -401,10 +401,54 @@ def gen_sweeps():
     save("sweeps.npz", **cases)
 
 
+def gen_pillars():
+    """The reference's PillarFeatureNet + PointPillarsScatter (pillar_encoder.py) and its RPN built with the pp configs'
+    stride pattern (a down-sampling Conv2d deblock, a 1x1 and a transposed one) at reduced width, on seeded inputs."""
+    import det3d.models  # noqa: F401
+    from det3d.models.readers.pillar_encoder import PillarFeatureNet, PointPillarsScatter
+    from det3d.models.necks.rpn import RPN
+    from det3d.ops.point_cloud.point_cloud_ops import points_to_voxel
+    out = {}
+    vs, rg = [0.2, 0.2, 8.0], [-6.4, -6.4, -5.0, 6.4, 6.4, 3.0]
+    for name, nf, wd in (("two", [64, 64], False), ("one", [64], True)):
+        rng = np.random.default_rng(17)
+        pts = np.concatenate([rng.uniform(-7, 7, (1600, 2)), rng.uniform(-4, 2, (1600, 1)), rng.uniform(0, 255, (1600, 1)),
+                              rng.integers(0, 10, (1600, 1)) * 0.05], axis=1).astype(np.float32)
+        pts[:400, :2] = rng.normal(1.0, 0.15, (400, 2))                          # pillars that overflow 20 slots
+        voxels, coors, num = points_to_voxel(pts, np.array(vs, np.float32), np.array(rg, np.float32), 20, True, 3000)
+        B = 2
+        coors4 = np.concatenate([np.concatenate([np.full((len(coors), 1), b, np.int32), coors], 1) for b in range(B)])
+        voxels2, num2 = np.concatenate([voxels, voxels[::-1]]), np.concatenate([num, num[::-1]])
+        coors4[len(coors):, 1:] = coors[::-1]
+        net = PillarFeatureNet(num_input_features=5, num_filters=nf, with_distance=wd, voxel_size=vs, pc_range=rg).eval()
+        sd = seeded_state_dict(net, 23)
+        net.load_state_dict(sd, strict=False)
+        with torch.no_grad():
+            f = net(torch.from_numpy(voxels2), torch.from_numpy(num2), torch.from_numpy(coors4))
+            canvas = PointPillarsScatter(num_input_features=64)(f, torch.from_numpy(coors4), B, np.array([64, 64, 1]))
+        out.update({"voxels": voxels2, "num": num2, "coors": coors4, name + "_feats": f.numpy(),
+                    name + "_canvas_sum": canvas.numpy().sum(axis=1), name + "_canvas_c5": canvas.numpy()[:, 5]})
+        for k, v in sd.items():
+            out[name + "_sd_" + k] = v.numpy()
+        print("pillars", name, voxels2.shape, f.shape, canvas.shape, int((num2 == 20).sum()), "full pillars")
+    rpn = RPN(layer_nums=[1, 2, 2], ds_layer_strides=[2, 2, 2], ds_num_filters=[16, 32, 64], us_layer_strides=[0.5, 1, 2],
+              us_num_filters=[32, 32, 32], num_input_features=64, logger=__import__("logging").getLogger("RPN")).eval()
+    sd = seeded_state_dict(rpn, 29)
+    rpn.load_state_dict(sd, strict=False)
+    x = torch.from_numpy(np.random.default_rng(31).standard_normal((1, 64, 32, 32)).astype(np.float32))
+    with torch.no_grad():
+        y = rpn(x)
+    out["rpn_in"], out["rpn_out"] = x.numpy(), y.numpy()
+    for k, v in sd.items():
+        out["rpn_sd_" + k] = v.numpy()
+    print("pp rpn", tuple(y.shape))
+    save("pillars.npz", **out)
+
+
 if __name__ == "__main__":
     install_shims()
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["voxelizer", "configs", "dense", "predict", "iou", "backbone", "sweeps"]
+    which = sys.argv[1:] or ["voxelizer", "configs", "dense", "predict", "iou", "backbone", "sweeps", "pillars"]
     for w in which:
         {"voxelizer": gen_voxelizer, "configs": gen_configs, "dense": gen_dense_nets, "predict": gen_predict,
-         "iou": gen_iou, "backbone": gen_backbone, "sweeps": gen_sweeps}[w]()
+         "iou": gen_iou, "backbone": gen_backbone, "sweeps": gen_sweeps, "pillars": gen_pillars}[w]()

@@ -40,6 +40,12 @@ def test_config_builder_matches_parsed_reference_configs():
         c = centerpoint_config(variant, cls)
         for k in ("model", "test_cfg", "voxel_generator", "timesteps", "tasks", "class_names"):
             assert _plain(c[k]) == g[fname][k], (fname, k)
+    from futuredet_amd.configs import pointpillars_config
+    for fname, cls in [("nusc_centerpoint_pp_forecast_n3dtf_detection.py", "car"),
+                       ("nusc_centerpoint_pp_pedestrian_forecast_n3dtf_detection.py", "pedestrian")]:
+        c = pointpillars_config(cls)
+        for k in ("model", "test_cfg", "voxel_generator", "timesteps", "tasks", "class_names"):
+            assert _plain(c[k]) == g[fname][k], (fname, k)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference configs only exist in the build container")
@@ -56,9 +62,9 @@ def test_reference_config_files_load_unchanged():
         if cfg.model.type == "VoxelNet":
             net = fa.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
             assert type(net).__name__ == "VoxelNet"
-        else:  # PointPillars configs load; the model itself is outside the hot path and says so
-            with pytest.raises(NotImplementedError):
-                fa.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+        else:
+            net = fa.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+            assert type(net).__name__ == "PointPillars" and "reader.pfn_layers.1.linear.weight" in net.state_dict()
 
 
 def test_registry_contract():

@@ -202,3 +202,31 @@ def test_oracle_sweep_assembly_matches_reference_golden(golden, case):
     assert out.shape == ref.shape and out.dtype == ref.dtype
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
     assert np.array_equal(out[:, :4], g[case + "_points"]) and np.array_equal(out[:, 4:5], g[case + "_times"])
+
+
+# ------------------------------------------------------------------------------------------------ PointPillars
+@pytest.mark.parametrize("name,nf,wd", [("two", [64, 64], False), ("one", [64], True)])
+def test_oracle_pillar_reader_and_scatter_match_reference_golden(golden, name, nf, wd):
+    g = golden("pillars.npz")
+    net = omodel.PillarFeatureNet(num_input_features=5, num_filters=nf, with_distance=wd, voxel_size=[0.2, 0.2, 8.0],
+                                  pc_range=[-6.4, -6.4, -5.0, 6.4, 6.4, 3.0]).eval()
+    sd = {k[len(name) + 4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(name + "_sd_")}
+    net.load_state_dict(sd)
+    coors = torch.from_numpy(g["coors"])
+    with torch.no_grad():
+        f = net(torch.from_numpy(g["voxels"]), torch.from_numpy(g["num"]), coors)
+    assert np.allclose(f.numpy(), g[name + "_feats"], rtol=1e-4, atol=1e-4)
+    canvas = omodel.pillars_scatter(f, coors, 2, [64, 64, 1]).numpy()
+    assert np.allclose(canvas.sum(axis=1), g[name + "_canvas_sum"], rtol=1e-4, atol=1e-3)
+    assert np.allclose(canvas[:, 5], g[name + "_canvas_c5"], rtol=1e-4, atol=1e-4)
+
+
+def test_oracle_pp_rpn_matches_reference_golden(golden):
+    """RPN with the pp configs' deblock pattern: Conv2d(k=2,s=2) for us stride 0.5, 1x1, ConvTranspose2d(k=2,s=2)."""
+    g = golden("pillars.npz")
+    rpn = omodel.RPN(layer_nums=[1, 2, 2], ds_layer_strides=[2, 2, 2], ds_num_filters=[16, 32, 64], us_layer_strides=[0.5, 1, 2],
+                     us_num_filters=[32, 32, 32], num_input_features=64).eval()
+    rpn.load_state_dict({k[7:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("rpn_sd_")})
+    with torch.no_grad():
+        y = rpn(torch.from_numpy(g["rpn_in"]))
+    assert np.allclose(y.numpy(), g["rpn_out"], rtol=1e-4, atol=1e-4)
