@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--variant", default="forecast_n0", choices=["forecast_n0", "forecast_n3", "forecast_n3dtf"])
+    ap.add_argument("--variant", default="forecast_n0", choices=["forecast_n0", "forecast_n3", "forecast_n3dtf", "pp_n3dtf"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--points", type=int, default=300000)
     ap.add_argument("--batch", type=int, default=1, help="clouds per rank per step")
@@ -121,8 +121,12 @@ def main():
         torch.distributed.barrier()
     lib.load()
 
-    cfg = centerpoint_config(args.variant, args.class_name, voxel_size=(args.voxel_xy, args.voxel_xy, 0.2),
-                             max_voxel_num=(min(120000, args.max_voxels), args.max_voxels))
+    if args.variant == "pp_n3dtf":  # secondary line: the PointPillars configs; no sparse conv, no roofline object
+        from futuredet_amd.configs import pointpillars_config
+        cfg = pointpillars_config(args.class_name)
+    else:
+        cfg = centerpoint_config(args.variant, args.class_name, voxel_size=(args.voxel_xy, args.voxel_xy, 0.2),
+                                 max_voxel_num=(min(120000, args.max_voxels), args.max_voxels))
     net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
     sd = seeded_state_dict(net, 7)
     net.load_state_dict(sd, strict=False)
@@ -131,6 +135,7 @@ def main():
     net.set_precision(dtype, None if args.channels_last < 0 else bool(args.channels_last))
     prof = SpconvProfiler()
     net.backbone.profile_hook = prof
+    is_pp = args.variant == "pp_n3dtf"
 
     # inputs resident in HBM before the timed region; every rank owns its own clouds (seeds by global sample id)
     host_clouds = [synthetic_cloud(seed=rank * args.batch + i, target_points=args.points) for i in range(args.batch)]
@@ -186,11 +191,21 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16",
         "data": "synthetic",
-        "config": {"workload": "%s cars, %d-pt synthetic 10-sweep cloud x%d per GPU, VoxelNet+SpMiddleResNetFHD+RPN+CenterHead, %s"
-                               % (args.variant, len(host_clouds[0]), args.batch, args.dtype),
+        "config": {"workload": "%s cars, %d-pt synthetic 10-sweep cloud x%d per GPU, %s+RPN+CenterHead, %s"
+                               % (args.variant, len(host_clouds[0]), args.batch,
+                                  "PointPillars(PillarFeatureNet+Scatter)" if is_pp else "VoxelNet+SpMiddleResNetFHD", args.dtype),
                    "parallelism": "sample-sharded x%d (no data-path collective)" % world, "detections_per_sweep": int(host_c[0].sum())},
     }
-    if rank == 0:
+    if rank == 0 and is_pp:
+        out["roofline"] = None
+        if args.stage_times:
+            st = {}
+            for (n0, e0), (n1, e1) in zip(stage_events[:-1], stage_events[1:]):
+                if n1 != "start":
+                    st[n1] = st.get(n1, 0.0) + e0.elapsed_time(e1)
+            print("[stage] GPU ms/step: " + ", ".join("%s=%.3f" % (k, v / args.steps) for k, v in st.items()), file=sys.stderr)
+        print(json.dumps(out))
+    elif rank == 0:
         # ---- roofline of the dominant kernel (sparse conv apply), from the events recorded in the timed region
         with torch.no_grad():
             ms = [(tag, info, e0.elapsed_time(e1)) for tag, info, e0, e1 in prof.records]

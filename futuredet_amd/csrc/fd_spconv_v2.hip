@@ -28,6 +28,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxTaps = 27;
 
+
 template <int CIN, int COUT, int TM, int DEPTH>
 __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restrict__ in, const float4 *__restrict__ wp,
                                                           const float *__restrict__ bias, const float *__restrict__ residual, int relu,
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
             const int u = __shfl_up(inc, off);
             if (lane >= off) inc += u;
         }
-        n_items = __shfl(inc, 63);
+        n_items = __builtin_amdgcn_readfirstlane(__shfl(inc, 63));
         for (int g = 0; g < ng; ++g) items[inc - ng + g] = (unsigned short)((lane << 3) | g);
     }
     // wave-local LDS hand-off (items written above are read below by other lanes of the same wave)
@@ -126,17 +127,33 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     // wave-uniform (scalar registers), and a list entry needs no compare/select -- the padding entry kPad has all
     // high bits set, so its byte offset lands beyond the buffer (hardware returns zeros) and its row field is the
     // scratch row TM.
-    auto fetch = [&](int it, int &kk, i32x4 &rows, u32x4(&a)[NC]) {
-        const bool v = it < n_items;  // uniform
-        const int code = __builtin_amdgcn_readfirstlane((int)items[v ? it : 0]);
+    // Bookkeeping is software pipelined so that no LDS round trip sits between two MFMA blocks of a wave (in-order
+    // issue: a dependent ds_read chain costs ~1.3k cycles per item under load, as much as the gather itself):
+    //   stage A0 (item i+DEPTH+1): read the item code          -> consumed one iteration later
+    //   stage A1 (item i+DEPTH)  : read its 16 list entries     -> consumed one iteration later
+    //   stage B  (item i+DEPTH-1): issue its gather (buffer loads; a padding entry / a slot past the end of the work list
+    //                              has an out-of-range offset: the hardware returns zeros, no branch, no exec mask)
+    //   item i                   : request the old accumulator values, run the MFMAs from a zero accumulator, then add
+    //                              and write back -- nothing waits in front of the MFMAs.  (LDS float atomics would
+    //                              drop the read altogether but ds_add_f32 measured 2-4x slower for the whole kernel.)
+    // A wave owns its accumulator elements and LDS operations of a wave execute in order, so the sums are formed in a
+    // fixed order (taps ascending): deterministic.
+    auto stage_a0 = [&](int it) -> int { return (int)items[it < n_items ? it : 0]; };
+    auto stage_a1 = [&](int it, int code_v, int &kk, int &e, i32x4 &rows) {
+        const bool v = it < n_items;  // uniform (n_items is in a scalar register)
+        const int code = __builtin_amdgcn_readfirstlane(code_v);
         const int ks = v ? (code >> 3) : 0;
         kk = v ? ks : -1;
         const int *lst = s_list + ks * TM + wr * RW + ((code & 7) << 4);
-        int e = lst[lrow];
+        e = lst[lrow];
         rows = *reinterpret_cast<const i32x4 *>(lst + lq * 4);
-        if (!v) {  // uniform
+    };
+    auto stage_b = [&](int kk, int e, const i32x4 &rows_in, i32x4 &rows, u32x4(&a)[NC]) {
+        if (kk < 0) {  // uniform: past the end of the work list
             e = kPad;
             rows = (i32x4){kPad, kPad, kPad, kPad};
+        } else {
+            rows = rows_in;
         }
         // byte offset of the input row = (e >> 8) * CIN * 4, computed on the masked entry without a multiply
         const unsigned hi = (unsigned)e & 0xffffff00u;
@@ -160,9 +177,17 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         if (tapmask) load_b(__builtin_ctzll(tapmask), bn);  // weights of the first non-empty tap
     }
     static_assert(DEPTH >= 2, "the slot freed by the previous item is refilled during the current item's MFMAs");
+    int k_s, e_s, code_s;
+    i32x4 rows_s;
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d) fetch(d, k_r[d], rows_r[d], a_r[d]);
+    for (int d = 0; d < DEPTH - 1; ++d) {
+        stage_a1(d, stage_a0(d), k_s, e_s, rows_s);
+        stage_b(k_s, e_s, rows_s, rows_r[d], a_r[d]);
+        k_r[d] = k_s;
+    }
     k_r[DEPTH - 1] = -1;
+    stage_a1(DEPTH - 1, stage_a0(DEPTH - 1), k_s, e_s, rows_s);  // staged for the first loop iteration
+    code_s = stage_a0(DEPTH);
 
     for (int i0 = 0; i0 < n_items; i0 += DEPTH) {
 #pragma unroll
@@ -184,20 +209,28 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
             int aoff[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) aoff[r] = (rows_r[d][r] & 255) * COUT + cb + lrow;
-            f32x4 acc[NACC];
+            // the old accumulator values are requested now and first touched after the MFMAs (which start from zero):
+            // their LDS latency hides under the matrix work instead of sitting in front of it
+            float cold[NBW][4];
 #pragma unroll
             for (int nw = 0; nw < NBW; ++nw)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[nw][r] = s_acc[aoff[r] + nw * 16];
-            if constexpr (NBW == 1) acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // refill the slot freed by the previous item BEFORE this item's MFMAs.  Left to itself hipcc sinks these
-            // loads below the MFMA block and then waits vmcnt(0) for them at the top of the next item, exposing the whole
-            // gather latency on every item; the scheduling barrier pins them here so they fly under 2048 MFMA cycles.
+                for (int r = 0; r < 4; ++r) cold[nw][r] = s_acc[aoff[r] + nw * 16];
+            // refill the slot freed by the previous item BEFORE this item's MFMAs (left to itself hipcc sinks the loads
+            // below the MFMA block and waits vmcnt(0) for them at the top of the next item), then advance the two
+            // bookkeeping stages; their results are first touched in the next iteration.
             {
                 const int dn = (d + DEPTH - 1) % DEPTH;  // compile-time after unrolling
-                fetch(i0 + d + DEPTH - 1, k_r[dn], rows_r[dn], a_r[dn]);
+                const int it = i0 + d + DEPTH - 1;
+                stage_b(k_s, e_s, rows_s, rows_r[dn], a_r[dn]);
+                k_r[dn] = k_s;
+                stage_a1(it + 1, code_s, k_s, e_s, rows_s);
+                code_s = stage_a0(it + 2);
             }
             __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[NACC];
+#pragma unroll
+            for (int n = 0; n < NACC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const float4 av = __builtin_bit_cast(float4, a_r[d][c]);
@@ -220,12 +253,12 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
             }
             if constexpr (NBW == 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s_acc[aoff[r]] = acc[0][r] + acc[1][r];
+                for (int r = 0; r < 4; ++r) s_acc[aoff[r]] = cold[0][r] + (acc[0][r] + acc[1][r]);
             } else {
 #pragma unroll
                 for (int nw = 0; nw < NBW; ++nw)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s_acc[aoff[r] + nw * 16] = acc[nw][r];
+                    for (int r = 0; r < 4; ++r) s_acc[aoff[r] + nw * 16] = cold[nw][r] + acc[nw][r];
             }
             __builtin_amdgcn_sched_barrier(0);
         }
