@@ -168,14 +168,12 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 #pragma unroll
             for (int nw = 0; nw < NBW; ++nw) dst[c][nw] = wk[(c * NB + nw) * 64];
     };
-    // small weight slices are double buffered a whole tap ahead; the 128x128 slice (64 VGPRs) is loaded at the tap
-    // switch instead, which keeps the kernel at two waves per SIMD (the LDS tile allows two workgroups per CU)
-    constexpr bool BPF = NC * NBW <= 8;
-    float4 b[NC][NBW], bn[BPF ? NC : 1][BPF ? NBW : 1];
-    int kcur = -1;
-    if constexpr (BPF) {
-        if (tapmask) load_b(__builtin_ctzll(tapmask), bn);  // weights of the first non-empty tap
-    }
+    // One weight slice in registers.  It is replaced IN PLACE during the last item of a tap: as soon as the MFMAs of a
+    // 16-channel chunk have consumed b[c], the same registers are reloaded with the next tap's chunk, so the weights
+    // of the next tap arrive under the matrix work of the current one without a second buffer.  (A double buffer
+    // swapped at the tap switch costs hipcc a full register copy plus an s_waitcnt vmcnt(0) per switch -- the loop-
+    // carried swap cannot be allocated copy-free -- which also drained the gather prefetch ring one item in five.)
+    float4 b[NC][NBW];
     static_assert(DEPTH >= 2, "the slot freed by the previous item is refilled during the current item's MFMAs");
     int k_s, e_s, code_s;
     i32x4 rows_s;
@@ -188,23 +186,31 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     k_r[DEPTH - 1] = -1;
     stage_a1(DEPTH - 1, stage_a0(DEPTH - 1), k_s, e_s, rows_s);  // staged for the first loop iteration
     code_s = stage_a0(DEPTH);
+    if (n_items > 0) load_b(k_r[0], b);  // weights of the first tap (the only exposed weight latency of the tile)
+
+    auto mfma_chunk = [&](const u32x4 &a4, const float4(&bc)[NBW], f32x4(&acc)[NACC]) {
+        const float4 av = __builtin_bit_cast(float4, a4);
+        if constexpr (NBW == 1) {
+            // one column block: alternate two accumulators so consecutive MFMAs are independent
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bc[0].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bc[0].y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bc[0].z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bc[0].w, acc[1], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bc[nw].x, acc[nw], 0, 0, 0);
+#pragma unroll
+            for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bc[nw].y, acc[nw], 0, 0, 0);
+#pragma unroll
+            for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bc[nw].z, acc[nw], 0, 0, 0);
+#pragma unroll
+            for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bc[nw].w, acc[nw], 0, 0, 0);
+        }
+    };
 
     for (int i0 = 0; i0 < n_items; i0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            if (k_r[d] >= 0 && k_r[d] != kcur) {  // wave-uniform tap switch (about one item in five)
-                kcur = k_r[d];
-                if constexpr (BPF) {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-#pragma unroll
-                        for (int nw = 0; nw < NBW; ++nw) b[c][nw] = bn[c][nw];
-                    const unsigned long long rest = (kcur + 1 < 64) ? (tapmask >> (kcur + 1)) : 0ull;
-                    if (rest) load_b(kcur + 1 + __builtin_ctzll(rest), bn);  // next tap's weights, a whole tap ahead
-                } else {
-                    load_b(kcur, b);
-                }
-            }
             // accumulator rows: the row field of a padding entry is the scratch row TM
             int aoff[4];
 #pragma unroll
@@ -227,29 +233,23 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
                 stage_a1(it + 1, code_s, k_s, e_s, rows_s);
                 code_s = stage_a0(it + 2);
             }
+            const int knext = k_r[(d + 1) % DEPTH];                 // tap of the next item (-1 past the end), wave-uniform
+            const bool reload = knext >= 0 && knext != k_r[d];      // this is the last item of its tap
             __builtin_amdgcn_sched_barrier(0);
             f32x4 acc[NACC];
 #pragma unroll
             for (int n = 0; n < NACC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (reload) {
+                const float4 *wk = wp + ((int64_t)knext * NC * NB + wc * NBW) * 64 + lane;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const float4 av = __builtin_bit_cast(float4, a_r[d][c]);
-                if constexpr (NBW == 1) {
-                    // one column block: alternate two accumulators so consecutive MFMAs are independent
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b[c][0].x, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b[c][0].y, acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b[c][0].z, acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b[c][0].w, acc[1], 0, 0, 0);
-                } else {
+                for (int c = 0; c < NC; ++c) {
+                    mfma_chunk(a_r[d][c], b[c], acc);
 #pragma unroll
-                    for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b[c][nw].x, acc[nw], 0, 0, 0);
-#pragma unroll
-                    for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b[c][nw].y, acc[nw], 0, 0, 0);
-#pragma unroll
-                    for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b[c][nw].z, acc[nw], 0, 0, 0);
-#pragma unroll
-                    for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b[c][nw].w, acc[nw], 0, 0, 0);
+                    for (int nw = 0; nw < NBW; ++nw) b[c][nw] = wk[(c * NB + nw) * 64];
                 }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) mfma_chunk(a_r[d][c], b[c], acc);
             }
             if constexpr (NBW == 1) {
 #pragma unroll
