@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     constexpr int NBW = NB / WC;          // 16-column blocks per wave
     constexpr int WR = 4 / WC;            // row splits
     constexpr int RW = TM / WR;           // rows in a wave's row set
-    constexpr int NACC = NBW == 1 ? 2 : NBW;  // independent MFMA chains (a single column block splits its K chain in two)
+    constexpr int NACC = NBW;  // one accumulator chain per column block (dependent 16x16x4 MFMAs issue back to back at full rate)
     static_assert((TM == 128 || TM == 64) && RW >= 16, "local row uses 8 bits (0..TM, TM = scratch row)");
     constexpr int kMaxItems = kMaxTaps * (TM / 16);           // per wave: taps x 16-row groups
     constexpr int kPad = (int)(0xffffff00u | (unsigned)TM);  // list padding: input offset out of range, local row = TM (scratch row)
@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     int *s_list = reinterpret_cast<int *>(smem);                                            // [K][TM] raw nbr, then compacted entries
     unsigned short *s_items = reinterpret_cast<unsigned short *>(s_list + kMaxTaps * TM);   // [4 waves][kMaxItems]
     unsigned char *s_cnt = reinterpret_cast<unsigned char *>(s_items + 4 * kMaxItems);      // [K][4] (<= 128 each)
-    float *s_acc = reinterpret_cast<float *>(s_cnt + 112);                                  // [TM + 1][COUT], 16-byte aligned for TM = 64 and 128
+    int *s_pad = reinterpret_cast<int *>(s_cnt + 112);                                      // 16 padding entries (tail of the work list)
+    float *s_acc = reinterpret_cast<float *>(s_pad + 16);                                   // [TM + 1][COUT], 16-byte aligned for TM = 64 and 128
 
     // tiles differ in work by up to 2x (dense regions near the sensor): the optional order puts heavy tiles first and
     // pairs them with light ones on a CU (fd_spconv_tile_order); without it tiles run in index order.
@@ -60,6 +61,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         s_list[t] = (o < nbr_stride) ? nbr[(int64_t)k * nbr_stride + o] : -1;
     }
     for (int t = tid; t < (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 16) s_pad[tid] = kPad;
     __syncthreads();
     // ---- in-place compaction: wave w takes taps w, w+4, ...; tails are filled with kPad
     for (int k = wave; k < K; k += 4) {
@@ -94,6 +96,10 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     const int lrow = lane & 15, lq = lane >> 4;
     const int wc = wave % WC, wr = wave / WC;
     const int cb = wc * NBW * 16;
+    constexpr int kRowShift = COUT == 16 ? 6 : COUT == 32 ? 7 : COUT == 64 ? 8 : 9;  // log2(COUT * 4)
+    static_assert((COUT * 4) == (1 << kRowShift), "COUT must be 16, 32, 64 or 128");
+    unsigned char *acc_bytes = reinterpret_cast<unsigned char *>(s_acc);
+    const unsigned lane_off = (unsigned)(cb + lrow) * 4u;
     // ---- flattened work list of this wave: one item = 16 compacted pairs of one tap, code = (tap << 3) | group
     unsigned short *items = s_items + wave * kMaxItems;
     int n_items;
@@ -144,17 +150,13 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         const int code = __builtin_amdgcn_readfirstlane(code_v);
         const int ks = v ? (code >> 3) : 0;
         kk = v ? ks : -1;
-        const int *lst = s_list + ks * TM + wr * RW + ((code & 7) << 4);
+        // past the end of the work list the (scalar) list pointer selects a block of 16 padding entries: no per-lane select
+        const int *lst = v ? s_list + ks * TM + wr * RW + ((code & 7) << 4) : s_pad;
         e = lst[lrow];
         rows = *reinterpret_cast<const i32x4 *>(lst + lq * 4);
     };
     auto stage_b = [&](int kk, int e, const i32x4 &rows_in, i32x4 &rows, u32x4(&a)[NC]) {
-        if (kk < 0) {  // uniform: past the end of the work list
-            e = kPad;
-            rows = (i32x4){kPad, kPad, kPad, kPad};
-        } else {
-            rows = rows_in;
-        }
+        rows = rows_in;
         // byte offset of the input row = (e >> 8) * CIN * 4, computed on the masked entry without a multiply
         const unsigned hi = (unsigned)e & 0xffffff00u;
         const unsigned voff = (CIN >= 64 ? hi << (CIN == 128 ? 1 : 0) : hi >> (CIN == 32 ? 1 : 2)) + (unsigned)(lq * 16);
@@ -190,38 +192,33 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 
     auto mfma_chunk = [&](const u32x4 &a4, const float4(&bc)[NBW], f32x4(&acc)[NACC]) {
         const float4 av = __builtin_bit_cast(float4, a4);
-        if constexpr (NBW == 1) {
-            // one column block: alternate two accumulators so consecutive MFMAs are independent
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bc[0].x, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bc[0].y, acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bc[0].z, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bc[0].w, acc[1], 0, 0, 0);
-        } else {
 #pragma unroll
-            for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bc[nw].x, acc[nw], 0, 0, 0);
+        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bc[nw].x, acc[nw], 0, 0, 0);
 #pragma unroll
-            for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bc[nw].y, acc[nw], 0, 0, 0);
+        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bc[nw].y, acc[nw], 0, 0, 0);
 #pragma unroll
-            for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bc[nw].z, acc[nw], 0, 0, 0);
+        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bc[nw].z, acc[nw], 0, 0, 0);
 #pragma unroll
-            for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bc[nw].w, acc[nw], 0, 0, 0);
-        }
+        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bc[nw].w, acc[nw], 0, 0, 0);
     };
 
     for (int i0 = 0; i0 < n_items; i0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             // accumulator rows: the row field of a padding entry is the scratch row TM
-            int aoff[4];
+            // (byte offsets: one AND and one shift-add per row; the lane's column offset is loop invariant)
+            unsigned aoff[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) aoff[r] = (rows_r[d][r] & 255) * COUT + cb + lrow;
-            // the old accumulator values are requested now and first touched after the MFMAs (which start from zero):
-            // their LDS latency hides under the matrix work instead of sitting in front of it
-            float cold[NBW][4];
+            for (int r = 0; r < 4; ++r) aoff[r] = (((unsigned)rows_r[d][r] & 255u) << kRowShift) + lane_off;
+            // The old accumulator values are requested first and are the C operand of the MFMA chain: the matrix pipe
+            // does the accumulation and D goes back to LDS untouched -- no vector-ALU work on the accumulators at all
+            // (VALU instructions of one wave barely overlap the MFMAs of the other waves of its SIMD, so every VALU
+            // instruction saved per item is matrix-pipe time gained).  The bookkeeping below covers the LDS latency.
+            f32x4 acc[NACC];
 #pragma unroll
             for (int nw = 0; nw < NBW; ++nw)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cold[nw][r] = s_acc[aoff[r] + nw * 16];
+                for (int r = 0; r < 4; ++r) acc[nw][r] = *reinterpret_cast<const float *>(acc_bytes + aoff[r] + nw * 64);
             // refill the slot freed by the previous item BEFORE this item's MFMAs (left to itself hipcc sinks the loads
             // below the MFMA block and waits vmcnt(0) for them at the top of the next item), then advance the two
             // bookkeeping stages; their results are first touched in the next iteration.
@@ -236,9 +233,6 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
             const int knext = k_r[(d + 1) % DEPTH];                 // tap of the next item (-1 past the end), wave-uniform
             const bool reload = knext >= 0 && knext != k_r[d];      // this is the last item of its tap
             __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc[NACC];
-#pragma unroll
-            for (int n = 0; n < NACC; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (reload) {
                 const float4 *wk = wp + ((int64_t)knext * NC * NB + wc * NBW) * 64 + lane;
 #pragma unroll
@@ -251,15 +245,10 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 #pragma unroll
                 for (int c = 0; c < NC; ++c) mfma_chunk(a_r[d][c], b[c], acc);
             }
-            if constexpr (NBW == 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s_acc[aoff[r]] = cold[0][r] + (acc[0][r] + acc[1][r]);
-            } else {
+            for (int nw = 0; nw < NBW; ++nw)
 #pragma unroll
-                for (int nw = 0; nw < NBW; ++nw)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s_acc[aoff[r] + nw * 16] = cold[nw][r] + acc[nw][r];
-            }
+                for (int r = 0; r < 4; ++r) *reinterpret_cast<float *>(acc_bytes + aoff[r] + nw * 64) = acc[nw][r];
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -287,7 +276,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 template <int CIN, int COUT, int TM, int DEPTH>
 int launch_compact(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
                    int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, const int *tile_order, hipStream_t stream) {
-    const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxTaps * (TM / 16) + 112 + sizeof(float) * (TM + 1) * COUT;
+    const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxTaps * (TM / 16) + 112 + 64 + sizeof(float) * (TM + 1) * COUT;
     static bool attr_set = false;
     auto kern = spconv_f32_compact<CIN, COUT, TM, DEPTH>;
     if (!attr_set) {
