@@ -99,11 +99,8 @@ class SepHead(nn.Module):
             x = conv(x)
         if self.forecast_feature:
             ret["feats"] = x
-        if x.is_cuda and FoldedConv.fuse_relu and x.is_contiguous():
-            y = torch.miopen_convolution_relu(x, w1, b1, [1, 1], [p1, p1], [1, 1], 1)
-        else:
-            y = torch.nn.functional.relu_(torch.nn.functional.conv2d(x, w1, b1, padding=p1))
-        z = torch.nn.functional.conv2d(y, w2, b2, padding=p2)
+        y = FoldedConv(w1, b1, 1, p1, True)(x)
+        z = FoldedConv(w2, b2, 1, p2, False)(y)
         o = 0
         for name, c in zip(names, couts):
             ret[name] = z[:, o:o + c]

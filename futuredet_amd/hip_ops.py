@@ -405,3 +405,10 @@ def pillar_scatter(feats, coors4, n_dev, batch_size, ny, nx, out_dtype=None, cha
     check(L.fd_pillar_scatter(_p(feats), C, feats.stride(0), _DT[feats.dtype], _p(coors4), _p(n_dev), M, batch_size, ny, nx,
                               _p(out), _DT[out.dtype], sb, sc, sy, sx, int(bool(zero_first)), _stream()), "fd_pillar_scatter")
     return out
+
+
+def bias_act_nchw_(x, bias, relu):
+    """In-place per-channel bias (+ReLU) on a contiguous NCHW float32 device tensor (fd_bias_act_nchw_f32)."""
+    B, C, H, W = x.shape
+    check(_lib.load().fd_bias_act_nchw_f32(_p(x), _p(bias), B, C, H * W, int(bool(relu)), _stream()), "fd_bias_act_nchw_f32")
+    return x

@@ -79,14 +79,23 @@ class FoldedConv(object):
         self.weight, self.bias, self.stride, self.padding, self.relu, self.transposed = \
             weight, bias, stride, padding, relu, transposed
 
-    fuse_relu = True  # MIOpen's fused conv+bias+ReLU (one kernel instead of conv + elementwise pass over the map)
+    fuse_relu = True  # one in-place bias(+ReLU) pass after the convolution instead of PyTorch's broadcast add + clamp
 
     def __call__(self, x):
+        if (FoldedConv.fuse_relu and x.is_cuda and x.dtype == torch.float32 and self.bias is not None and x.is_contiguous()):
+            # fp32 NCHW on the GPU: MIOpen's Winograd / GEMM kernels have no epilogue (torch.miopen_convolution_relu runs
+            # conv + add + clamp as three kernels here), so the folded-BN shift and the ReLU are one HIP pass in place
+            if self.transposed:
+                y = F.conv_transpose2d(x, self.weight, None, stride=self.stride, padding=self.padding)
+            else:
+                y = F.conv2d(x, self.weight, None, stride=self.stride, padding=self.padding)
+            if y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0:
+                from . import hip_ops
+                return hip_ops.bias_act_nchw_(y, self.bias, self.relu)
+            y = y + self.bias.view(1, -1, 1, 1)
+            return F.relu_(y) if self.relu else y
         if self.transposed:
             y = F.conv_transpose2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
-        elif self.relu and x.is_cuda and FoldedConv.fuse_relu and self.bias is not None and x.is_contiguous():
-            # (NCHW only: on channels-last inputs this MIOpen entry falls back to a naive kernel, 200x slower)
-            return torch.miopen_convolution_relu(x, self.weight, self.bias, [self.stride] * 2, [self.padding] * 2, [1, 1], 1)
         else:
             y = F.conv2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
         return F.relu_(y) if self.relu else y

@@ -224,6 +224,11 @@ int fd_pillar_scatter(const void *feats, int c, int feat_stride, int dtype, cons
                       int64_t m_max, int B, int H, int W, void *out, int out_dtype, int64_t stride_b, int64_t stride_c,
                       int64_t stride_y, int64_t stride_x, int zero_first, fd_stream_t stream);
 
+/* In-place per-channel bias (+ReLU when relu != 0) on a contiguous NCHW float32 map with H*W % 4 == 0: the folded
+ * BatchNorm shift + activation after each RPN / head convolution (det3d/models/necks/rpn.py:124-142,
+ * det3d/models/bbox_heads/center_head.py:129-143) when the convolution itself runs in MIOpen without an epilogue. */
+int fd_bias_act_nchw_f32(float *x, const float *bias, int B, int C, int64_t hw, int relu, fd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
