@@ -293,20 +293,24 @@ int launch_compact(const float *in, const void *wp, const float *bias, const flo
 
 // ---------------------------------------------------------------------------------------------- tile order
 // work of a 128-row tile = number of 16-pair MFMA groups = sum over taps of ceil(valid rows / 16)
-__global__ void __launch_bounds__(128) tile_work_kernel(const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_tiles, unsigned *__restrict__ keys) {
-    const int tile = blockIdx.x, r = threadIdx.x;
-    __shared__ int s_half[2];
+__global__ void __launch_bounds__(256) tile_work_kernel(const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_tiles, unsigned *__restrict__ keys) {
+    // one workgroup per tile; wave w counts taps w, w+4, ... with two 64-row ballots each (no barrier per tap)
+    const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int s_work[4];
     int work = 0;
-    for (int k = 0; k < K; ++k) {
-        const int64_t o = (int64_t)tile * 128 + r;
-        const bool v = o < nbr_stride && nbr[(int64_t)k * nbr_stride + o] >= 0;
-        const int c = __popcll(__ballot(v));
-        if ((r & 63) == 0) s_half[r >> 6] = c;
-        __syncthreads();
-        work += (s_half[0] + s_half[1] + 15) >> 4;
-        __syncthreads();
+    const int64_t o0 = (int64_t)tile * 128 + lane, o1 = o0 + 64;
+    for (int k = wave; k < K; k += 4) {
+        const int *row = nbr + (int64_t)k * nbr_stride;
+        const bool v0 = o0 < nbr_stride && row[o0] >= 0;
+        const bool v1 = o1 < nbr_stride && row[o1] >= 0;
+        work += (__popcll(__ballot(v0)) + __popcll(__ballot(v1)) + 15) >> 4;
     }
-    if (r == 0) keys[tile] = ((unsigned)work << 20) | (0xfffffu - (unsigned)tile);  // sort key: work desc, tile asc
+    if (lane == 0) s_work[wave] = work;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        work = s_work[0] + s_work[1] + s_work[2] + s_work[3];
+        keys[tile] = ((unsigned)work << 20) | (0xfffffu - (unsigned)tile);  // sort key: work desc, tile asc
+    }
 }
 
 // single workgroup: counting sort by work (at most 27 * 8 = 216 distinct values), heaviest first, then the CU
@@ -356,7 +360,7 @@ extern "C" int fd_spconv_tile_order(const int32_t *nbr, int64_t nbr_stride, int 
     }
     unsigned *keys = (unsigned *)workspace;
     int *sorted = (int *)(keys + n_tiles);
-    hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)n_tiles), dim3(128), 0, stream, nbr, nbr_stride, K, (int)n_tiles, keys);
+    hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)n_tiles), dim3(256), 0, stream, nbr, nbr_stride, K, (int)n_tiles, keys);
     hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(1024), 0, stream, keys, (int)n_tiles, n_cu, sorted, order);
     return fd::check_launch("fd_spconv_tile_order");
 }

@@ -608,3 +608,27 @@ def test_pointpillars_end_to_end_vs_oracle(hip):
             gt = torch.cat([res[b]["box3d_lidar"], res[b]["scores"][:, None], res[b]["label_preds"][:, None].float()], 1).cpu().numpy()
             bad = _match_detections(gt, w)
             assert bad <= max(2, 0.02 * (len(gt) + len(w))), (b, bad, len(gt), len(w))
+
+
+def test_spconv_tile_order_is_a_work_sorted_permutation(hip):
+    """fd_spconv_tile_order only steers scheduling; it must be a permutation of the 128-row tiles that starts with the
+    heaviest one (work = sum over taps of ceil(valid rows / 16))."""
+    rng = np.random.default_rng(5)
+    K, n_out = 27, 128 * 37 + 50
+    stride = (n_out + 63) // 64 * 64
+    nbr = np.full((K, stride), -1, np.int32)
+    dens = rng.uniform(0.05, 0.9, (n_out + 127) // 128)
+    for t, d in enumerate(dens):
+        lo, hi = t * 128, min(n_out, t * 128 + 128)
+        m = rng.uniform(size=(K, hi - lo)) < d
+        nbr[:, lo:hi] = np.where(m, rng.integers(0, 1000, (K, hi - lo)), -1)
+    t = _dev(nbr)
+    t.n_out = n_out
+    order = hip.tile_order_for(t).cpu().numpy()
+    n_tiles = (n_out + 127) // 128
+    assert sorted(order.tolist()) == list(range(n_tiles))
+    pad = np.full((K, n_tiles * 128), -1, np.int32)
+    pad[:, :stride] = nbr
+    work = ((pad.reshape(K, n_tiles, 128) >= 0).sum(-1) + 15) // 16
+    work = work.sum(0)
+    assert work[order[0]] == work.max()
