@@ -64,6 +64,8 @@ SIGNATURES = {
     "fd_pillar_scatter": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_int,
                                   c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "fd_bias_act_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_i64, c_int, c_void_p]),
+    "fd_forecast_chains": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_sweep_assemble_workspace_bytes": (c_size_t, [c_i64]),
     "fd_sweep_assemble": (c_int, [c_void_p, c_int, c_int, c_i64, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

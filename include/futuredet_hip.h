@@ -229,6 +229,21 @@ int fd_pillar_scatter(const void *feats, int c, int feat_stride, int dtype, cons
  * det3d/models/bbox_heads/center_head.py:129-143) when the convolution itself runs in MIOpen without an epilogue. */
 int fd_bias_act_nchw_f32(float *x, const float *bias, int B, int C, int64_t hw, int relu, fd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Forecast association: the numeric core of `tracker` (det3d/datasets/nuscenes/nuscenes.py:125-257), `match_boxes`
+ * (:112-123) and `distance_matrix` (:100-110) for one sweep: T forecast steps with counts[t] <= n_max boxes each.
+ *   centers, velocity [T, n_max, 3] float64 (Box.center / Box.velocity);  time_dev [T-1] float64 (seconds between steps)
+ *   fwd_idx [n_max, T], fwd_ok [n_max] : forward chain of step-0 box i (index per step) and "not void" flag
+ *                                        (every hop <= reject_thresh, :160-173)
+ *   bwd_idx [n_max, T], bwd_ok [n_max] : back-cast chain of last-step box i, hop s goes from step T-1-s to T-2-s (:222-237)
+ *   match_idx [T, n_max]               : match_boxes: nearest step-t box to step-0 box i
+ *   cv_centers [n_max, T, 3]           : constant-velocity forward trajectory of step-0 box i (:183-193)
+ *   status int32[1]                    : 1 when some step has no box (the reference then returns no trajectory)
+ * ------------------------------------------------------------------------------------------------- */
+int fd_forecast_chains(const double *centers, const double *velocity, const int32_t *counts, const double *time_dev, int T,
+                       int n_max, double reject_thresh, int32_t *fwd_idx, int32_t *fwd_ok, int32_t *bwd_idx, int32_t *bwd_ok,
+                       int32_t *match_idx, double *cv_centers, int32_t *status, fd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

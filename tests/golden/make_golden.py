@@ -445,10 +445,59 @@ def gen_pillars():
     save("pillars.npz", **out)
 
 
+def gen_forecast():
+    """The reference's tracker / match_boxes (det3d/datasets/nuscenes/nuscenes.py:112-257) on seeded detections.  The
+    module's third-party imports (nuScenes devkit, shapely, pyquaternion, networkx) get inert shims; the boxes are plain
+    attribute holders (.center, .velocity, .tag) standing in for the devkit Box the functions only read those from."""
+    import importlib
+    mod = lambda name, **a: sys.modules.setdefault(name, type(sys)(name)).__dict__.update(a)
+    mod("nuscenes"), mod("nuscenes.utils"), mod("nuscenes.utils.geometry_utils", view_points=None)
+    mod("shapely"), mod("shapely.geometry", Polygon=object), mod("pyquaternion", Quaternion=object), mod("networkx")
+    mod("tqdm", tqdm=lambda x, **k: x)
+    if "det3d.datasets" not in sys.modules:
+        m = types.ModuleType("det3d.datasets")
+        m.__path__ = [os.path.join(REF, "det3d", "datasets")]
+        sys.modules["det3d.datasets"] = m
+    nm = importlib.import_module("det3d.datasets.nuscenes.nuscenes")
+
+    class B(object):
+        def __init__(self, c, v, tag):
+            self.center, self.velocity, self.tag = np.array(c, np.float64), np.array(v, np.float64), tag
+
+    out = {}
+    rng = np.random.default_rng(41)
+    T = 7
+    for case, (n0, jitter, cls) in {"car": (40, 0.6, "car"), "ped": (25, 0.5, "pedestrian"), "sparse": (6, 3.0, "car"),
+                                     "empty": (5, 0.5, "car")}.items():
+        time = list(0.5 + rng.uniform(-0.02, 0.02, T - 1))
+        base = rng.uniform(-40, 40, (n0, 3)) * [1, 1, 0.02]
+        vel = rng.normal(0, 3.0, (n0, 3)) * [1, 1, 0]
+        ret_boxes = []
+        for t in range(T):
+            n_t = n0 + int(rng.integers(-3, 4)) if case != "empty" or t != 3 else 0
+            sel = rng.permutation(n0)[:max(0, min(n0, n_t))]
+            extra = max(0, n_t - len(sel))
+            c = np.concatenate([base[sel] + vel[sel] * (0.5 * t) + rng.normal(0, jitter, (len(sel), 3)) * [1, 1, 0],
+                                rng.uniform(-40, 40, (extra, 3)) * [1, 1, 0.02]])
+            v = np.concatenate([vel[sel] + rng.normal(0, 0.3, (len(sel), 3)) * [1, 1, 0], rng.normal(0, 3.0, (extra, 3)) * [1, 1, 0]])
+            c, v = c.astype(np.float32).astype(np.float64), v.astype(np.float32).astype(np.float64)  # head outputs are float32
+            ret_boxes.append([B(c[j], v[j], (t, j)) for j in range(len(c))])
+            out["%s_centers_%d" % (case, t)], out["%s_velocity_%d" % (case, t)] = c.reshape(-1, 3), v.reshape(-1, 3)
+        out[case + "_time"] = np.asarray(time)
+        traj = nm.tracker(cls, time, ret_boxes)
+        out[case + "_traj_tags"] = np.asarray([[b.tag[1] for b in tr] for tr in traj], np.int64).reshape(-1, T)
+        out[case + "_traj_centers"] = np.asarray([[b.center for b in tr] for tr in traj], np.float64).reshape(-1, T, 3)
+        if len(ret_boxes[0]) and all(len(b) for b in ret_boxes):
+            mb = nm.match_boxes(ret_boxes)
+            out[case + "_match_tags"] = np.asarray([[b.tag[1] for b in row] for row in mb], np.int64)
+        print("forecast", case, "trajectories", len(traj))
+    save("forecast.npz", **out)
+
+
 if __name__ == "__main__":
     install_shims()
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["voxelizer", "configs", "dense", "predict", "iou", "backbone", "sweeps", "pillars"]
+    which = sys.argv[1:] or ["voxelizer", "configs", "dense", "predict", "iou", "backbone", "sweeps", "pillars", "forecast"]
     for w in which:
         {"voxelizer": gen_voxelizer, "configs": gen_configs, "dense": gen_dense_nets, "predict": gen_predict,
-         "iou": gen_iou, "backbone": gen_backbone, "sweeps": gen_sweeps, "pillars": gen_pillars}[w]()
+         "iou": gen_iou, "backbone": gen_backbone, "sweeps": gen_sweeps, "pillars": gen_pillars, "forecast": gen_forecast}[w]()

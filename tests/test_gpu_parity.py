@@ -632,3 +632,30 @@ def test_spconv_tile_order_is_a_work_sorted_permutation(hip):
     work = ((pad.reshape(K, n_tiles, 128) >= 0).sum(-1) + 15) // 16
     work = work.sum(0)
     assert work[order[0]] == work.max()
+
+
+# ------------------------------------------------------------------------------------------------ forecast association
+class _Box(object):
+    def __init__(self, c, v, tag):
+        self.center, self.velocity, self.tag = np.array(c, np.float64), np.array(v, np.float64), tag
+
+
+@pytest.mark.parametrize("case,cls", [("car", "car"), ("ped", "pedestrian"), ("sparse", "car"), ("empty", "car")])
+def test_forecast_tracker_matches_reference_golden(hip, golden, case, cls):
+    """futuredet_amd.forecast.tracker / match_boxes (fd_forecast_chains) vs the reference's own functions: identical
+    trajectory membership and order, identical float64 centres."""
+    from futuredet_amd import forecast
+
+    g = golden("forecast.npz")
+    T = 7
+    ret_boxes = [[_Box(c, v, (t, j)) for j, (c, v) in enumerate(zip(g["%s_centers_%d" % (case, t)], g["%s_velocity_%d" % (case, t)]))]
+                 for t in range(T)]
+    traj = forecast.tracker(cls, list(g[case + "_time"]), ret_boxes)
+    tags = np.asarray([[b.tag[1] for b in tr] for tr in traj], np.int64).reshape(-1, T)
+    cents = np.asarray([[b.center for b in tr] for tr in traj], np.float64).reshape(-1, T, 3)
+    assert np.array_equal(tags, g[case + "_traj_tags"])
+    assert np.array_equal(cents, g[case + "_traj_centers"])
+    if case + "_match_tags" in g:
+        mb = forecast.match_boxes(ret_boxes)
+        assert np.array_equal(np.asarray([[b.tag[1] for b in row] for row in mb], np.int64), g[case + "_match_tags"])
+    assert forecast.tracker("truck", list(g[case + "_time"]), ret_boxes) == []

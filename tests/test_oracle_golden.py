@@ -230,3 +230,36 @@ def test_oracle_pp_rpn_matches_reference_golden(golden):
     with torch.no_grad():
         y = rpn(torch.from_numpy(g["rpn_in"]))
     assert np.allclose(y.numpy(), g["rpn_out"], rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ forecast association
+FORECAST_CASES = [("car", "car"), ("ped", "pedestrian"), ("sparse", "car"), ("empty", "car")]
+
+
+def _forecast_case(g, case):
+    T = 7
+    centers = [g["%s_centers_%d" % (case, t)] for t in range(T)]
+    velocity = [g["%s_velocity_%d" % (case, t)] for t in range(T)]
+    return centers, velocity, g[case + "_time"]
+
+
+@pytest.mark.parametrize("case,cls", FORECAST_CASES)
+def test_oracle_forecast_tracker_matches_reference_golden(golden, case, cls):
+    """Trajectory index lists and centres identical to the reference's tracker (nuscenes.py:125-257) output."""
+    from oracle import forecast as ofc
+
+    g = golden("forecast.npz")
+    centers, velocity, time = _forecast_case(g, case)
+    res = ofc.tracker(cls, time, centers, velocity)
+    want_tags, want_centers = g[case + "_traj_tags"], g[case + "_traj_centers"]
+    if res is None:
+        assert len(want_tags) == 0
+        return
+    fwd, cv, bwd = res
+    tags = fwd + [[i] * 7 for i in range(len(centers[0]))] + bwd
+    assert np.array_equal(np.asarray(tags, np.int64).reshape(-1, 7), want_tags)
+    got_centers = [[centers[t][j] for t, j in enumerate(ch)] for ch in fwd] + [list(cv[i]) for i in range(len(cv))] + \
+                  [[centers[t][j] for t, j in enumerate(ch)] for ch in bwd]
+    assert np.array_equal(np.asarray(got_centers, np.float64).reshape(-1, 7, 3), want_centers)
+    if case + "_match_tags" in g:
+        assert np.array_equal(np.asarray(ofc.match_indices(centers)), g[case + "_match_tags"])
