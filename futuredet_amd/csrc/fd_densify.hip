@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(256) densify_kernel(const void *__restrict__ f
 extern "C" int fd_densify(const void *feats, int c, int dtype, const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W,
                           void *out, int out_dtype, int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x,
                           fd_stream_t stream) {
-    FD_REQUIRE(feats && words && prefix && out, "fd_densify: null argument");
+    FD_REQUIRE(words && prefix && out, "fd_densify: null argument");  // feats may be null when no cell is active
     FD_REQUIRE(c > 0 && D > 0 && D <= 64, "fd_densify: bad shape");
     fd::IndexGeom g = fd::make_geom(B, D, H, W);
     int64_t total = g.num_cols() * c * D;

@@ -163,7 +163,7 @@ class VoxelNet(SingleStageDetector):
         mark_stage("index")
         feats0 = torch.zeros((max(idx[0].n, 1), cpad), dtype=bb.compute_dtype, device=dev)[: idx[0].n]
         L = hip_ops._lib.load()
-        for b in range(B):
+        for b in range(B if idx[0].n > 0 else 0):  # (nothing to place when every cloud of the batch is empty)
             sl = slice(b * max_voxels, (b + 1) * max_voxels)
             row_of = idx[0].lookup(coors[sl], n_dev=nvox[b:b + 1])
             hip_ops.check(L.fd_rows_permute(hip_ops._p(mean[sl]), cpad, hip_ops._p(row_of), hip_ops._p(nvox[b:b + 1]), max_voxels,
