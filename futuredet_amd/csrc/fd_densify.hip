@@ -39,6 +39,46 @@ __global__ void __launch_bounds__(256) densify_kernel(const void *__restrict__ f
     else reinterpret_cast<float *>(out)[o] = v;
 }
 
+// NCHW float32 output (the reference layout): one workgroup per 8x8 spatial tile of the index (64 consecutive
+// columns).  Phase 1 stages the tile's features in LDS with row-contiguous reads; phase 2 writes channel planes with
+// lane = cell, so each group of 8 lanes stores 32 contiguous bytes of an image row (the generic kernel above stores 4).
+template <bool IN_BF16>
+__global__ void __launch_bounds__(256) densify_nchw_tile(const void *__restrict__ feats, int C, const unsigned long long *__restrict__ words,
+                                                         const int *__restrict__ prefix, fd::IndexGeom g, float *__restrict__ out,
+                                                         int64_t sb, int64_t sc, int64_t sy, int64_t sx) {
+    extern __shared__ float s_tile[];  // [64 cells][CH + 1], CH = channels of this workgroup (blockIdx.y selects the chunk)
+    const int CD = C * g.D, CH = CD / gridDim.y, ch0 = blockIdx.y * CH, ld = CH + 1;
+    const int64_t cell0 = (int64_t)blockIdx.x * 64;
+    __shared__ unsigned long long s_w[64];
+    __shared__ int s_p[64];
+    if (threadIdx.x < 64) {
+        s_w[threadIdx.x] = words[cell0 + threadIdx.x];
+        s_p[threadIdx.x] = prefix[cell0 + threadIdx.x];
+    }
+    __syncthreads();
+    // chunk = channels [ch0, ch0 + CH) with channel = c*D + d  ->  c in [ch0/D, (ch0+CH)/D), all d
+    const int Cc = CH / g.D, c0 = ch0 / g.D;
+    for (int i = threadIdx.x; i < 64 * CH; i += 256) {
+        const int cell = i / CH, r = i - cell * CH;
+        const int d = r / Cc, c = c0 + (r - d * Cc);  // feature rows are contiguous in c
+        const unsigned long long w = s_w[cell];
+        float v = 0.0f;
+        if ((w >> d) & 1ull) {
+            const int row = s_p[cell] + __popcll(w & ((1ull << d) - 1ull));
+            if (IN_BF16) v = __uint_as_float(((unsigned)reinterpret_cast<const unsigned short *>(feats)[(int64_t)row * C + c]) << 16);
+            else v = reinterpret_cast<const float *>(feats)[(int64_t)row * C + c];
+        }
+        s_tile[cell * ld + (c - c0) * g.D + d] = v;
+    }
+    __syncthreads();
+    int b, y0, x0;
+    fd::col_to_byx(g, cell0, b, y0, x0);
+    const int cell = threadIdx.x & 63, y = y0 + (cell >> 3), x = x0 + (cell & 7);
+    if (y >= g.H || x >= g.W) return;
+    const int64_t o0 = b * sb + y * sy + x * sx;
+    for (int ch = threadIdx.x >> 6; ch < CH; ch += 4) out[o0 + (ch0 + ch) * sc] = s_tile[cell * ld + ch];
+}
+
 }  // namespace
 
 extern "C" int fd_densify(const void *feats, int c, int dtype, const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W,
@@ -51,6 +91,17 @@ extern "C" int fd_densify(const void *feats, int c, int dtype, const uint64_t *w
     dim3 grid((unsigned)((total + 255) / 256));
     const unsigned long long *wd = (const unsigned long long *)words;
     hipStream_t s = fd::as_stream(stream);
+    int chunks = 1;
+    while ((c % (2 * chunks)) == 0 && (size_t)64 * (c * D / chunks + 1) * sizeof(float) > 40 * 1024) chunks *= 2;
+    const size_t tile_lds = (size_t)64 * (c * D / chunks + 1) * sizeof(float);
+    if (out_dtype == 0 && stride_x == 1 && tile_lds <= 60 * 1024) {  // NCHW float32: tile kernel with wider stores
+        const dim3 tgrid((unsigned)(g.num_cols() / 64), (unsigned)chunks);
+        if (dtype == 0)
+            hipLaunchKernelGGL((densify_nchw_tile<false>), tgrid, dim3(256), tile_lds, s, feats, c, wd, prefix, g, (float *)out, stride_b, stride_c, stride_y, stride_x);
+        else
+            hipLaunchKernelGGL((densify_nchw_tile<true>), tgrid, dim3(256), tile_lds, s, feats, c, wd, prefix, g, (float *)out, stride_b, stride_c, stride_y, stride_x);
+        return fd::check_launch("fd_densify(tile)");
+    }
     if (dtype == 0 && out_dtype == 0)
         hipLaunchKernelGGL((densify_kernel<false, false>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x);
     else if (dtype == 0 && out_dtype == 1)
