@@ -339,3 +339,42 @@ extern "C" int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, i
                        (const unsigned long long *)in_words, in_prefix, gi, out_coords, n_out_dev, nbr_stride, dp, nbr);
     return fd::check_launch("fd_rulebook");
 }
+
+// -------------------------------------------------------------------------------------------------------------------
+// Whole index pyramid in one call.  The kernels above are a few microseconds each; launched one ctypes call at a time
+// the front of a sweep was bound by host launch latency (≈45 calls, GPU idle more than half of the first 0.8 ms).
+extern "C" int fd_index_pyramid(const int32_t *coords, const int32_t *n_dev, int64_t n_max_per_sample, int B, int n_levels,
+                                const fd_index_level *levels, int32_t *counts_dev, void *workspace, size_t workspace_bytes,
+                                fd_stream_t stream) {
+    FD_REQUIRE(coords && levels && counts_dev && workspace, "fd_index_pyramid: null argument");
+    FD_REQUIRE(n_levels >= 1 && n_levels <= 8 && B >= 1, "fd_index_pyramid: need 1 <= n_levels <= 8 and B >= 1");
+    const fd_index_level &l0 = levels[0];
+    for (int b = 0; b < B; ++b) {
+        int rc = fd_index_mark(coords + (int64_t)b * n_max_per_sample * 4, n_dev ? n_dev + b : nullptr, n_max_per_sample, B, l0.D, l0.H, l0.W,
+                               l0.words, stream);
+        if (rc != FD_OK) return rc;
+    }
+    for (int l = 0; l < n_levels; ++l) {
+        const fd_index_level &lv = levels[l];
+        FD_REQUIRE(lv.words && lv.prefix, "fd_index_pyramid: null level buffer");
+        if (l > 0) {
+            const fd_index_level &pv = levels[l - 1];
+            int rc = fd_index_downsample(pv.words, B, pv.D, pv.H, pv.W, lv.ksize, lv.stride, lv.pad, lv.words, stream);
+            if (rc != FD_OK) return rc;
+        }
+        int rc = fd_index_scan(lv.words, fd_index_num_cols(B, lv.H, lv.W), lv.prefix, counts_dev + l, workspace, workspace_bytes, stream);
+        if (rc != FD_OK) return rc;
+    }
+    return FD_OK;
+}
+
+extern "C" int fd_index_pyramid_coords(int B, int n_levels, const fd_index_level *levels, fd_stream_t stream) {
+    FD_REQUIRE(levels && n_levels >= 1 && n_levels <= 8, "fd_index_pyramid_coords: bad argument");
+    for (int l = 0; l < n_levels; ++l) {
+        const fd_index_level &lv = levels[l];
+        if (!lv.coords) continue;  // empty level
+        int rc = fd_index_coords(lv.words, lv.prefix, B, lv.D, lv.H, lv.W, lv.coords, stream);
+        if (rc != FD_OK) return rc;
+    }
+    return FD_OK;
+}

@@ -159,7 +159,7 @@ class VoxelNet(SingleStageDetector):
 
         mark_stage("voxelize")
         bb = self.backbone
-        idx = bb.build_indexes(mark, B, list(grid), dev)
+        idx = bb.build_indexes(mark, B, list(grid), dev, voxels=(coors, nvox, max_voxels))
         mark_stage("index")
         feats0 = torch.zeros((max(idx[0].n, 1), cpad), dtype=bb.compute_dtype, device=dev)[: idx[0].n]
         L = hip_ops._lib.load()

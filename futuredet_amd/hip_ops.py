@@ -84,12 +84,12 @@ def voxelize(points, voxel_size, coors_range, max_points, max_voxels, batch_idx=
 class SparseIndex(object):
     """Active set on a (B, D, H, W) grid: column occupancy words + prefix counts (+ coords once counted)."""
 
-    def __init__(self, B, D, H, W, device):
+    def __init__(self, B, D, H, W, device, words=None, prefix=None):
         L = _lib.load()
         self.B, self.D, self.H, self.W = int(B), int(D), int(H), int(W)
         self.ncols = L.fd_index_num_cols(self.B, self.H, self.W)
-        self.words = torch.zeros((self.ncols,), dtype=torch.int64, device=device)
-        self.prefix = torch.empty((self.ncols,), dtype=torch.int32, device=device)
+        self.words = torch.zeros((self.ncols,), dtype=torch.int64, device=device) if words is None else words
+        self.prefix = torch.empty((self.ncols,), dtype=torch.int32, device=device) if prefix is None else prefix
         self.n_dev = None     # device int32[1] view
         self.n = None         # host int, set by finalize()
         self.coords = None    # [n,4] int32 (b,z,y,x), rows in index order
@@ -154,6 +154,43 @@ class SparseIndex(object):
                             (ctypes.c_int * 3)(*pad), _p(nbr), _stream()), "fd_rulebook")
         nbr.n_out = out_index.n
         return nbr
+
+
+def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device):
+    """All sparse indexes of the backbone with two library calls and ONE host read: level 0 (D,H,W = shape0) marked
+    from the voxelizer output ``coors`` [B*n_max, 4] / ``nvox`` [B]; level l from level l-1 by geoms[l-1] =
+    (ksize, stride, pad).  Returns the list of finalised SparseIndex (coords materialised)."""
+    L = _lib.load()
+    shapes = [tuple(int(v) for v in shape0)]
+    for ks, st, pd in geoms:
+        shapes.append(tuple((i + 2 * p - (k - 1) - 1) // s + 1 for i, k, s, p in zip(shapes[-1], ks, st, pd)))
+    ncols = [L.fd_index_num_cols(B, sh[1], sh[2]) for sh in shapes]
+    words_all = torch.zeros((sum(ncols),), dtype=torch.int64, device=device)   # one fill for every level
+    prefix_all = torch.empty((sum(ncols),), dtype=torch.int32, device=device)
+    counts = torch.empty((len(shapes),), dtype=torch.int32, device=device)
+    idx, off = [], 0
+    for sh, nc in zip(shapes, ncols):
+        idx.append(SparseIndex(B, sh[0], sh[1], sh[2], device, words=words_all[off:off + nc], prefix=prefix_all[off:off + nc]))
+        off += nc
+    levels = (_lib.IndexLevel * len(shapes))()
+    for l, ix in enumerate(idx):
+        lv = levels[l]
+        lv.D, lv.H, lv.W = ix.D, ix.H, ix.W
+        if l:
+            ks, st, pd = geoms[l - 1]
+            lv.ksize[:], lv.stride[:], lv.pad[:] = list(ks), list(st), list(pd)
+        lv.words, lv.prefix, lv.coords = ix.words.data_ptr(), ix.prefix.data_ptr(), None
+        ix.n_dev = counts[l:l + 1]
+    ws = workspace.get("index_scan", L.fd_index_workspace_bytes(max(ncols)), device)
+    check(L.fd_index_pyramid(_p(coors), _p(nvox), int(n_max), int(B), len(shapes), levels, _p(counts), _p(ws), ws.numel(), _stream()),
+          "fd_index_pyramid")
+    host = counts.cpu()  # the only synchronisation of the backbone
+    for l, ix in enumerate(idx):
+        ix.n = int(host[l])
+        ix.coords = torch.empty((max(ix.n, 1), 4), dtype=torch.int32, device=device)[: ix.n]
+        levels[l].coords = ix.coords.data_ptr() if ix.n else None
+    check(L.fd_index_pyramid_coords(int(B), len(shapes), levels, _stream()), "fd_index_pyramid_coords")
+    return idx
 
 
 def tile_order_for(nbr):

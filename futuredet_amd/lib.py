@@ -23,6 +23,12 @@ class DecodeCfg(ctypes.Structure):
                 ("nms_iou_threshold", c_float), ("nms_pre_max", c_int), ("nms_post_max", c_int)]
 
 
+class IndexLevel(ctypes.Structure):  # struct fd_index_level
+    _fields_ = [("D", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("ksize", ctypes.c_int32 * 3),
+                ("stride", ctypes.c_int32 * 3), ("pad", ctypes.c_int32 * 3), ("words", c_void_p), ("prefix", c_void_p),
+                ("coords", c_void_p)]
+
+
 # name -> (restype, argtypes); this table is checked against include/futuredet_hip.h by the tests
 SIGNATURES = {
     "fd_abi_version": (c_int, []),
@@ -66,6 +72,9 @@ SIGNATURES = {
     "fd_bias_act_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_i64, c_int, c_void_p]),
     "fd_forecast_chains": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_index_pyramid": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, ctypes.POINTER(IndexLevel), c_void_p, c_void_p, c_size_t,
+                                 c_void_p]),
+    "fd_index_pyramid_coords": (c_int, [c_int, c_int, ctypes.POINTER(IndexLevel), c_void_p]),
     "fd_sweep_assemble_workspace_bytes": (c_size_t, [c_i64]),
     "fd_sweep_assemble": (c_int, [c_void_p, c_int, c_int, c_i64, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

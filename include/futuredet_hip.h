@@ -244,6 +244,25 @@ int fd_forecast_chains(const double *centers, const double *velocity, const int3
                        int n_max, double reject_thresh, int32_t *fwd_idx, int32_t *fwd_ok, int32_t *bwd_idx, int32_t *bwd_ok,
                        int32_t *match_idx, double *cv_centers, int32_t *status, fd_stream_t stream);
 
+/* The whole index pyramid of the backbone in one call (the same launches as fd_index_mark / _downsample / _scan /
+ * _coords above, issued back to back): level 0 is marked from the voxelizer's coords of every sample
+ * (coords [B * n_max_per_sample, 4], n_dev[b] = voxel count of sample b or NULL), level l > 0 is derived from
+ * level l-1 with its ksize/stride/pad (the strided SparseConv3d of scn.py:110,120,130,141); counts_dev[l] receives
+ * the active count of level l.  words of every level must be zero-filled by the caller; workspace as for
+ * fd_index_scan of the largest level.  fd_index_pyramid_coords materialises coords for the levels whose pointer is
+ * set (after the host has read the counts and allocated them). */
+typedef struct fd_index_level {
+    int32_t D, H, W;
+    int32_t ksize[3], stride[3], pad[3]; /* how this level derives from the previous one (unused for level 0) */
+    uint64_t *words;
+    int32_t *prefix;
+    int32_t *coords; /* [n_l, 4] or NULL */
+} fd_index_level;
+int fd_index_pyramid(const int32_t *coords, const int32_t *n_dev, int64_t n_max_per_sample, int B, int n_levels,
+                     const fd_index_level *levels_host, int32_t *counts_dev, void *workspace, size_t workspace_bytes,
+                     fd_stream_t stream);
+int fd_index_pyramid_coords(int B, int n_levels, const fd_index_level *levels_host, fd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

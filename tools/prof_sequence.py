@@ -1,0 +1,12 @@
+"""Ordered kernel sequence of the last full step of bench.py from a rocprofv3 --kernel-trace CSV (a step starts at vox_hash)."""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+starts = [i for i, r in enumerate(rows) if "vox_hash" in r["Kernel_Name"]]
+a, b = starts[-2], starts[-1]
+t0 = int(rows[a]["Start_Timestamp"])
+for r in rows[a:b]:
+    n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+    print("%9.1f  %7.1f us  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, n))
