@@ -46,6 +46,9 @@ def parse():
     return ap.parse_args()
 
 
+PROF_EVERY = 4
+
+
 class SpconvProfiler(object):
     """backbone.profile_hook: brackets every fd_spconv_apply launch with events on the launch stream."""
 
@@ -170,9 +173,12 @@ def main():
             p, c = step()
             p.cpu()
         sync_all()
-        prof.enabled = True
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for si in range(args.steps):
+            # the per-launch HIP events of the roofline measurement are taken on every PROF_EVERY-th step of the timed
+            # region: an event pair costs ~5 us of queue time per launch (21 launches per step), which would otherwise
+            # be charged to every step of the headline number
+            prof.enabled = (si % PROF_EVERY == 0)
             p, c = step()
             host_p, host_c = p.cpu(), c.cpu()  # detections on the host = end of a sweep
         if world > 1:
@@ -203,13 +209,15 @@ def main():
             for (n0, e0), (n1, e1) in zip(stage_events[:-1], stage_events[1:]):
                 if n1 != "start":
                     st[n1] = st.get(n1, 0.0) + e0.elapsed_time(e1)
-            print("[stage] GPU ms/step: " + ", ".join("%s=%.3f" % (k, v / args.steps) for k, v in st.items()), file=sys.stderr)
+            n_prof = (args.steps + PROF_EVERY - 1) // PROF_EVERY
+            print("[stage] GPU ms/step: " + ", ".join("%s=%.3f" % (k, v / n_prof) for k, v in st.items()), file=sys.stderr)
         print(json.dumps(out))
     elif rank == 0:
         # ---- roofline of the dominant kernel (sparse conv apply), from the events recorded in the timed region
         with torch.no_grad():
             ms = [(tag, info, e0.elapsed_time(e1)) for tag, info, e0, e1 in prof.records]
-            per_step = len(ms) // max(args.steps, 1)
+            n_prof = (args.steps + PROF_EVERY - 1) // PROF_EVERY  # instrumented steps
+            per_step = len(ms) // max(n_prof, 1)
             pair_counts = [info["pairs"]() for _, info, _ in ms[:per_step]]
         tot_ms = sum(m for _, _, m in ms)
         tot_bytes = sum(algorithmic_bytes(info, pair_counts[i % per_step]) for i, (_, info, _) in enumerate(ms))
@@ -230,14 +238,14 @@ def main():
                            "kernel": "spconv_f32/spconv_bf16 (fd_spconv_apply)", "launches_per_step": per_step,
                            "avg_launch_us": round(1e3 * tot_ms / max(launches, 1), 2),
                            "algorithmic_bytes_per_launch": int(tot_bytes / max(launches, 1)),
-                           "pair_gflop_per_step": round(tot_flops / max(args.steps, 1) / 1e9, 2),
-                           "spconv_ms_per_step": round(tot_ms / max(args.steps, 1), 3)}
+                           "pair_gflop_per_step": round(tot_flops / max(n_prof, 1) / 1e9, 2),
+                           "spconv_ms_per_step": round(tot_ms / max(n_prof, 1), 3), "instrumented_steps": n_prof}
         if args.stage_times:
             st = {}
             for (n0, e0), (n1, e1) in zip(stage_events[:-1], stage_events[1:]):
                 if n1 != "start":
                     st[n1] = st.get(n1, 0.0) + e0.elapsed_time(e1)
-            print("[stage] GPU ms/step: " + ", ".join("%s=%.3f" % (k, v / args.steps) for k, v in st.items()), file=sys.stderr)
+            print("[stage] GPU ms/step: " + ", ".join("%s=%.3f" % (k, v / n_prof) for k, v in st.items()), file=sys.stderr)
             agg = {}
             for i, (tag, info, m) in enumerate(ms):
                 a = agg.setdefault((tag, info["n_out"]), [0.0, 0, 0])
@@ -245,7 +253,7 @@ def main():
                 a[1] += 1
                 a[2] = pair_counts[i % per_step]
             for (tag, n_out), (m, cnt, pairs) in agg.items():
-                print("[stage] %-22s n_out=%7d pairs=%8d launches/step=%d avg=%.1f us" % (tag, n_out, pairs, cnt // args.steps, 1e3 * m / cnt),
+                print("[stage] %-22s n_out=%7d pairs=%8d launches/step=%d avg=%.1f us" % (tag, n_out, pairs, cnt // n_prof, 1e3 * m / cnt),
                       file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -156,40 +156,66 @@ class SparseIndex(object):
         return nbr
 
 
+class _PyramidPlan(object):
+    """Static part of build_pyramid for one (B, shape, geometry): level shapes, one words / prefix allocation for all
+    levels, the fd_index_level array.  Reused across sweeps so a step pays one memset and two library calls."""
+
+    def __init__(self, B, shape0, geoms, device):
+        L = _lib.load()
+        self.B, self.geoms, self.device = int(B), geoms, device
+        self.shapes = [tuple(int(v) for v in shape0)]
+        for ks, st, pd in geoms:
+            self.shapes.append(tuple((i + 2 * p - (k - 1) - 1) // s + 1 for i, k, s, p in zip(self.shapes[-1], ks, st, pd)))
+        self.ncols = [L.fd_index_num_cols(self.B, sh[1], sh[2]) for sh in self.shapes]
+        self.ws_bytes = L.fd_index_workspace_bytes(max(self.ncols))
+
+
+_pyramid_plans = {}
+
+
 def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device):
     """All sparse indexes of the backbone with two library calls and ONE host read: level 0 (D,H,W = shape0) marked
     from the voxelizer output ``coors`` [B*n_max, 4] / ``nvox`` [B]; level l from level l-1 by geoms[l-1] =
     (ksize, stride, pad).  Returns the list of finalised SparseIndex (coords materialised)."""
     L = _lib.load()
-    shapes = [tuple(int(v) for v in shape0)]
-    for ks, st, pd in geoms:
-        shapes.append(tuple((i + 2 * p - (k - 1) - 1) // s + 1 for i, k, s, p in zip(shapes[-1], ks, st, pd)))
-    ncols = [L.fd_index_num_cols(B, sh[1], sh[2]) for sh in shapes]
-    words_all = torch.zeros((sum(ncols),), dtype=torch.int64, device=device)   # one fill for every level
+    key = (int(B), tuple(int(v) for v in shape0), tuple((tuple(k), tuple(s), tuple(p)) for k, s, p in geoms), str(device))
+    plan = _pyramid_plans.get(key)
+    if plan is None:
+        plan = _pyramid_plans[key] = _PyramidPlan(B, shape0, geoms, device)
+    shapes, ncols = plan.shapes, plan.ncols
+    # fresh buffers every sweep (the indexes are handed out and may outlive the call); one fill covers every level
+    words_all = torch.zeros((sum(ncols),), dtype=torch.int64, device=device)
     prefix_all = torch.empty((sum(ncols),), dtype=torch.int32, device=device)
     counts = torch.empty((len(shapes),), dtype=torch.int32, device=device)
     idx, off = [], 0
-    for sh, nc in zip(shapes, ncols):
-        idx.append(SparseIndex(B, sh[0], sh[1], sh[2], device, words=words_all[off:off + nc], prefix=prefix_all[off:off + nc]))
-        off += nc
     levels = (_lib.IndexLevel * len(shapes))()
-    for l, ix in enumerate(idx):
+    wp, pp = words_all.data_ptr(), prefix_all.data_ptr()
+    for l, (sh, nc) in enumerate(zip(shapes, ncols)):
+        ix = SparseIndex.__new__(SparseIndex)
+        ix.B, ix.D, ix.H, ix.W, ix.ncols, ix.device = plan.B, sh[0], sh[1], sh[2], nc, device
+        ix.words, ix.prefix = words_all[off:off + nc], prefix_all[off:off + nc]
+        ix.n_dev, ix.n, ix.coords = counts[l:l + 1], None, None
         lv = levels[l]
-        lv.D, lv.H, lv.W = ix.D, ix.H, ix.W
+        lv.D, lv.H, lv.W = sh
         if l:
             ks, st, pd = geoms[l - 1]
             lv.ksize[:], lv.stride[:], lv.pad[:] = list(ks), list(st), list(pd)
-        lv.words, lv.prefix, lv.coords = ix.words.data_ptr(), ix.prefix.data_ptr(), None
-        ix.n_dev = counts[l:l + 1]
-    ws = workspace.get("index_scan", L.fd_index_workspace_bytes(max(ncols)), device)
-    check(L.fd_index_pyramid(_p(coors), _p(nvox), int(n_max), int(B), len(shapes), levels, _p(counts), _p(ws), ws.numel(), _stream()),
+        lv.words, lv.prefix, lv.coords = wp + 8 * off, pp + 4 * off, None
+        idx.append(ix)
+        off += nc
+    ws = workspace.get("index_scan", plan.ws_bytes, device)
+    check(L.fd_index_pyramid(_p(coors), _p(nvox), int(n_max), plan.B, len(shapes), levels, _p(counts), _p(ws), ws.numel(), _stream()),
           "fd_index_pyramid")
-    host = counts.cpu()  # the only synchronisation of the backbone
+    host = counts.tolist()  # the only synchronisation of the backbone
+    total = sum(host)
+    coords_all = torch.empty((max(total, 1), 4), dtype=torch.int32, device=device)
+    o = 0
     for l, ix in enumerate(idx):
         ix.n = int(host[l])
-        ix.coords = torch.empty((max(ix.n, 1), 4), dtype=torch.int32, device=device)[: ix.n]
-        levels[l].coords = ix.coords.data_ptr() if ix.n else None
-    check(L.fd_index_pyramid_coords(int(B), len(shapes), levels, _stream()), "fd_index_pyramid_coords")
+        ix.coords = coords_all[o:o + ix.n]
+        levels[l].coords = (coords_all.data_ptr() + 16 * o) if ix.n else None
+        o += ix.n
+    check(L.fd_index_pyramid_coords(plan.B, len(shapes), levels, _stream()), "fd_index_pyramid_coords")
     return idx
 
 
