@@ -687,3 +687,42 @@ def test_forward_points_empty_and_ragged_batch(hip):
         assert batch[b]["box3d_lidar"].shape[1] == 9 and bool(torch.isfinite(batch[b]["box3d_lidar"]).all())
     none = net.forward_points([empty], cfg.voxel_generator, padded=False)
     assert len(none) == 1 and bool(torch.isfinite(none[0]["scores"]).all())
+
+
+# ------------------------------------------------------------------------------------------------ C ABI error behaviour
+def test_c_abi_reports_errors_instead_of_exiting(hip):
+    """The reference extension calls exit(-1) on bad input (iou3d_nms.cpp:14-38); this library returns a negative status
+    and a message, for every family of entry points, and stays usable afterwards."""
+    import ctypes
+
+    from futuredet_amd import lib
+
+    L = lib.load()
+    x = torch.zeros((64, 16), device="cuda")
+    cases = [
+        ("fd_voxelize", lambda: L.fd_voxelize(x.data_ptr(), 64, 99, None, None, 10, 100, 0, None, None, 0, None, 3, None, None, None, 0, None)),
+        ("fd_spconv_apply", lambda: L.fd_spconv_apply(x.data_ptr(), 64, x.data_ptr(), None, None, 0, x.data_ptr(), 64, None, 99, 64, 16, 16, 0,
+                                                     x.data_ptr(), None)),
+        ("fd_rotated_nms", lambda: L.fd_rotated_nms(None, 10, ctypes.c_float(0.2), None, None, None, 0, None)),
+        ("fd_conv2d_nhwc_bf16", lambda: L.fd_conv2d_nhwc_bf16(x.data_ptr(), 1, 8, 8, 7, x.data_ptr(), None, 16, 3, 1, 1, 1, x.data_ptr(), 16, 0, 1, 1,
+                                                             0, 0, None)),
+        ("fd_sweep_assemble", lambda: L.fd_sweep_assemble(x.data_ptr(), 5, 9, 10, x.data_ptr(), 1, ctypes.c_float(1.0), x.data_ptr(), x.data_ptr(),
+                                                         None, 0, None)),
+        ("fd_pillar_encode", lambda: L.fd_pillar_encode(x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 4, 99, 5, 0, ctypes.c_float(1), ctypes.c_float(1),
+                                                       ctypes.c_float(0), ctypes.c_float(0), x.data_ptr(), x.data_ptr(), x.data_ptr(), 64, None, None,
+                                                       None, 0, 0, x.data_ptr(), 64, None)),
+        ("fd_forecast_chains", lambda: L.fd_forecast_chains(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 99, 8, ctypes.c_double(1.0),
+                                                           x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                                           x.data_ptr(), None)),
+    ]
+    for name, call in cases:
+        status = call()
+        assert status < 0, name
+        msg = L.fd_last_error()
+        assert msg and name.encode() in msg, (name, msg)
+    # workspace too small is its own code, and the library still works afterwards
+    pts = torch.rand((100, 5), device="cuda")
+    out = hip.voxelize(pts, [0.5, 0.5, 0.5], [0, 0, 0, 1, 1, 1], 4, 64)
+    assert 0 < int(out["num_voxels"].item()) <= 8
+    with pytest.raises(lib.FutureDetHipError):
+        hip.voxelize(torch.rand((10, 5)), [0.5, 0.5, 0.5], [0, 0, 0, 1, 1, 1], 4, 64)  # CPU tensor: no CPU path
