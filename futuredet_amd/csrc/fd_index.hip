@@ -195,6 +195,31 @@ __global__ void __launch_bounds__(256) rows_permute(const float *__restrict__ sr
     }
 }
 
+// lookup + permute in one pass: thread (voxel i, channel): row of the voxel in the index, then dst[row][ch] = src[i][ch]
+template <bool BF16>
+__global__ void __launch_bounds__(256) rows_place(const unsigned long long *__restrict__ words, const int *__restrict__ prefix, IndexGeom g,
+                                                  const int *__restrict__ coords, const int *__restrict__ n_dev, int64_t n_max,
+                                                  const float *__restrict__ src, int c_src, void *__restrict__ dst, int c_dst) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = n_dev ? (int64_t)n_dev[0] : n_max;
+    if (n > n_max) n = n_max;
+    int64_t i = t / c_dst;
+    int ch = (int)(t % c_dst);
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    if (c.x < 0 || c.x >= g.B) return;
+    const int r = lookup_row(words, prefix, g, c.x, c.y, c.z, c.w);
+    if (r < 0) return;
+    float v = ch < c_src ? src[i * c_src + ch] : 0.0f;
+    if (BF16) {
+        unsigned u = __float_as_uint(v);
+        u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+        reinterpret_cast<unsigned short *>(dst)[(int64_t)r * c_dst + ch] = (unsigned short)(u >> 16);
+    } else {
+        reinterpret_cast<float *>(dst)[(int64_t)r * c_dst + ch] = v;
+    }
+}
+
 // one thread per (output row, (ky,kx) column pair): fills the kz taps of that column from one word load
 __global__ void __launch_bounds__(256) rulebook_kernel(const unsigned long long *__restrict__ in_words, const int *__restrict__ in_prefix,
                                                        IndexGeom gi, const int *__restrict__ out_coords, const int *__restrict__ n_out_dev,
@@ -324,6 +349,23 @@ extern "C" int fd_rows_permute(const float *src, int c_src, const int32_t *row_o
     else
         hipLaunchKernelGGL(rows_permute<false>, grid, dim3(256), 0, fd::as_stream(stream), src, c_src, row_of, n_dev, n_max, dst, c_dst);
     return fd::check_launch("fd_rows_permute");
+}
+
+extern "C" int fd_rows_place(const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W, const int32_t *coords_in,
+                             const int32_t *n_dev, int64_t n_max, const float *src, int c_src, void *dst, int c_dst, int dst_bf16,
+                             fd_stream_t stream) {
+    FD_REQUIRE(words && prefix && coords_in && src && dst, "fd_rows_place: null argument");
+    FD_REQUIRE(c_src > 0 && c_dst >= c_src, "fd_rows_place: c_dst < c_src");
+    if (n_max <= 0) return FD_OK;
+    IndexGeom g = fd::make_geom(B, D, H, W);
+    dim3 grid((unsigned)((n_max * c_dst + 255) / 256));
+    if (dst_bf16)
+        hipLaunchKernelGGL(rows_place<true>, grid, dim3(256), 0, fd::as_stream(stream), (const unsigned long long *)words, prefix, g, coords_in,
+                           n_dev, n_max, src, c_src, dst, c_dst);
+    else
+        hipLaunchKernelGGL(rows_place<false>, grid, dim3(256), 0, fd::as_stream(stream), (const unsigned long long *)words, prefix, g, coords_in,
+                           n_dev, n_max, src, c_src, dst, c_dst);
+    return fd::check_launch("fd_rows_place");
 }
 
 extern "C" int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int Din, int Hin, int Win,

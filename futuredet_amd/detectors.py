@@ -161,14 +161,15 @@ class VoxelNet(SingleStageDetector):
         bb = self.backbone
         idx = bb.build_indexes(mark, B, list(grid), dev, voxels=(coors, nvox, max_voxels))
         mark_stage("index")
-        feats0 = torch.zeros((max(idx[0].n, 1), cpad), dtype=bb.compute_dtype, device=dev)[: idx[0].n]
+        # every row of the level-0 index is exactly one voxel, and fd_rows_place writes all cpad channels of it: no fill
+        feats0 = torch.empty((max(idx[0].n, 1), cpad), dtype=bb.compute_dtype, device=dev)[: idx[0].n]
         L = hip_ops._lib.load()
-        for b in range(B if idx[0].n > 0 else 0):  # (nothing to place when every cloud of the batch is empty)
+        i0 = idx[0]
+        for b in range(B if i0.n > 0 else 0):  # (nothing to place when every cloud of the batch is empty)
             sl = slice(b * max_voxels, (b + 1) * max_voxels)
-            row_of = idx[0].lookup(coors[sl], n_dev=nvox[b:b + 1])
-            hip_ops.check(L.fd_rows_permute(hip_ops._p(mean[sl]), cpad, hip_ops._p(row_of), hip_ops._p(nvox[b:b + 1]), max_voxels,
-                                            hip_ops._p(feats0), cpad, hip_ops._DT[bb.compute_dtype], hip_ops._stream()),
-                          "fd_rows_permute")
+            hip_ops.check(L.fd_rows_place(hip_ops._p(i0.words), hip_ops._p(i0.prefix), i0.B, i0.D, i0.H, i0.W, hip_ops._p(coors[sl]),
+                                          hip_ops._p(nvox[b:b + 1]), max_voxels, hip_ops._p(mean[sl]), cpad, hip_ops._p(feats0), cpad,
+                                          hip_ops._DT[bb.compute_dtype], hip_ops._stream()), "fd_rows_place")
         graph = None if (bev_map is not None or os.environ.get("FD_NO_GRAPH")) else self._dense_graph(B, idx[4], dev)
         if graph is not None:
             # neck + head have static shapes: replay them as one hipGraph (one launch instead of ~25-60)

@@ -263,6 +263,13 @@ int fd_index_pyramid(const int32_t *coords, const int32_t *n_dev, int64_t n_max_
                      fd_stream_t stream);
 int fd_index_pyramid_coords(int B, int n_levels, const fd_index_level *levels_host, fd_stream_t stream);
 
+/* fd_index_lookup + fd_rows_permute in one launch: dst[row(coords_in[i])][:] = src[i][:] (channels >= c_src zeroed) for
+ * the first n_dev[0] (<= n_max) voxels; this is how the voxelizer's per-voxel features become rows of the level-0
+ * SparseConvTensor (scn.py:154) in index order. */
+int fd_rows_place(const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W, const int32_t *coords_in,
+                  const int32_t *n_dev, int64_t n_max, const float *src, int c_src, void *dst, int c_dst, int dst_bf16,
+                  fd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
