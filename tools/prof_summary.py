@@ -8,8 +8,10 @@ def main(path, steps_back=1):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if "vox_hash" in r["Kernel_Name"]]
-    first = starts[-steps_back]
-    sel = rows[first:]
+    # full steps only: from the (steps_back+1)-th last step start up to the start of the last step (the trailing
+    # part of the trace also holds bench.py's post-loop pair counting, which is not part of a step)
+    first, last = starts[-1 - steps_back], starts[-1]
+    sel = rows[first:last]
     agg = OrderedDict()
     for r in sel:
         n = r["Kernel_Name"]
