@@ -742,3 +742,50 @@ def test_c_abi_reports_errors_instead_of_exiting(hip):
     assert 0 < int(out["num_voxels"].item()) <= 8
     with pytest.raises(lib.FutureDetHipError):
         hip.voxelize(torch.rand((10, 5)), [0.5, 0.5, 0.5], [0, 0, 0, 1, 1, 1], 4, 64)  # CPU tensor: no CPU path
+
+
+def test_voxelnet_bf16_end_to_end_vs_fp32_oracle(hip):
+    """BASELINE config 3 precision: bf16 conv features/weights with fp32 accumulation (sparse convs on the bf16 MFMA
+    kernels, RPN + head on the hand-written NHWC conv plan, replayed as a hipGraph) against the fp32 CPU oracle.  bf16
+    carries 8 mantissa bits through ~45 layers: the BEV map must agree within 4e-2 of its scale, and the detections
+    that the oracle scores well clear of the threshold must be found at the same place (0.3 m) by the bf16 path."""
+    from futuredet_amd import build_detector
+    from futuredet_amd.configs import centerpoint_config
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
+    from oracle import model as omodel
+    from oracle import ops as oops
+
+    cfg = centerpoint_config("forecast_n3")
+    net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    sd = seeded_state_dict(net, 7)
+    net.load_state_dict(sd, strict=False)
+    net = net.cuda().eval()
+    net.set_precision(torch.bfloat16)
+    onet = omodel.VoxelNet(cfg.model["reader"], cfg.model["backbone"], cfg.model["neck"], cfg.model["bbox_head"],
+                           test_cfg=cfg.test_cfg).eval()
+    onet.load_state_dict(sd, strict=False)
+    cloud = synthetic_cloud(seed=0, target_points=30000)
+    vg = cfg.voxel_generator
+    v, c, n = oops.points_to_voxel(cloud, vg["voxel_size"], vg["range"], vg["max_points_in_voxel"], True, vg["max_voxel_num"][1])
+    ex = dict(voxels=torch.from_numpy(v), coordinates=torch.from_numpy(np.pad(c, ((0, 0), (1, 0)))), num_points=torch.from_numpy(n),
+              num_voxels=torch.tensor([len(n)]), shape=np.array([[1440, 1440, 40]]), metadata=[None])
+    with torch.no_grad():
+        want = onet(ex)[0]
+        obev = onet.extract_feat(ex)
+        for _ in range(2):  # second call replays the captured graph
+            got = net.forward_points([_dev(cloud)], vg, padded=False)[0]
+        feats = net.reader(_dev(v).float(), _dev(n))
+        bev, _ = net.backbone(feats, _dev(np.pad(c, ((0, 0), (1, 0)))), 1, [1440, 1440, 40])
+        x = net.neck(bev)
+    scale = float(obev.abs().max())
+    assert float((x.float().cpu() - obev).abs().max()) <= 4e-2 * scale
+    wb, ws, wl = want["box3d_lidar"].numpy(), want["scores"].numpy(), want["label_preds"].numpy()
+    gb, gl = got["box3d_lidar"].cpu().numpy(), got["label_preds"].cpu().numpy()
+    assert len(gb) > 0.8 * len(wb)
+    strong = ws > 0.3
+    assert strong.sum() > 20
+    found = 0
+    for b, l in zip(wb[strong], wl[strong]):
+        d = np.abs(gb[gl == l][:, :2] - b[:2]).max(1) if (gl == l).any() else np.array([9.0])
+        found += d.min() < 0.3
+    assert found >= 0.9 * strong.sum(), (found, strong.sum())
