@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
                                                           const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
                                                           float *__restrict__ out, unsigned in_bytes, const int *__restrict__ tile_order) {
     constexpr int NB = COUT / 16, NC = CIN / 16;
-    constexpr int WC = NB >= 4 ? 4 : NB;  // column splits across the 4 waves
+    constexpr int WC = NB == 8 ? 4 : (NB >= 2 ? 2 : 1);  // column splits across the 4 waves (64 columns: 2 x 32)
     constexpr int NBW = NB / WC;          // 16-column blocks per wave
     constexpr int WR = 4 / WC;            // row splits
     constexpr int RW = TM / WR;           // rows in a wave's row set
