@@ -114,8 +114,13 @@ def main():
     from futuredet_amd.configs import centerpoint_config
     from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
 
-    rank, world, local = dist_infer.init_from_env("nccl")
+    # FD_BENCH_ONE_DEVICE=1 (test hook for 1-GPU boxes): every rank uses cuda:0 and the collectives run over gloo, so the
+    # world > 1 logic (sharded seeds, barriers, MAX over ranks, result gather, rank-0 print) can be exercised anywhere
+    one_dev = bool(os.environ.get("FD_BENCH_ONE_DEVICE"))
+    rank, world, local = dist_infer.init_from_env("gloo" if one_dev else "nccl")
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if rank == 0:
