@@ -121,23 +121,29 @@ extern "C" int fd_densify(const void *feats, int c, int dtype, const uint64_t *w
 // In-place per-channel bias (+ReLU) on an NCHW float32 map: the epilogue MIOpen's fp32 Winograd kernels lack (PyTorch
 // otherwise runs a broadcast add and a clamp as two more passes over the map).  One float4 per thread, HW % 4 == 0.
 namespace {
-__global__ void __launch_bounds__(256) bias_act_nchw(float4 *__restrict__ x, const float *__restrict__ bias, int C, int hw4, long long n4,
-                                                     int relu) {
+__global__ void __launch_bounds__(256) bias_act_nchw(const float4 *__restrict__ x, const float *__restrict__ bias, int C, int hw4, long long n4,
+                                                     int relu, float4 *__restrict__ dst, long long dst_batch4) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
-    const float b = bias[(int)((i / hw4) % C)];
+    const long long chw4 = (long long)C * hw4;
+    const long long bidx = i / chw4, r = i - bidx * chw4;
+    const float b = bias[(int)(r / hw4)];
     float4 v = x[i];
     v.x += b; v.y += b; v.z += b; v.w += b;
     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    x[i] = v;
+    dst[bidx * dst_batch4 + r] = v;  // in place: dst = x, dst_batch4 = C*hw4; into a concat buffer: dst = slice base
 }
 }  // namespace
 
-extern "C" int fd_bias_act_nchw_f32(float *x, const float *bias, int B, int C, int64_t hw, int relu, fd_stream_t stream) {
+extern "C" int fd_bias_act_nchw_f32(float *x, const float *bias, int B, int C, int64_t hw, int relu, float *dst, int64_t dst_batch_stride,
+                                    fd_stream_t stream) {
     FD_REQUIRE(x && bias && B > 0 && C > 0 && hw > 0, "fd_bias_act_nchw_f32: bad argument");
     FD_REQUIRE(hw % 4 == 0 && hw / 4 < (1ll << 31), "fd_bias_act_nchw_f32: H*W must be a multiple of 4");
+    FD_REQUIRE(!dst || (dst_batch_stride >= (int64_t)C * hw && dst_batch_stride % 4 == 0), "fd_bias_act_nchw_f32: bad destination stride");
     const long long n4 = (long long)B * C * (hw / 4);
-    hipLaunchKernelGGL(bias_act_nchw, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, fd::as_stream(stream), reinterpret_cast<float4 *>(x),
-                       bias, C, (int)(hw / 4), n4, relu);
+    float *d = dst ? dst : x;
+    const long long db4 = dst ? dst_batch_stride / 4 : (long long)C * (hw / 4);
+    hipLaunchKernelGGL(bias_act_nchw, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, fd::as_stream(stream),
+                       reinterpret_cast<const float4 *>(x), bias, C, (int)(hw / 4), n4, relu, reinterpret_cast<float4 *>(d), db4);
     return fd::check_launch("fd_bias_act_nchw_f32");
 }

@@ -483,26 +483,14 @@ def pillar_scatter(feats, coors4, n_dev, batch_size, ny, nx, out_dtype=None, cha
     return out
 
 
-def bias_act_nchw_(x, bias, relu):
-    """In-place per-channel bias (+ReLU) on a contiguous NCHW float32 device tensor (fd_bias_act_nchw_f32)."""
+def bias_act_nchw_(x, bias, relu, out=None):
+    """Per-channel bias (+ReLU) on a contiguous NCHW float32 device tensor (fd_bias_act_nchw_f32): in place, or into
+    ``out`` = a channel slice [B, C, H, W] of a wider contiguous NCHW buffer (the concat destination)."""
     B, C, H, W = x.shape
-    check(_lib.load().fd_bias_act_nchw_f32(_p(x), _p(bias), B, C, H * W, int(bool(relu)), _stream()), "fd_bias_act_nchw_f32")
-    return x
-
-
-# ------------------------------------------------------------------------------------------------ forecast association
-def forecast_chains(centers, velocity, counts, time, reject_thresh):
-    """fd_forecast_chains on device tensors: centers/velocity [T,n,3] float64, counts [T] int32, time [T-1] float64."""
-    L = _lib.load()
-    centers = _dev(centers, "centers", torch.float64)
-    velocity = _dev(velocity, "velocity", torch.float64)
-    T, n, _ = centers.shape
-    dev = centers.device
-    i32 = dict(dtype=torch.int32, device=dev)
-    out = dict(fwd_idx=torch.zeros((n, T), **i32), fwd_ok=torch.zeros((n,), **i32), bwd_idx=torch.zeros((n, T), **i32),
-               bwd_ok=torch.zeros((n,), **i32), match_idx=torch.zeros((T, n), **i32),
-               cv_centers=torch.zeros((n, T, 3), dtype=torch.float64, device=dev), status=torch.zeros((1,), **i32))
-    check(L.fd_forecast_chains(_p(centers), _p(velocity), _p(counts), _p(time), T, n, float(reject_thresh), _p(out["fwd_idx"]),
-                               _p(out["fwd_ok"]), _p(out["bwd_idx"]), _p(out["bwd_ok"]), _p(out["match_idx"]), _p(out["cv_centers"]),
-                               _p(out["status"]), _stream()), "fd_forecast_chains")
+    if out is None:
+        check(_lib.load().fd_bias_act_nchw_f32(_p(x), _p(bias), B, C, H * W, int(bool(relu)), None, 0, _stream()), "fd_bias_act_nchw_f32")
+        return x
+    assert out.shape == x.shape and out.stride()[1:] == (H * W, W, 1)
+    check(_lib.load().fd_bias_act_nchw_f32(_p(x), _p(bias), B, C, H * W, int(bool(relu)), _p(out), out.stride(0), _stream()),
+          "fd_bias_act_nchw_f32")
     return out

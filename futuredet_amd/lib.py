@@ -69,7 +69,7 @@ SIGNATURES = {
                                  c_void_p, c_int, c_void_p]),
     "fd_pillar_scatter": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_int,
                                   c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
-    "fd_bias_act_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_i64, c_int, c_void_p]),
+    "fd_bias_act_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_i64, c_int, c_void_p, c_i64, c_void_p]),
     "fd_forecast_chains": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_index_pyramid": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, ctypes.POINTER(IndexLevel), c_void_p, c_void_p, c_size_t,

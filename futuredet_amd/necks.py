@@ -118,13 +118,24 @@ class RPN(nn.Module):
         x = x.to(self.compute_dtype)
         if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
-        ups = []
+        # the deblock outputs are written straight into their channel slices of the concatenated map (the epilogue of a
+        # deblock's last conv takes the slice as destination): no torch.cat pass
+        couts = [d[-1].weight.shape[1 if d[-1].transposed else 0] for d in deblocks]
+        cat, co = None, 0
         for i, stack in enumerate(blocks):
             for conv in stack:
                 x = conv(x)
-            if i - self._upsample_start_idx >= 0:
+            j = i - self._upsample_start_idx
+            if j >= 0:
                 y = x
-                for conv in deblocks[i - self._upsample_start_idx]:
+                for conv in deblocks[j][:-1]:
                     y = conv(y)
-                ups.append(y)
-        return torch.cat(ups, dim=1) if ups else x
+                last = deblocks[j][-1]
+                if cat is None:
+                    k = last.weight.shape[-1]
+                    H, W = (y.shape[2] * k, y.shape[3] * k) if last.transposed else ((y.shape[2] - k) // last.stride + 1,
+                                                                                     (y.shape[3] - k) // last.stride + 1)
+                    cat = torch.empty((y.shape[0], sum(couts), H, W), dtype=y.dtype, device=y.device)
+                last(y, out=cat[:, co:co + couts[j]])
+                co += couts[j]
+        return cat if cat is not None else x

@@ -81,7 +81,8 @@ class FoldedConv(object):
 
     fuse_relu = True  # one in-place bias(+ReLU) pass after the convolution instead of PyTorch's broadcast add + clamp
 
-    def __call__(self, x):
+    def __call__(self, x, out=None):
+        """``out``: optional destination view (channel slice of a wider NCHW buffer) for the fused epilogue."""
         if (FoldedConv.fuse_relu and x.is_cuda and x.dtype == torch.float32 and self.bias is not None and x.is_contiguous()):
             # fp32 NCHW on the GPU: MIOpen's Winograd / GEMM kernels have no epilogue (torch.miopen_convolution_relu runs
             # conv + add + clamp as three kernels here), so the folded-BN shift and the ReLU are one HIP pass in place
@@ -91,14 +92,16 @@ class FoldedConv(object):
                 y = F.conv2d(x, self.weight, None, stride=self.stride, padding=self.padding)
             if y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0:
                 from . import hip_ops
-                return hip_ops.bias_act_nchw_(y, self.bias, self.relu)
+                return hip_ops.bias_act_nchw_(y, self.bias, self.relu, out=out)
             y = y + self.bias.view(1, -1, 1, 1)
-            return F.relu_(y) if self.relu else y
+            y = F.relu_(y) if self.relu else y
+            return y if out is None else out.copy_(y)
         if self.transposed:
             y = F.conv_transpose2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
         else:
             y = F.conv2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
-        return F.relu_(y) if self.relu else y
+        y = F.relu_(y) if self.relu else y
+        return y if out is None else out.copy_(y)
 
 
 def fold_stack(modules, dtype, channels_last):

@@ -227,7 +227,10 @@ int fd_pillar_scatter(const void *feats, int c, int feat_stride, int dtype, cons
 /* In-place per-channel bias (+ReLU when relu != 0) on a contiguous NCHW float32 map with H*W % 4 == 0: the folded
  * BatchNorm shift + activation after each RPN / head convolution (det3d/models/necks/rpn.py:124-142,
  * det3d/models/bbox_heads/center_head.py:129-143) when the convolution itself runs in MIOpen without an epilogue. */
-int fd_bias_act_nchw_f32(float *x, const float *bias, int B, int C, int64_t hw, int relu, fd_stream_t stream);
+int fd_bias_act_nchw_f32(float *x, const float *bias, int B, int C, int64_t hw, int relu, float *dst,
+                         int64_t dst_batch_stride, fd_stream_t stream);
+/* dst == NULL: in place.  Otherwise the result goes to dst[b * dst_batch_stride + c * hw + p] -- the channel slice of a
+ * wider NCHW buffer, which is how the RPN's torch.cat of the deblock outputs (rpn.py:156-157) is written in place. */
 
 /* ---------------------------------------------------------------------------------------------------
  * Forecast association: the numeric core of `tracker` (det3d/datasets/nuscenes/nuscenes.py:125-257), `match_boxes`
