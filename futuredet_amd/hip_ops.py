@@ -494,3 +494,14 @@ def bias_act_nchw_(x, bias, relu, out=None):
     check(_lib.load().fd_bias_act_nchw_f32(_p(x), _p(bias), B, C, H * W, int(bool(relu)), _p(out), out.stride(0), _stream()),
           "fd_bias_act_nchw_f32")
     return out
+
+
+def shuffle_bias_act(y, bias, cout, k, relu, out=None):
+    """fd_shuffle_bias_act_f32: y [B, k*k*cout, H, W] -> [B, cout, H*k, W*k] (+bias, +ReLU), optionally into a channel slice."""
+    B, _, H, W = y.shape
+    if out is None:
+        out = torch.empty((B, cout, H * k, W * k), dtype=torch.float32, device=y.device)
+    assert out.shape == (B, cout, H * k, W * k) and out.stride()[1:] == (H * k * W * k, W * k, 1)
+    check(_lib.load().fd_shuffle_bias_act_f32(_p(y), _p(bias), B, cout, H, W, k, int(bool(relu)), _p(out), out.stride(0), _stream()),
+          "fd_shuffle_bias_act_f32")
+    return out

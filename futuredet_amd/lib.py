@@ -77,6 +77,7 @@ SIGNATURES = {
     "fd_index_pyramid_coords": (c_int, [c_int, c_int, ctypes.POINTER(IndexLevel), c_void_p]),
     "fd_rows_place": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p,
                               c_int, c_int, c_void_p]),
+    "fd_shuffle_bias_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "fd_sweep_assemble_workspace_bytes": (c_size_t, [c_i64]),
     "fd_sweep_assemble": (c_int, [c_void_p, c_int, c_int, c_i64, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

@@ -86,6 +86,14 @@ class FoldedConv(object):
         if (FoldedConv.fuse_relu and x.is_cuda and x.dtype == torch.float32 and self.bias is not None and x.is_contiguous()):
             # fp32 NCHW on the GPU: MIOpen's Winograd / GEMM kernels have no epilogue (torch.miopen_convolution_relu runs
             # conv + add + clamp as three kernels here), so the folded-BN shift and the ReLU are one HIP pass in place
+            if self.transposed and self.padding == 0 and self.weight.shape[-1] == self.stride:
+                # kernel = stride: a 1x1 convolution to k*k*Cout channels + a fused shuffle/bias/ReLU pass
+                from . import hip_ops
+                k = self.stride
+                if getattr(self, "_w1x1", None) is None:  # [Cin, Cout, k, k] -> [(dy,dx,Cout), Cin, 1, 1]
+                    self._w1x1 = self.weight.permute(2, 3, 1, 0).reshape(-1, self.weight.shape[0], 1, 1).contiguous()
+                y = F.conv2d(x, self._w1x1, None)
+                return hip_ops.shuffle_bias_act(y, self.bias, self.weight.shape[1], k, self.relu, out=out)
             if self.transposed:
                 y = F.conv_transpose2d(x, self.weight, None, stride=self.stride, padding=self.padding)
             else:

@@ -273,6 +273,12 @@ int fd_rows_place(const uint64_t *words, const int32_t *prefix, int B, int D, in
                   const int32_t *n_dev, int64_t n_max, const float *src, int c_src, void *dst, int c_dst, int dst_bf16,
                   fd_stream_t stream);
 
+/* Epilogue of a ConvTranspose2d with kernel = stride = k (det3d/models/necks/rpn.py:81-94) computed as a 1x1 convolution to
+ * k*k*cout channels: y [B, k*k*cout, H, W] (channel = (dy*k+dx)*cout + co) -> dst[b*dst_batch_stride + (co*H*k + i*k+dy)*W*k
+ * + j*k+dx] = act(y + bias[co]); dst may be the channel slice of the concatenated RPN output. */
+int fd_shuffle_bias_act_f32(const float *y, const float *bias, int B, int cout, int H, int W, int k, int relu, float *dst,
+                            int64_t dst_batch_stride, fd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
