@@ -277,17 +277,23 @@ template <int CIN, int COUT, int TM, int DEPTH>
 int launch_compact(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
                    int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, const int *tile_order, hipStream_t stream) {
     const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxTaps * (TM / 16) + 112 + 64 + sizeof(float) * (TM + 1) * COUT;
+    static const size_t lds_pad = getenv("FD_V2_LDSPAD") ? (size_t)atoi(getenv("FD_V2_LDSPAD")) : 0;  // occupancy experiments
+    // Occupancy is not a lever here: MFMA and non-MFMA instructions of the waves sharing a SIMD execute almost serially
+    // (128 channels: one workgroup per CU is only 9 % slower than two), and for the 64->64 layers two workgroups per
+    // CU beat the three that would fit (300 -> 278 us: less contention in the gather path), so their LDS request is
+    // rounded up to just over a third of the CU's 160 KB.
+    const size_t lds_req = (CIN == 64 && COUT == 64 && TM == 128 && !lds_pad ? (lds > 56 * 1024 ? lds : (size_t)56 * 1024) : lds) + lds_pad;
     static bool attr_set = false;
     auto kern = spconv_f32_compact<CIN, COUT, TM, DEPTH>;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
         attr_set = true;
     }
     dim3 grid((unsigned)((n_out + TM - 1) / TM));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, in, (const float4 *)wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, tile_order);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_req, stream, in, (const float4 *)wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, tile_order);
     return 1;
 }
 
