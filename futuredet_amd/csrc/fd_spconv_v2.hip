@@ -155,14 +155,15 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         e = lst[lrow];
         rows = *reinterpret_cast<const i32x4 *>(lst + lq * 4);
     };
-    auto stage_b = [&](int kk, int e, const i32x4 &rows_in, i32x4 &rows, u32x4(&a)[NC]) {
+    auto stage_b = [&](int kk, int e, const i32x4 &rows_in, i32x4 &rows, u32x4(&a)[NC]) -> unsigned {
         rows = rows_in;
         // byte offset of the input row = (e >> 8) * CIN * 4, computed on the masked entry without a multiply
         const unsigned hi = (unsigned)e & 0xffffff00u;
         const unsigned voff = (CIN >= 64 ? hi << (CIN == 128 ? 1 : 0) : hi >> (CIN == 32 ? 1 : 2)) + (unsigned)(lq * 16);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) a[c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + c * 64, 0, 0);
+        (void)a;
+        return voff;
     };
+    auto gather_chunk = [&](unsigned voff, int c) { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + c * 64, 0, 0); };
     auto load_b = [&](int k, float4(&dst)[NC][NBW]) {
         const float4 *wk = wp + ((int64_t)k * NC * NB + wc * NBW) * 64 + lane;
 #pragma unroll
@@ -182,7 +183,9 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) {
         stage_a1(d, stage_a0(d), k_s, e_s, rows_s);
-        stage_b(k_s, e_s, rows_s, rows_r[d], a_r[d]);
+        const unsigned vo = stage_b(k_s, e_s, rows_s, rows_r[d], a_r[d]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) a_r[d][c] = gather_chunk(vo, c);
         k_r[d] = k_s;
     }
     k_r[DEPTH - 1] = -1;
@@ -222,10 +225,11 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
             // refill the slot freed by the previous item BEFORE this item's MFMAs (left to itself hipcc sinks the loads
             // below the MFMA block and waits vmcnt(0) for them at the top of the next item), then advance the two
             // bookkeeping stages; their results are first touched in the next iteration.
+            const int dn = (d + DEPTH - 1) % DEPTH;  // compile-time after unrolling
+            unsigned vo;
             {
-                const int dn = (d + DEPTH - 1) % DEPTH;  // compile-time after unrolling
                 const int it = i0 + d + DEPTH - 1;
-                stage_b(k_s, e_s, rows_s, rows_r[dn], a_r[dn]);
+                vo = stage_b(k_s, e_s, rows_s, rows_r[dn], a_r[dn]);
                 k_r[dn] = k_s;
                 stage_a1(it + 1, code_s, k_s, e_s, rows_s);
                 code_s = stage_a0(it + 2);
@@ -238,12 +242,20 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     mfma_chunk(a_r[d][c], b[c], acc);
+                    a_r[dn][c] = gather_chunk(vo, c);  // the gather of item i+DEPTH-1 is spread between the MFMAs
 #pragma unroll
                     for (int nw = 0; nw < NBW; ++nw) b[c][nw] = wk[(c * NB + nw) * 64];
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NBW, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1 + NBW, 0);
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) mfma_chunk(a_r[d][c], b[c], acc);
+                for (int c = 0; c < NC; ++c) {
+                    mfma_chunk(a_r[d][c], b[c], acc);
+                    a_r[dn][c] = gather_chunk(vo, c);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NBW, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
             }
 #pragma unroll
             for (int nw = 0; nw < NBW; ++nw)
