@@ -505,3 +505,21 @@ def shuffle_bias_act(y, bias, cout, k, relu, out=None):
     check(_lib.load().fd_shuffle_bias_act_f32(_p(y), _p(bias), B, cout, H, W, k, int(bool(relu)), _p(out), out.stride(0), _stream()),
           "fd_shuffle_bias_act_f32")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ forecast association
+def forecast_chains(centers, velocity, counts, time, reject_thresh):
+    """fd_forecast_chains on device tensors: centers/velocity [T,n,3] float64, counts [T] int32, time [T-1] float64."""
+    L = _lib.load()
+    centers = _dev(centers, "centers", torch.float64)
+    velocity = _dev(velocity, "velocity", torch.float64)
+    T, n, _ = centers.shape
+    dev = centers.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    out = dict(fwd_idx=torch.zeros((n, T), **i32), fwd_ok=torch.zeros((n,), **i32), bwd_idx=torch.zeros((n, T), **i32),
+               bwd_ok=torch.zeros((n,), **i32), match_idx=torch.zeros((T, n), **i32),
+               cv_centers=torch.zeros((n, T, 3), dtype=torch.float64, device=dev), status=torch.zeros((1,), **i32))
+    check(L.fd_forecast_chains(_p(centers), _p(velocity), _p(counts), _p(time), T, n, float(reject_thresh), _p(out["fwd_idx"]),
+                               _p(out["fwd_ok"]), _p(out["bwd_idx"]), _p(out["bwd_ok"]), _p(out["match_idx"]), _p(out["cv_centers"]),
+                               _p(out["status"]), _stream()), "fd_forecast_chains")
+    return out

@@ -287,3 +287,14 @@ def test_load_point_cloud_class_resolves_and_rejects_other_datasets():
     assert stage.type == "NuScenesDataset"
     with pytest.raises(NotImplementedError):
         build_from_cfg(dict(type="LoadPointCloudFromFile", dataset="WaymoDataset"), PIPELINES)({"lidar": {}}, {})
+
+
+def test_hip_ops_exposes_every_wrapper():
+    """Guards the Python front end against accidental deletions: every op family has its wrapper."""
+    from futuredet_amd import hip_ops
+
+    for name in ("voxelize", "SparseIndex", "build_pyramid", "tile_order_for", "rows_permute", "pack_spconv_weight", "spconv_apply",
+                 "densify", "pack_conv2d_weight", "conv2d_nhwc_bf16", "make_decode_cfg", "centerpoint_decode", "rotated_nms",
+                 "boxes_iou_bev", "sweep_descriptors", "assemble_sweeps", "pillar_encode", "pillar_scatter", "bias_act_nchw_",
+                 "shuffle_bias_act", "forecast_chains"):
+        assert hasattr(hip_ops, name), name
