@@ -236,25 +236,34 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
             }
             const int knext = k_r[(d + 1) % DEPTH];                 // tap of the next item (-1 past the end), wave-uniform
             const bool reload = knext >= 0 && knext != k_r[d];      // this is the last item of its tap
+            // narrow layers (fewer than 16 MFMAs per item) have too little matrix work between the loads for the
+            // interleaving to pay: their gather goes out in one piece in front of the MFMAs
+            constexpr bool kSpread = NC * 4 * NBW >= 16;
+            if constexpr (!kSpread) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) a_r[dn][c] = gather_chunk(vo, c);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (reload) {
                 const float4 *wk = wp + ((int64_t)knext * NC * NB + wc * NBW) * 64 + lane;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     mfma_chunk(a_r[d][c], b[c], acc);
-                    a_r[dn][c] = gather_chunk(vo, c);  // the gather of item i+DEPTH-1 is spread between the MFMAs
+                    if constexpr (kSpread) a_r[dn][c] = gather_chunk(vo, c);  // the gather of item i+DEPTH-1 is spread between the MFMAs
 #pragma unroll
                     for (int nw = 0; nw < NBW; ++nw) b[c][nw] = wk[(c * NB + nw) * 64];
                     __builtin_amdgcn_sched_group_barrier(0x008, 4 * NBW, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1 + NBW, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, (kSpread ? 1 : 0) + NBW, 0);
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     mfma_chunk(a_r[d][c], b[c], acc);
-                    a_r[dn][c] = gather_chunk(vo, c);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NBW, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if constexpr (kSpread) {
+                        a_r[dn][c] = gather_chunk(vo, c);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NBW, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
                 }
             }
 #pragma unroll
