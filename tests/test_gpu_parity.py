@@ -789,3 +789,41 @@ def test_voxelnet_bf16_end_to_end_vs_fp32_oracle(hip):
         d = np.abs(gb[gl == l][:, :2] - b[:2]).max(1) if (gl == l).any() else np.array([9.0])
         found += d.min() < 0.3
     assert found >= 0.9 * strong.sum(), (found, strong.sum())
+
+
+def test_full_size_backbone_is_deterministic_and_linear(hip):
+    """Size-independent properties at the bench size (300k-point cloud, all 21 sparse convs): the HIP backbone has no
+    atomics and a fixed summation order, so two runs agree bit for bit; and with BatchNorm folded and ReLU removed from
+    a single SubM conv the op is linear: conv(a*x + y) == a*conv(x) + conv(y) within fp32 rounding."""
+    from futuredet_amd import build_detector
+    from futuredet_amd.configs import centerpoint_config
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
+
+    cfg = centerpoint_config("forecast_n0")
+    net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    net.load_state_dict(seeded_state_dict(net, 7), strict=False)
+    net = net.cuda().eval()
+    cloud = [_dev(synthetic_cloud(seed=0, target_points=300000))]
+    outs = []
+    for _ in range(2):
+        b, s, l, c = net.forward_points(cloud, cfg.voxel_generator, padded=True)
+        outs.append((b.clone(), s.clone(), l.clone(), c.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    # linearity of one full-size 64->64 SubM convolution (level-2 geometry taken from the same cloud)
+    bb = net.backbone
+    vg = cfg.voxel_generator
+    vox = hip.voxelize(cloud[0], vg["voxel_size"], vg["range"], 10, vg["max_voxel_num"][1], want_voxels=False, want_mean=True,
+                       mean_stride=16, coor_cols=4)
+    idx = bb.build_indexes(None, 1, [1440, 1440, 40], torch.device("cuda"), voxels=(vox["coors"], vox["num_voxels"], vg["max_voxel_num"][1]))
+    i2 = idx[2]
+    nbr = i2.rulebook(i2, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    g = torch.Generator("cuda").manual_seed(3)
+    w = torch.randn((27, 64, 64), device="cuda", generator=g) * 0.05
+    wpk = hip.pack_spconv_weight(w)
+    x = torch.randn((i2.n, 64), device="cuda", generator=g)
+    y = torch.randn((i2.n, 64), device="cuda", generator=g)
+    f = lambda t: hip.spconv_apply(t, wpk, None, nbr, i2.n, 64)  # noqa: E731
+    lhs, rhs = f(2.5 * x + y), 2.5 * f(x) + f(y)
+    assert i2.n > 100000
+    assert float((lhs - rhs).abs().max()) <= 1e-4 * float(rhs.abs().max())
