@@ -37,8 +37,12 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     constexpr int NB = COUT / 16, NC = CIN / 16;
     constexpr int WC = NB == 8 ? 4 : (NB >= 2 ? 2 : 1);  // column splits across the 4 waves (64 columns: 2 x 32)
     constexpr int NBW = NB / WC;          // 16-column blocks per wave
-    constexpr int WR = 4 / WC;            // row splits
-    constexpr int RW = TM / WR;           // rows in a wave's row set
+    // 64 columns: instead of two row halves (whose separately compacted lists pad 17 % more MFMA rows) the two waves of a
+    // column slice split the TAPS (even / odd) over the full tile and accumulate into private copies of the tile that
+    // the epilogue adds up; the LDS for the second copy is there anyway (these layers run two workgroups per CU).
+    constexpr int TS = (NB == 4) ? 2 : 1;         // tap splits
+    constexpr int WR = 4 / (WC * TS);             // row splits
+    constexpr int RW = TM / WR;                   // rows in a wave's row set
     constexpr int NACC = NBW;  // one accumulator chain per column block (dependent 16x16x4 MFMAs issue back to back at full rate)
     static_assert((TM == 128 || TM == 64) && RW >= 16, "local row uses 8 bits (0..TM, TM = scratch row)");
     constexpr int kMaxItems = kMaxTaps * (TM / 16);           // per wave: taps x 16-row groups
@@ -60,7 +64,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         int64_t o = (int64_t)row0 + r;
         s_list[t] = (o < nbr_stride) ? nbr[(int64_t)k * nbr_stride + o] : -1;
     }
-    for (int t = tid; t < (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = tid; t < TS * (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 16) s_pad[tid] = kPad;
     __syncthreads();
     // ---- in-place compaction: wave w takes taps w, w+4, ...; tails are filled with kPad
@@ -94,18 +98,18 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     __syncthreads();
 
     const int lrow = lane & 15, lq = lane >> 4;
-    const int wc = wave % WC, wr = wave / WC;
+    const int wc = wave % WC, wr = TS == 1 ? wave / WC : 0, ts = TS == 1 ? 0 : wave / WC;
     const int cb = wc * NBW * 16;
     constexpr int kRowShift = COUT == 16 ? 6 : COUT == 32 ? 7 : COUT == 64 ? 8 : 9;  // log2(COUT * 4)
     static_assert((COUT * 4) == (1 << kRowShift), "COUT must be 16, 32, 64 or 128");
-    unsigned char *acc_bytes = reinterpret_cast<unsigned char *>(s_acc);
+    unsigned char *acc_bytes = reinterpret_cast<unsigned char *>(s_acc + ts * (TM + 1) * COUT);  // this wave's tile copy
     const unsigned lane_off = (unsigned)(cb + lrow) * 4u;
     // ---- flattened work list of this wave: one item = 16 compacted pairs of one tap, code = (tap << 3) | group
     unsigned short *items = s_items + wave * kMaxItems;
     int n_items;
     unsigned long long tapmask;
     {
-        const int ng = (lane < K) ? ((int)s_cnt[lane * 4 + wr] + 15) >> 4 : 0;
+        const int ng = (lane < K && (TS == 1 || (lane & 1) == ts)) ? ((int)s_cnt[lane * 4 + wr] + 15) >> 4 : 0;
         tapmask = __ballot(ng > 0);
         int inc = ng;
 #pragma unroll
@@ -281,6 +285,10 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         const int row = row0 + r;
         if (row >= n_out) break;
         float4 v = reinterpret_cast<const float4 *>(s_acc)[t];
+        if constexpr (TS == 2) {
+            const float4 v2 = reinterpret_cast<const float4 *>(s_acc + (TM + 1) * COUT)[t];
+            v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
+        }
         if (bias) {
             const float4 bv = reinterpret_cast<const float4 *>(bias)[c4];
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
@@ -297,7 +305,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 template <int CIN, int COUT, int TM, int DEPTH>
 int launch_compact(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
                    int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, const int *tile_order, hipStream_t stream) {
-    const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxTaps * (TM / 16) + 112 + 64 + sizeof(float) * (TM + 1) * COUT;
+    const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxTaps * (TM / 16) + 112 + 64 + sizeof(float) * (TM + 1) * COUT * (COUT == 64 ? 2 : 1);
     static const size_t lds_pad = getenv("FD_V2_LDSPAD") ? (size_t)atoi(getenv("FD_V2_LDSPAD")) : 0;  // occupancy experiments
     // Occupancy is not a lever here: MFMA and non-MFMA instructions of the waves sharing a SIMD execute almost serially
     // (128 channels: one workgroup per CU is only 9 % slower than two), and for the 64->64 layers two workgroups per
