@@ -37,10 +37,10 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     constexpr int NB = COUT / 16, NC = CIN / 16;
     constexpr int WC = NB == 8 ? 4 : (NB >= 2 ? 2 : 1);  // column splits across the 4 waves (64 columns: 2 x 32)
     constexpr int NBW = NB / WC;          // 16-column blocks per wave
-    // 64 columns: instead of two row halves (whose separately compacted lists pad 17 % more MFMA rows) the two waves of a
+    // 32 / 64 columns: instead of two row halves (whose separately compacted lists pad 17 % more MFMA rows) the two waves of a
     // column slice split the TAPS (even / odd) over the full tile and accumulate into private copies of the tile that
     // the epilogue adds up; the LDS for the second copy is there anyway (these layers run two workgroups per CU).
-    constexpr int TS = (NB == 4) ? 2 : 1;         // tap splits
+    constexpr int TS = (NB == 2 || NB == 4) ? 2 : 1;  // tap splits (16 columns keep four row quarters: measured faster)
     constexpr int WR = 4 / (WC * TS);             // row splits
     constexpr int RW = TM / WR;                   // rows in a wave's row set
     constexpr int NACC = NBW;  // one accumulator chain per column block (dependent 16x16x4 MFMAs issue back to back at full rate)
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     int n_items;
     unsigned long long tapmask;
     {
-        const int ng = (lane < K && (TS == 1 || (lane & 1) == ts)) ? ((int)s_cnt[lane * 4 + wr] + 15) >> 4 : 0;
+        const int ng = (lane < K && (lane % TS) == ts) ? ((int)s_cnt[lane * 4 + wr] + 15) >> 4 : 0;
         tapmask = __ballot(ng > 0);
         int inc = ng;
 #pragma unroll
@@ -285,8 +285,9 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         const int row = row0 + r;
         if (row >= n_out) break;
         float4 v = reinterpret_cast<const float4 *>(s_acc)[t];
-        if constexpr (TS == 2) {
-            const float4 v2 = reinterpret_cast<const float4 *>(s_acc + (TM + 1) * COUT)[t];
+#pragma unroll
+        for (int q = 1; q < TS; ++q) {
+            const float4 v2 = reinterpret_cast<const float4 *>(s_acc + q * (TM + 1) * COUT)[t];
             v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
         }
         if (bias) {
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
 template <int CIN, int COUT, int TM, int DEPTH>
 int launch_compact(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
                    int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, const int *tile_order, hipStream_t stream) {
-    const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxTaps * (TM / 16) + 112 + 64 + sizeof(float) * (TM + 1) * COUT * (COUT == 64 ? 2 : 1);
+    const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxTaps * (TM / 16) + 112 + 64 + sizeof(float) * (TM + 1) * COUT * (COUT == 32 || COUT == 64 ? 2 : 1);
     static const size_t lds_pad = getenv("FD_V2_LDSPAD") ? (size_t)atoi(getenv("FD_V2_LDSPAD")) : 0;  // occupancy experiments
     // Occupancy is not a lever here: MFMA and non-MFMA instructions of the waves sharing a SIMD execute almost serially
     // (128 channels: one workgroup per CU is only 9 % slower than two), and for the 64->64 layers two workgroups per
