@@ -24,11 +24,6 @@ def conv3x3(in_planes, out_planes, stride=1, indice_key=None, bias=True):
                              indice_key=indice_key)
 
 
-def conv1x1(in_planes, out_planes, stride=1, indice_key=None, bias=True):
-    return spconv.SubMConv3d(in_planes, out_planes, kernel_size=1, stride=stride, padding=1, bias=bias,
-                             indice_key=indice_key)
-
-
 class SparseBasicBlock(spconv.SparseModule):
     expansion = 1
 
@@ -62,8 +57,6 @@ class SpMiddleResNetFHD(nn.Module):
     def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleResNetFHD", **kwargs):
         super().__init__()
         self.name = name
-        self.dcn = None
-        self.zero_init_residual = False
         if norm_cfg is None:
             norm_cfg = dict(type="BN1d", eps=1e-3, momentum=0.01)
         S = spconv.SparseSequential

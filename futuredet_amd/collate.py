@@ -1,5 +1,5 @@
-"""Batch assembly for the path: collate_kitti_multi's hot keys (det3d/torchie/parallel/collate.py:163-245) and
-example_to_device (det3d/torchie/apis/train.py:28-71)."""
+"""Batch assembly for the path: collate_kitti_multi's hot keys (det3d/torchie/parallel/collate.py:163-245),
+example_to_device (det3d/torchie/apis/train.py:28-71) and the inference branch of batch_processor (:106-126)."""
 import collections
 
 import numpy as np
@@ -40,3 +40,15 @@ def example_to_device(example, device, non_blocking=False):
         else:
             out[k] = v
     return out
+
+
+def batch_processor(model, data, train_mode, **kwargs):
+    """det3d/torchie/apis/train.py:106-126, the call tools/dist_test.py:177 makes per batch: move the collated example to
+    the rank's device (``local_rank`` keyword) and run the detector.  Only the inference branch exists on this path."""
+    if train_mode:
+        raise NotImplementedError("training (losses, optimiser) is outside the inference hot path (SURVEY 2)")
+    device = torch.device("cuda", kwargs["local_rank"]) if "local_rank" in kwargs else None
+    assert device is not None, "batch_processor needs local_rank (the reference asserts the same in example_to_device)"
+    example = example_to_device(data, device, non_blocking=False)
+    del data
+    return model(example, return_loss=False)

@@ -27,7 +27,7 @@ def install_det3d_alias(force=False):
         return False
     if existing is not None and getattr(existing, "__futuredet_amd_alias__", False):
         return True
-    from . import config, config_tool, detectors, nms, registry, voxelize
+    from . import apis, collate, config, config_tool, detectors, dist_infer, nms, registry, voxelize
     from . import backbones, heads, necks, readers  # noqa: F401  (populate the registries)
 
     _mod("det3d")
@@ -37,7 +37,17 @@ def install_det3d_alias(force=False):
     _mod("det3d.torchie", Config=config.Config, ConfigDict=config.ConfigDict)
     _mod("det3d.torchie.utils", Config=config.Config, ConfigDict=config.ConfigDict)
     _mod("det3d.torchie.utils.config", Config=config.Config, ConfigDict=config.ConfigDict)
-    _mod("det3d.torchie.trainer", load_checkpoint=detectors.load_checkpoint)
+    _mod("det3d.torchie.trainer", load_checkpoint=detectors.load_checkpoint, get_dist_info=dist_infer.get_dist_info)
+    _mod("det3d.torchie.trainer.utils", all_gather=dist_infer.all_gather, synchronize=dist_infer.synchronize,
+         get_dist_info=dist_infer.get_dist_info)
+    _mod("det3d.torchie.trainer.checkpoint", load_checkpoint=detectors.load_checkpoint)
+    # tools/dist_test.py:141,177,220 reach the path through these two (det3d/torchie/apis/train.py:28-71,106-126)
+    _mod("det3d.torchie.apis", batch_processor=collate.batch_processor, example_to_device=collate.example_to_device,
+         get_root_logger=apis.get_root_logger, set_random_seed=apis.set_random_seed, init_dist=apis.init_dist,
+         build_optimizer=apis.build_optimizer, train_detector=apis.train_detector)
+    _mod("det3d.torchie.apis.train", batch_processor=collate.batch_processor, example_to_device=collate.example_to_device)
+    _mod("det3d.torchie.parallel")
+    _mod("det3d.torchie.parallel.collate", collate_kitti_multi=collate.collate_kitti_multi, collate_kitti=collate.collate_kitti_multi)
     names = ("READERS", "BACKBONES", "NECKS", "HEADS", "LOSSES", "DETECTORS", "SECOND_STAGE", "ROI_HEAD")
     regs = {n: getattr(registry, n) for n in names}
     builders = {n: getattr(registry, n) for n in ("build_reader", "build_backbone", "build_neck", "build_head",
@@ -45,7 +55,8 @@ def install_det3d_alias(force=False):
     _mod("det3d.models", **regs, **builders)
     _mod("det3d.models.registry", **regs)
     _mod("det3d.models.builder", **builders)
-    _mod("det3d.datasets", PIPELINES=registry.PIPELINES, DATASETS=registry.DATASETS)
+    _mod("det3d.datasets", PIPELINES=registry.PIPELINES, DATASETS=registry.DATASETS,
+         build_dataset=apis._training_only("build_dataset (dataset / devkit code"), build_dataloader=apis._training_only("build_dataloader (dataset code"))
     _mod("det3d.datasets.registry", PIPELINES=registry.PIPELINES, DATASETS=registry.DATASETS)
     _mod("det3d.core")
     _mod("det3d.core.input")

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/futuredet_hip.h"
 
 namespace fd {
@@ -31,6 +33,20 @@ inline int check_launch(const char *what) {
     } while (0)
 
 inline hipStream_t as_stream(fd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- per-process state (fd_error.hip).  The library keeps NO per-call mutable state; what it caches is
+//      keyed by device ordinal and published with atomics, so calls from several threads / for several
+//      devices of one process are safe.
+constexpr int kMaxDevices = 64;
+int current_device();   // hipGetDevice (0 when the runtime cannot tell)
+int device_cu_count();  // compute units of the current device, cached per device
+// Kernels that need more than 64 KB of dynamic LDS must be told so once per (kernel, device).  `done` is the
+// kernel instantiation's own bit mask of devices already configured.  Returns false when the runtime refuses.
+bool ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done);
+// Tuning / test knobs (fd_tuning_set; initial values are read ONCE from the FD_* environment variables when the
+// library is loaded).  0 = the built-in heuristic.
+enum TuneKey { kTuneSpconvRG = 0, kTuneSpconvV1, kTuneSpconvBf16V1, kTuneV2Depth, kTuneV2TM, kTuneV2LdsPad, kTuneConvNT, kTuneCount };
+int tuning(TuneKey key);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

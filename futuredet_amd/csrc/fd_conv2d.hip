@@ -227,19 +227,15 @@ void launch_conv(const void *x, const void *wp, const float *bias, void *y, cons
     size_t lds = 2 * (size_t)PH * PW * 64;
     if (lds < (size_t)TH * TW * NT * 2) lds = (size_t)TH * TW * NT * 2;  // the epilogue transposes the tile through LDS
     auto kern = conv2d_nhwc_bf16<KS, S, WMT, WNT, WAVES_M, WAVES_N>;
-    static bool attr = false;
-    if (!attr && lds > 65536) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    static std::atomic<uint64_t> lds_set{0};
+    if (lds > 65536) (void)fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_set);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)(p.Cout_pad / NT));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const unsigned short *)x, (const bf16x8 *)wp, bias, (unsigned short *)y, p);
 }
 
 template <int KS, int S>
 int dispatch_nt(const void *x, const void *wp, const float *bias, void *y, const ConvParams &p, hipStream_t stream) {
-    const char *e = getenv("FD_CONV_NT");  // tuning override
-    const int force = e ? atoi(e) : 0;
+    const int force = fd::tuning(fd::kTuneConvNT);  // tuning override
     if (p.Cout_pad % 128 == 0 && force != 64 && force != 32) launch_conv<KS, S, 2, 2, 2, 2>(x, wp, bias, y, p, stream);
     else if (p.Cout_pad % 64 == 0 && force != 32) launch_conv<KS, S, 1, 2, 4, 1>(x, wp, bias, y, p, stream);
     else launch_conv<KS, S, 1, 1, 4, 1>(x, wp, bias, y, p, stream);

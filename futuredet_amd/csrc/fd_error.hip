@@ -1,5 +1,8 @@
-// Error reporting for the C ABI: thread-local last-error text, never exit().
+// Process-level pieces of the C ABI: thread-local last-error text (never exit()), per-device caches and the
+// tuning knobs.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "fd_common.h"
 
@@ -11,7 +14,76 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return dev;
+}
+
+int device_cu_count() {
+    static std::atomic<int> cache[kMaxDevices];  // zero-initialised; racing first calls store the same value
+    const int dev = current_device();
+    if (dev < 0 || dev >= kMaxDevices) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            n = 256;
+        }
+        cache[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+bool ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done) {
+    const int dev = current_device();
+    const uint64_t bit = (dev >= 0 && dev < kMaxDevices) ? (1ull << dev) : 0ull;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return true;
+    // idempotent: two threads racing here both set the same attribute value
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (bit) done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
+
+namespace {
+struct TuneTable {
+    std::atomic<int> v[kTuneCount];
+    TuneTable() {
+        static const char *const env[kTuneCount] = {"FD_SPCONV_RG", "FD_SPCONV_V1", "FD_SPCONV_BF16_V1", "FD_V2_DEPTH", "FD_V2_TM",
+                                                    "FD_V2_LDSPAD", "FD_CONV_NT"};
+        for (int i = 0; i < kTuneCount; ++i) {
+            const char *e = getenv(env[i]);
+            v[i].store(e ? atoi(e) : 0, std::memory_order_relaxed);
+        }
+    }
+};
+TuneTable &tune_table() {
+    static TuneTable t;  // constructed once, thread-safe (C++11); the environment is read here and nowhere else
+    return t;
+}
+const char *const kTuneNames[kTuneCount] = {"spconv_rg", "spconv_v1", "spconv_bf16_v1", "v2_depth", "v2_tm", "v2_ldspad", "conv_nt"};
+}  // namespace
+
+int tuning(TuneKey key) { return tune_table().v[key].load(std::memory_order_relaxed); }
 }  // namespace fd
 
 extern "C" const char *fd_last_error(void) { return fd::g_err; }
-extern "C" int fd_abi_version(void) { return 1; }
+extern "C" int fd_abi_version(void) { return 2; }
+
+extern "C" int fd_tuning_set(const char *name, int value) {
+    FD_REQUIRE(name, "fd_tuning_set: null name");
+    for (int i = 0; i < fd::kTuneCount; ++i)
+        if (strcmp(name, fd::kTuneNames[i]) == 0) {
+            fd::tune_table().v[i].store(value, std::memory_order_relaxed);
+            return FD_OK;
+        }
+    fd::set_error("fd_tuning_set: unknown knob '%s'", name);
+    return FD_EINVAL;
+}

@@ -358,8 +358,7 @@ void launch_rg(const LaunchArgs &a, int dtype, int rg) {
 }
 
 int pick_rg(int64_t n_out, int cin, int cout) {
-    const char *e = getenv("FD_SPCONV_RG");  // tuning / test override
-    const int forced = e ? atoi(e) : 0;
+    const int forced = fd::tuning(fd::kTuneSpconvRG);  // tuning / test override (fd_tuning_set)
     if (forced > 0) return forced;
     // Measured on MI355X (tools/spconv_bench.py, 300k-point cloud): the kernel is bound by the L2->L1 weight stream
     // (every wave reads all of W[k] per tap), so more rows per wave (RG) help until the wave count drops below
@@ -432,13 +431,13 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
     FD_REQUIRE(n_out >= 0 && n_out <= nbr_stride && n_out < (1ll << 31), "fd_spconv_apply: n_out out of range");
     if (n_out == 0) return FD_OK;  // an empty active set (empty cloud): nothing to compute, buffers may be null
     FD_REQUIRE(in_feats && wpacked && nbr && out_feats, "fd_spconv_apply: null argument");
-    if (dtype == 0 && !getenv("FD_SPCONV_V1")) {
+    if (dtype == 0 && !fd::tuning(fd::kTuneSpconvV1)) {
         // fp32 is MFMA-bound: the pair-compacting kernel (fd_spconv_v2.hip) feeds the matrix core no zero rows
         if (fd::spconv_f32_compact_dispatch((const float *)in_feats, wpacked, bias, (const float *)residual, relu, nbr, nbr_stride, K, n_in,
                                             (int)n_out, cin, cout, (float *)out_feats, tile_order, fd::as_stream(stream)))
             return fd::check_launch("fd_spconv_apply(compact)");
     }
-    if (dtype == 1 && cin >= 32 && cout >= 64 && !getenv("FD_SPCONV_BF16_V1") && n_in * cin * 2 < (1ll << 31)) {
+    if (dtype == 1 && cin >= 32 && cout >= 64 && !fd::tuning(fd::kTuneSpconvBf16V1) && n_in * cin * 2 < (1ll << 31)) {
         // bf16, wide layers: column-split workgroups (shared gather through LDS, per-wave weight slices)
         const unsigned in_bytes = (unsigned)(n_in * cin * 2);
         const dim3 grid((unsigned)((n_out + 63) / 64));

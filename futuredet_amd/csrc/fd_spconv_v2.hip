@@ -307,20 +307,21 @@ template <int CIN, int COUT, int TM, int DEPTH>
 int launch_compact(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
                    int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, const int *tile_order, hipStream_t stream) {
     const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxTaps * (TM / 16) + 112 + 64 + sizeof(float) * (TM + 1) * COUT * (COUT == 32 || COUT == 64 ? 2 : 1);
-    static const size_t lds_pad = getenv("FD_V2_LDSPAD") ? (size_t)atoi(getenv("FD_V2_LDSPAD")) : 0;  // occupancy experiments
+    const size_t lds_pad = (size_t)fd::tuning(fd::kTuneV2LdsPad);  // occupancy experiments
     // Occupancy is not a lever here: MFMA and non-MFMA instructions of the waves sharing a SIMD execute almost serially
     // (128 channels: one workgroup per CU is only 9 % slower than two), and for the 64->64 layers two workgroups per
     // CU beat the three that would fit (300 -> 278 us: less contention in the gather path), so their LDS request is
     // rounded up to just over a third of the CU's 160 KB.
     const size_t lds_req = (CIN == 64 && COUT == 64 && TM == 128 && !lds_pad ? (lds > 56 * 1024 ? lds : (size_t)56 * 1024) : lds) + lds_pad;
-    static bool attr_set = false;
+    static std::atomic<uint64_t> lds_set{0};  // devices on which this instantiation has its LDS limit raised
     auto kern = spconv_f32_compact<CIN, COUT, TM, DEPTH>;
-    if (!attr_set) {
+    if (lds_pad) {  // tuning runs change the request between calls: set it every time
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
-        attr_set = true;
+    } else if (!fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_req, lds_set)) {
+        return 0;
     }
     dim3 grid((unsigned)((n_out + TM - 1) / TM));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds_req, stream, in, (const float4 *)wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, tile_order);
@@ -389,11 +390,7 @@ extern "C" int fd_spconv_tile_order(const int32_t *nbr, int64_t nbr_stride, int 
     FD_REQUIRE(n_tiles >= 1 && n_tiles < (1 << 20), "fd_spconv_tile_order: supports up to 2^20 tiles of 128 rows (got %lld)", (long long)n_tiles);
     FD_REQUIRE(workspace_bytes >= 2 * sizeof(unsigned) * (size_t)n_tiles, "fd_spconv_tile_order: workspace too small");
     hipStream_t stream = fd::as_stream(stream_);
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = fd::device_cu_count();
     unsigned *keys = (unsigned *)workspace;
     int *sorted = (int *)(keys + n_tiles);
     hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)n_tiles), dim3(256), 0, stream, nbr, nbr_stride, K, (int)n_tiles, keys);
@@ -408,10 +405,7 @@ int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bi
     // (input row << 8 | local row) must fit an int32 and the feature matrix a 31-bit buffer range
     if (n_in_bound >= (1ll << 23) || n_in_bound * cin * 4 >= (1ll << 31)) return 0;
     const unsigned in_bytes = (unsigned)(n_in_bound * cin * 4);
-    const char *env = getenv("FD_V2_DEPTH");  // tuning overrides
-    const int dsel = env ? atoi(env) : 0;
-    const char *envt = getenv("FD_V2_TM");
-    const int tsel = envt ? atoi(envt) : 0;
+    const int dsel = fd::tuning(fd::kTuneV2Depth), tsel = fd::tuning(fd::kTuneV2TM);  // tuning overrides
 #define FD_LAUNCH(CI, CO, T, D) \
     launch_compact<CI, CO, T, D>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, (T == 128 ? tile_order : nullptr), stream)
 #define FD_CASE(CI, CO, DDEF, TDEF)                                  \

@@ -134,6 +134,9 @@ class HeadPlan(object):
             B, H, W, _ = x.shape
             if self._cat is None or self._cat[0].shape[:3] != (B, H, W) or self._cat[0].device != x.device:
                 self._cat = [torch.zeros((B, H, W, 2 * hc), dtype=torch.bfloat16, device=x.device) for _ in range(2)]
+            # task 0 reads [x | feats of the previous frame] through zero weights: clear that half so a non-finite value
+            # of an earlier frame (0 * Inf = NaN) cannot leak into this one
+            self._cat[0][..., hc:].zero_()
             last(x, out=self._cat[0], co_off=0)
             self._cat[1][..., :hc].copy_(self._cat[0][..., :hc])
         else:

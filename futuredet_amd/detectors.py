@@ -11,7 +11,10 @@ import torch
 from torch import nn
 
 from . import hip_ops, registry, sparse
+from .nn_utils import weights_version
 from .registry import DETECTORS
+
+_NO_GRAPH = bool(os.environ.get("FD_NO_GRAPH"))  # debugging: run neck + head eagerly
 
 
 class BaseDetector(nn.Module):
@@ -60,10 +63,25 @@ def load_checkpoint(model, filename, map_location="cpu", strict=False):
 class VoxelNet(SingleStageDetector):
     def __init__(self, reader, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None):
         super().__init__(reader, backbone, neck, bbox_head, train_cfg, test_cfg, pretrained)
+        # a captured neck+head graph replays kernels that read the folded / packed weights of the moment of capture
+        self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate_caches())
+
+    def invalidate_caches(self):
+        """Drops the captured hipGraphs (and, through the sub-modules' own hooks / version keys, every derived weight).
+        Called by load_state_dict, set_precision and device moves; call it by hand after writing weights through ``.data``."""
+        self.__dict__.pop("_graphs", None)
+        for m in (self.neck, self.bbox_head):
+            if hasattr(m, "invalidate_caches"):
+                m.invalidate_caches()
+
+    def _apply(self, fn, *a, **kw):
+        self.__dict__.pop("_graphs", None)
+        return super()._apply(fn, *a, **kw)
 
     def set_precision(self, dtype=torch.float32, channels_last=None):
         """fp32 (default) or bf16 conv features/weights with fp32 accumulation; voxelizer, indexes, decode and
         NMS always stay fp32/int."""
+        self.__dict__.pop("_graphs", None)
         if channels_last is None:
             channels_last = False  # measured on MI355X: MIOpen is as fast or faster on NCHW for these shapes
         self.backbone.compute_dtype = dtype
@@ -104,8 +122,14 @@ class VoxelNet(SingleStageDetector):
         MIOpen pick its kernels).  Returns (graph, static BEV input, static prediction dicts) or None."""
         bb = self.backbone
         dt = bb.dense_dtype or bb.compute_dtype
-        key = (B, dt, bb.dense_channels_last, idx4.D, idx4.H, idx4.W, dev)
+        # the weights' version is part of the key: after an in-place update (optimizer step, init_weights, BN statistics)
+        # the old graph would replay kernels that read freed weight buffers
+        ver = weights_version(self.neck, self.bbox_head)
         cache = self.__dict__.setdefault("_graphs", {})
+        if cache.get("version") != ver:
+            cache.clear()
+            cache["version"] = ver
+        key = (B, dt, bb.dense_channels_last, idx4.D, idx4.H, idx4.W, dev)
         if key in cache:
             return cache[key]
         try:
@@ -170,7 +194,7 @@ class VoxelNet(SingleStageDetector):
             hip_ops.check(L.fd_rows_place(hip_ops._p(i0.words), hip_ops._p(i0.prefix), i0.B, i0.D, i0.H, i0.W, hip_ops._p(coors[sl]),
                                           hip_ops._p(nvox[b:b + 1]), max_voxels, hip_ops._p(mean[sl]), cpad, hip_ops._p(feats0), cpad,
                                           hip_ops._DT[bb.compute_dtype], hip_ops._stream()), "fd_rows_place")
-        graph = None if (bev_map is not None or os.environ.get("FD_NO_GRAPH")) else self._dense_graph(B, idx[4], dev)
+        graph = None if (bev_map is not None or _NO_GRAPH) else self._dense_graph(B, idx[4], dev)
         if graph is not None:
             # neck + head have static shapes: replay them as one hipGraph (one launch instead of ~25-60)
             g, static_bev, preds = graph

@@ -28,6 +28,30 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def get_dist_info():
+    """det3d/torchie/trainer/utils.py:22-34 -> (rank, world_size)"""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def synchronize():
+    """det3d/torchie/trainer/utils.py:100-112: barrier among all ranks (no-op single process)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def all_gather(data):
+    """det3d/torchie/trainer/utils.py:115-155 contract (any picklable object in, list with one entry per rank out), as
+    tools/dist_test.py:237 uses it on the token -> detections dict.  Convenience for callers written against the
+    reference; the benchmarked path gathers fixed-shape tensors instead (gather_results)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [data]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, data)
+    return out
+
+
 def shard_indices(n_samples, rank, world):
     """DistributedSampler(shuffle=False) rule (det3d/datasets/loader/build_loader.py:38): rank r takes r, r+W, ...;
     the tail is padded by wrapping so every rank has the same count."""

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import hip_ops
-from .nn_utils import FoldedConv, Sequential, fold_stack, kaiming_init
+from .nn_utils import FoldedConv, Sequential, fold_stack, kaiming_init, weights_version
 from .registry import HEADS
 
 
@@ -49,7 +49,15 @@ class SepHead(nn.Module):
                         kaiming_init(m)
             self.__setattr__(head, fc)
         self._fused = None
-        self.register_load_state_dict_post_hook(lambda m, k: setattr(m, "_fused", None))
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
+
+    def invalidate_caches(self):
+        self._fused = None
+        self.__dict__.pop("_wv_tensors", None)
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_caches()
+        return super()._apply(fn, *a, **kw)
 
     def forward_modules(self, x):
         ret = {}
@@ -63,7 +71,7 @@ class SepHead(nn.Module):
     def _fuse(self, dtype, channels_last):
         """All heads read the same map: their first convs become one conv (Cout = 64*nheads, BN folded, ReLU) and
         their final convs one block-diagonal conv, so a task costs 2 launches instead of 12."""
-        key = (dtype, channels_last, next(self.parameters()).device)
+        key = (dtype, channels_last, next(self.parameters()).device, weights_version(self))
         if self._fused is not None and self._fused[0] == key:
             return self._fused[1:]
         names = list(self.heads)
@@ -112,9 +120,10 @@ class SepHead(nn.Module):
 
 
 
-def _drop_caches(module, incompatible_keys):
+def _drop_caches(module, incompatible_keys=None):
     module._folded = None
     module._plan = None
+    module.__dict__.pop("_wv_tensors", None)
 
 
 @HEADS.register_module
@@ -174,6 +183,12 @@ class CenterHead(nn.Module):
         self.register_load_state_dict_post_hook(_drop_caches)
         self.logger.info("Finish CenterHead Initialization")
 
+    invalidate_caches = _drop_caches
+
+    def _apply(self, fn, *a, **kw):
+        _drop_caches(self)
+        return super()._apply(fn, *a, **kw)
+
     # ----------------------------------------------------------------------------------------------- forward
     def forward_modules(self, x, bev_map=None):
         ret_dicts = []
@@ -191,13 +206,14 @@ class CenterHead(nn.Module):
         if self.training:
             return self.forward_modules(x, bev_map)
         if self.compute_dtype == torch.bfloat16 and x.is_cuda and self.use_hip_conv and not self.bev_map:
-            if self._plan is None:
+            ver = weights_version(self)
+            if self._plan is None or self._plan[0] != ver:
                 from .dense_bf16 import HeadPlan
 
-                self._plan = HeadPlan(self)
-            return self._plan(x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())
+                self._plan = (ver, HeadPlan(self))
+            return self._plan[1](x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())
         dt, cl = self.compute_dtype, self.channels_last
-        key = (dt, cl, next(self.parameters()).device)
+        key = (dt, cl, next(self.parameters()).device, weights_version(self.shared_conv) + (weights_version(self.bev_conv) if self.bev_map else 0))
         if self._folded is None or self._folded[0] != key:
             shared = fold_stack(self.shared_conv, dt, cl)
             bev = fold_stack(self.bev_conv, dt, cl) if self.bev_map else None

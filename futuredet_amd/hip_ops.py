@@ -56,6 +56,11 @@ workspace = _Workspace()
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
 
+def set_tuning(name, value):
+    """fd_tuning_set: kernel-variant knobs for tuning runs and for the tests that compare variants (0 = heuristic)."""
+    check(_lib.load().fd_tuning_set(name.encode(), int(value)), "fd_tuning_set")
+
+
 # ------------------------------------------------------------------------------------------------ voxelizer
 def voxelize(points, voxel_size, coors_range, max_points, max_voxels, batch_idx=0, want_voxels=True, want_mean=False,
              mean_stride=None, coor_cols=3, out=None):

@@ -33,6 +33,7 @@ class IndexLevel(ctypes.Structure):  # struct fd_index_level
 SIGNATURES = {
     "fd_abi_version": (c_int, []),
     "fd_last_error": (ctypes.c_char_p, []),
+    "fd_tuning_set": (c_int, [ctypes.c_char_p, c_int]),
     "fd_voxelize_workspace_bytes": (c_size_t, [c_i64, c_i64]),
     "fd_voxelize": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_int,
                             c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -8,14 +8,15 @@ import numpy as np
 import torch
 from torch import nn
 
-from .nn_utils import Sequential, build_norm_layer, fold_stack
+from .nn_utils import Sequential, build_norm_layer, fold_stack, weights_version
 from .registry import NECKS
 
 
 
-def _drop_caches(module, incompatible_keys):
+def _drop_caches(module, incompatible_keys=None):
     module._folded = None
     module._plan = None
+    module.__dict__.pop("_wv_tensors", None)
 
 
 @NECKS.register_module
@@ -95,8 +96,14 @@ class RPN(nn.Module):
             x = torch.cat(ups, dim=1)
         return x
 
+    invalidate_caches = _drop_caches
+
+    def _apply(self, fn, *a, **kw):  # .to() / .cuda() / .float(): derived weights live on the old device / dtype
+        _drop_caches(self)
+        return super()._apply(fn, *a, **kw)
+
     def _fold(self):
-        key = (self.compute_dtype, self.channels_last, next(self.parameters()).device)
+        key = (self.compute_dtype, self.channels_last, next(self.parameters()).device, weights_version(self))
         if self._folded is None or self._folded[0] != key:
             blocks = [fold_stack(b._modules.values(), self.compute_dtype, self.channels_last) for b in self.blocks]
             deblocks = [fold_stack(d._modules.values(), self.compute_dtype, self.channels_last) for d in self.deblocks]
@@ -108,11 +115,12 @@ class RPN(nn.Module):
             return self.forward_modules(x)
         if self.compute_dtype == torch.bfloat16 and x.is_cuda and self.use_hip_conv:
             # hand-written MFMA convolutions on NHWC bf16; returned as an NCHW-shaped view of the NHWC buffer
-            if self._plan is None:
+            ver = weights_version(self)
+            if self._plan is None or self._plan[0] != ver:
                 from .dense_bf16 import RPNPlan
 
-                self._plan = RPNPlan(self)
-            y = self._plan(x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())
+                self._plan = (ver, RPNPlan(self))
+            y = self._plan[1](x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())
             return y.permute(0, 3, 1, 2)
         blocks, deblocks = self._fold()
         x = x.to(self.compute_dtype)

@@ -65,6 +65,22 @@ def kaiming_init(module, mode="fan_out", nonlinearity="relu", bias=0):
         nn.init.constant_(module.bias, bias)
 
 
+def weights_version(*modules):
+    """Cheap change detector for derived-weight caches (folded BN, packed fragments, captured graphs).  Parameters and
+    buffers bump ``_version`` on every in-place update -- optimizer steps, ``init_weights``, ``load_state_dict``, BN
+    running statistics in train() -- so the sum over a module's tensors changes whenever one of them does (versions
+    only grow).  A write through ``p.data`` bypasses the counter: call ``invalidate_caches()`` after one."""
+    v = 0
+    for m in modules:
+        ts = m.__dict__.get("_wv_tensors")
+        if ts is None:
+            ts = list(m.parameters()) + list(m.buffers())
+            m.__dict__["_wv_tensors"] = ts
+        for t in ts:
+            v += t._version
+    return v
+
+
 def bn_affine(bn):
     """Eval-mode BatchNorm as y = x * scale + shift."""
     scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)

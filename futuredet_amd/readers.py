@@ -1,10 +1,9 @@
 """Readers (det3d/models/readers).  VoxelFeatureExtractorV3: per-voxel mean of the point slots."""
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import hip_ops
-from .nn_utils import bn_affine, build_norm_layer
+from .nn_utils import bn_affine, build_norm_layer, weights_version
 from .registry import READERS
 
 
@@ -28,7 +27,9 @@ class VoxelFeatureExtractorV3(nn.Module):
 
 
 class PFNLayer(nn.Module):
-    """det3d/models/readers/pillar_encoder.py:15-55 (state_dict: linear.weight, norm.*)."""
+    """Parameter holder with the state_dict keys of det3d/models/readers/pillar_encoder.py:15-55 (linear.weight,
+    norm.*).  The layer itself (Linear, BatchNorm, ReLU, max over the pillar's points, concat) is evaluated inside
+    fd_pillar_encode; there is no per-layer torch forward."""
 
     def __init__(self, in_channels, out_channels, norm_cfg=None, last_layer=False):
         super().__init__()
@@ -43,20 +44,11 @@ class PFNLayer(nn.Module):
         self.linear = nn.Linear(in_channels, self.units, bias=False)
         self.norm = build_norm_layer(self.norm_cfg, self.units)[1]
 
-    def forward(self, inputs):
-        x = self.linear(inputs)
-        x = self.norm(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
-        x = F.relu(x)
-        x_max = torch.max(x, dim=1, keepdim=True)[0]
-        if self.last_vfe:
-            return x_max
-        return torch.cat([x, x_max.repeat(1, inputs.shape[1], 1)], dim=2)
-
 
 @READERS.register_module
 class PillarFeatureNet(nn.Module):
     """det3d/models/readers/pillar_encoder.py:58-164.  In eval mode on the GPU the whole reader is one HIP launch
-    (fd_pillar_encode); the torch modules define the parameters / state_dict and serve training."""
+    (fd_pillar_encode); the torch modules only define the parameters / state_dict.  Training is outside this path."""
 
     def __init__(self, num_input_features=4, num_filters=(64,), with_distance=False, voxel_size=(0.2, 0.2, 4),
                  pc_range=(0, -40, -3, 70.4, 40, 1), norm_cfg=None):
@@ -80,26 +72,9 @@ class PillarFeatureNet(nn.Module):
         self._packed = None
         self.register_load_state_dict_post_hook(_drop_packed)
 
-    def forward_modules(self, features, num_voxels, coors):
-        dtype = features.dtype
-        points_mean = features[:, :, :3].sum(dim=1, keepdim=True) / num_voxels.type_as(features).view(-1, 1, 1)
-        f_cluster = features[:, :, :3] - points_mean
-        f_center = torch.zeros_like(features[:, :, :2])
-        f_center[:, :, 0] = features[:, :, 0] - (coors[:, 3].to(dtype).unsqueeze(1) * self.vx + self.x_offset)
-        f_center[:, :, 1] = features[:, :, 1] - (coors[:, 2].to(dtype).unsqueeze(1) * self.vy + self.y_offset)
-        features_ls = [features, f_cluster, f_center]
-        if self._with_distance:
-            features_ls.append(torch.norm(features[:, :, :3], 2, 2, keepdim=True))
-        features = torch.cat(features_ls, dim=-1)
-        voxel_count = features.shape[1]
-        mask = (torch.arange(voxel_count, device=features.device).view(1, -1) < num_voxels.view(-1, 1).int())
-        features = features * mask.unsqueeze(-1).type_as(features)
-        for pfn in self.pfn_layers:
-            features = pfn(features)
-        return features.squeeze()
-
     def _layers(self, device):
-        if self._packed is None or self._packed[0] != device:
+        key = (device, weights_version(self))
+        if self._packed is None or self._packed[0] != key:
             if len(self.pfn_layers) > 2:
                 raise NotImplementedError("fd_pillar_encode fuses one or two PFN layers (shipped configs: [64, 64])")
             layers = []
@@ -107,16 +82,18 @@ class PillarFeatureNet(nn.Module):
                 scale, shift = bn_affine(pfn.norm)
                 layers.append((pfn.linear.weight.detach().float().contiguous().to(device), scale.contiguous().to(device),
                                shift.contiguous().to(device)))
-            self._packed = (device, layers)
+            self._packed = (key, layers)
         return self._packed[1]
 
     def forward(self, features, num_voxels, coors, n_dev=None):
         if self.training:
-            return self.forward_modules(features, num_voxels, coors)
+            raise NotImplementedError("PillarFeatureNet runs as one fused inference kernel (fd_pillar_encode); training is outside "
+                                      "the hot path (SURVEY 2)")
         return hip_ops.pillar_encode(features, num_voxels.int(), coors.int().contiguous(), n_dev,
                                      (self.vx, self.vy, self.x_offset, self.y_offset), self._layers(features.device),
                                      with_distance=self._with_distance, out_dtype=self.compute_dtype)
 
 
-def _drop_packed(module, incompatible_keys):
+def _drop_packed(module, incompatible_keys=None):
     module._packed = None
+    module.__dict__.pop("_wv_tensors", None)

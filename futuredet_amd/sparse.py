@@ -112,11 +112,15 @@ class SparseConvolution(SparseModule):
 
     def packed_weight(self, dtype, bn=None):
         """Fragment-ordered weights (+ fp32 bias) with the eval-mode BatchNorm ``bn`` that follows the conv folded
-        in; channel counts are padded to multiples of 16.  Cached until the next load_state_dict."""
+        in; channel counts are padded to multiples of 16.  Cached per (dtype, bn, device) and re-derived whenever one
+        of the source tensors changed (their ``_version`` counters: load_state_dict, init, optimizer step, BN statistics)."""
         key = (dtype, id(bn), self.weight.device)
+        ver = self.weight._version + (self.bias._version if self.bias is not None else 0)
+        if bn is not None:
+            ver += bn.weight._version + bn.bias._version + bn.running_mean._version + bn.running_var._version
         hit = self._packed.get(key)
-        if hit is not None:
-            return hit
+        if hit is not None and hit[0] == ver:
+            return hit[1]
         scale = shift = None
         if bn is not None:
             from .nn_utils import bn_affine
@@ -137,7 +141,7 @@ class SparseConvolution(SparseModule):
             bp[: self.out_channels] = b
             bp = bp.contiguous()
         packed = (hip_ops.pack_spconv_weight(wp, dtype), bp, cin_p, cout_p)
-        self._packed[key] = packed
+        self._packed[key] = (ver, packed)
         return packed
 
     def rulebook_for(self, x):
@@ -160,6 +164,9 @@ class SparseConvolution(SparseModule):
 
     def forward(self, x):
         assert isinstance(x, SparseConvTensor)
+        if self.training and torch.is_grad_enabled() and self.weight.requires_grad:
+            raise NotImplementedError("the HIP sparse convolution is inference-only (no autograd): call under "
+                                      "torch.no_grad() / in eval mode; training is outside this path (SURVEY 2)")
         out_index, nbr = self.rulebook_for(x)
         wpk, bias, cin_p, cout_p = self.packed_weight(torch.float32)
         feats = x.features

@@ -4,7 +4,9 @@
  * caller-owned DEVICE memory unless marked host; every call is asynchronous on `stream` (a hipStream_t
  * passed as void*), performs no allocation and no device synchronisation, and returns 0 on success or a
  * negative FD_E* code (never exit()).  fd_last_error() returns a thread-local description of the last
- * failure.  Sizes that the GPU decides (voxel count, active rows per level, detections) are written to
+ * failure.  Calls are re-entrant across threads, streams and devices: a call works on the device that is
+ * current on the calling thread (the one `stream` belongs to); the only process-level state is a per-device
+ * cache of device attributes / kernel LDS limits (atomics) and the fd_tuning_set knobs.  Sizes that the GPU decides (voxel count, active rows per level, detections) are written to
  * device int32 counters supplied by the caller; host code reads them when it needs them.
  *
  * Each entry point names the reference interface it replaces (paths relative to the reference tree).
@@ -28,6 +30,12 @@ typedef void *fd_stream_t; /* hipStream_t */
 
 int fd_abi_version(void);
 const char *fd_last_error(void);
+/* Tuning / test knobs (no reference counterpart).  0 = built-in heuristic.  Names: "spconv_rg" (rows per wave of the
+ * register sparse-conv kernel: 1|2|4), "spconv_v1" (1: fp32 on the register kernel instead of the compacting one),
+ * "spconv_bf16_v1", "v2_depth", "v2_tm", "v2_ldspad", "conv_nt".  Initial values come from the FD_SPCONV_RG,
+ * FD_SPCONV_V1, ... environment variables, read once when the library is loaded; nothing on the launch path calls
+ * getenv(). */
+int fd_tuning_set(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------------------
  * Voxelizer (+ fused mean reader).

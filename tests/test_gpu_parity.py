@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity_util import assert_close, attribute_detection_diffs, greedy_violations, nms_layout, rel_err, report
+
 pytestmark = pytest.mark.gpu
 
 VOX_CASES = ["tiny", "edges", "cloud_cap", "coarse", "all_out"]
@@ -119,8 +121,11 @@ def test_rulebook_matches_oracle_pairs(hip, geom):
 @pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
-    """fd_spconv_apply (+bias +residual +relu) vs the oracle's pair-list indice_conv; fp32 tolerance 1e-3 of the
-    output scale (north_star), bf16 (config 3) 2e-2."""
+    """fd_spconv_apply (+bias +residual +relu) vs the oracle's pair-list indice_conv, element-wise
+    |d| <= tol * max(1, |ref|): fp32 1e-4 (north_star allows 1e-3; an fp32 FMA chain of 27*cin terms lands near 1e-6),
+    bf16 (config 3) 2e-2.  Every kernel variant is run: fp32 = the pair-compacting kernel (default) and the
+    register-resident kernel at 1 / 2 / 4 row groups per wave; bf16 = column-split (default where it applies) and the
+    register kernel.  Variants of one kernel agree bit for bit; different kernels agree within the tolerance."""
     from oracle import ops as oops
 
     rng = np.random.default_rng(cin * 7 + cout)
@@ -140,16 +145,20 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
     res = _dev(res_np).to(tdt)
     nbr = src.rulebook(src, (3, 3, 3), (1, 1, 1), (1, 1, 1))
     wpk = hip.pack_spconv_weight(torch.from_numpy(w), tdt).cuda()
-    ys = []
-    for rg in ("1", "2", "4", ""):  # every row-group variant of the kernel, then the heuristic
-        if rg:
-            os.environ["FD_SPCONV_RG"] = rg
-        else:
-            os.environ.pop("FD_SPCONV_RG", None)
-        ys.append(hip.spconv_apply(x, wpk, _dev(bias), nbr, src.n, cout, residual=res, relu=True).float().cpu().numpy())
+    run = lambda: hip.spconv_apply(x, wpk, _dev(bias), nbr, src.n, cout, residual=res, relu=True).float().cpu().numpy()  # noqa: E731
+    v1_knob = "spconv_v1" if dtype == "f32" else "spconv_bf16_v1"
+    try:
+        y_default = run()
+        hip.set_tuning(v1_knob, 1)
+        ys = []
+        for rg in (1, 2, 4):  # every row-group variant of the register kernel
+            hip.set_tuning("spconv_rg", rg)
+            ys.append(run())
+    finally:
+        hip.set_tuning("spconv_rg", 0)
+        hip.set_tuning(v1_knob, 0)
     for other in ys[1:]:
         assert np.array_equal(ys[0], other), "row-group variants must agree bit for bit (same fma chain per row)"
-    y = ys[0]
     # oracle in original row order, mapped to index order
     if dtype == "bf16":
         feats = torch.from_numpy(feats).bfloat16().float().numpy()
@@ -161,9 +170,73 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
     ref_sorted = np.empty_like(ref)
     ref_sorted[r] = ref
     ref_sorted = np.maximum(ref_sorted + res_np, 0)
-    tol = 1e-3 if dtype == "f32" else 2e-2
-    scale = max(1.0, np.abs(ref_sorted).max())
-    assert np.abs(y - ref_sorted).max() <= tol * scale
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    assert_close("spconv_apply %s %d->%d default kernel vs oracle" % (dtype, cin, cout), y_default, ref_sorted, tol)
+    assert_close("spconv_apply %s %d->%d register kernel vs oracle" % (dtype, cin, cout), ys[0], ref_sorted, tol)
+
+
+# the four conv geometries of SpMiddleResNetFHD (scn.py:99-143) x channel pairs from 16 to 128
+CONV3D_CASES = [((3, 3, 3), (1, 1, 1), (1, 1, 1), True, 16, 16, 0.10), ((3, 3, 3), (1, 1, 1), (1, 1, 1), True, 32, 32, 0.15),
+                ((3, 3, 3), (1, 1, 1), (1, 1, 1), True, 64, 64, 0.25), ((3, 3, 3), (1, 1, 1), (1, 1, 1), True, 128, 128, 0.30),
+                ((3, 3, 3), (2, 2, 2), (1, 1, 1), False, 16, 32, 0.05), ((3, 3, 3), (2, 2, 2), (1, 1, 1), False, 32, 64, 0.10),
+                ((3, 3, 3), (2, 2, 2), (0, 1, 1), False, 64, 128, 0.15), ((3, 1, 1), (2, 1, 1), (0, 0, 0), False, 128, 128, 0.30)]
+
+
+@pytest.mark.parametrize("case", CONV3D_CASES, ids=lambda c: "k%s_s%s_p%s_%d-%d" % ("".join(map(str, c[0])), "".join(map(str, c[1])),
+                                                                                       "".join(map(str, c[2])), c[4], c[5]))
+def test_sparse_conv_matches_dense_conv3d_directly(hip, case):
+    """An arbiter that is NOT this repo's oracle: fd_rulebook + fd_spconv_apply + fd_densify against
+    torch.nn.functional.conv3d on the densified input (a 41 x 96 x 96 grid, B = 2).  spconv's definition
+    (SURVEY 8a A5/A6): a strided SparseConv3d equals the dense convolution at every output site (sites without an active
+    input in their window are exactly zero either way); a SubMConv3d equals it at the active input sites.  The dense
+    convolution runs in float64 on the host for the narrow cases and through MIOpen fp32 on the device for the wide ones
+    (an independent implementation either way)."""
+    ks, st, pd, subm, cin, cout, dens = case
+    rng = np.random.default_rng(cin * 131 + cout + ks[1])
+    B, D, H, W = 2, 41, 96, 96
+    idx, feats = _random_sparse(rng, B, D, H, W, dens, cin)
+    w = (rng.standard_normal((ks[0] * ks[1] * ks[2], cin, cout)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    src = hip.SparseIndex(B, D, H, W, torch.device("cuda"))
+    n_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    src.mark(_dev(idx))
+    src.scan(n_dev)
+    src.finalize(int(n_dev.cpu()[0]))
+    x = hip.rows_permute(_dev(feats), src.lookup(_dev(idx)), cin, torch.float32, n_rows=src.n)
+    if subm:
+        dst = src
+    else:
+        dst = src.downsample(ks, st, pd)
+        nd = torch.zeros(1, dtype=torch.int32, device="cuda")
+        dst.scan(nd)
+        dst.finalize(int(nd.cpu()[0]))
+    nbr = src.rulebook(dst, ks, st, pd)
+    y = hip.spconv_apply(x, hip.pack_spconv_weight(torch.from_numpy(w)).cuda(), None, nbr, dst.n, cout)
+    # densify through fd_densify's general sibling: scatter rows by the index coordinates (exact, no arithmetic)
+    co = dst.coords.long()
+    got = torch.zeros((B, cout, dst.D, dst.H, dst.W), device="cuda")
+    got[co[:, 0], :, co[:, 1], co[:, 2], co[:, 3]] = y
+    dense_in = torch.zeros((B, cin, D, H, W), dtype=torch.float32)
+    ii = torch.from_numpy(idx.astype(np.int64))
+    dense_in[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]] = torch.from_numpy(feats)
+    w5 = torch.from_numpy(w).reshape(ks[0], ks[1], ks[2], cin, cout).permute(4, 3, 0, 1, 2).contiguous()  # [Cout,Cin,kD,kH,kW]
+    if cin * cout <= 32 * 32:
+        ref = torch.nn.functional.conv3d(dense_in.double(), w5.double(), None, stride=st, padding=pd).float()
+        how = "float64 host conv3d"
+    else:
+        ref = torch.nn.functional.conv3d(dense_in.cuda(), w5.cuda(), None, stride=st, padding=pd).cpu()
+        how = "MIOpen fp32 conv3d"
+    assert tuple(ref.shape[2:]) == (dst.D, dst.H, dst.W)
+    got = got.cpu()
+    if subm:
+        mask = torch.zeros((B, 1, D, H, W), dtype=torch.bool)
+        mask[ii[:, 0], 0, ii[:, 1], ii[:, 2], ii[:, 3]] = True
+        ref = ref * mask
+    else:
+        active = torch.zeros((B, 1, dst.D, dst.H, dst.W), dtype=torch.bool)
+        cc = co.cpu()
+        active[cc[:, 0], 0, cc[:, 1], cc[:, 2], cc[:, 3]] = True
+        assert float((ref * ~active).abs().max()) == 0.0, "the output set must cover every site the dense conv reaches"
+    assert_close("sparse conv vs F.conv3d k%s s%s p%s %d->%d (%d rows)" % (ks, st, pd, cin, cout, src.n), got.numpy(), ref.numpy(), 1e-4, how)
 
 
 def test_densify_matches_oracle(hip):
@@ -198,20 +271,18 @@ def test_backbone_matches_reference_topology_golden(hip, golden):
     bb = bb.cuda().eval()
     feats, coors = _dev(g["feats"]), _dev(g["coors"])
     grid = [int(v) for v in g["grid"]]
-    scale = np.abs(g["y"]).max()
     with torch.no_grad():
         y_fused, ms = bb(feats, coors, 2, grid)
         y_gen, ms_gen = bb.forward_generic(feats, coors, 2, grid)
     for name, y in (("fused", y_fused), ("generic", y_gen)):
-        err = np.abs(y.float().cpu().numpy() - g["y"]).max()
-        assert err <= 1e-3 * scale, (name, err, scale)
+        assert_close("backbone golden (%s path)" % name, y.float().cpu().numpy(), g["y"], 1e-3)
     for k in ("conv1", "conv2", "conv3", "conv4"):
         for m in (ms, ms_gen):
             ind = m[k].indices.cpu().numpy()
             order = np.lexsort(ind.T[::-1])
             assert np.array_equal(ind[order], g["ms_%s_idx" % k])
             fs = m[k].features.float().cpu().numpy()[order].sum(1)
-            assert np.abs(fs - g["ms_%s_feat_sum" % k]).max() <= 1e-3 * max(1.0, np.abs(g["ms_%s_feat_sum" % k]).max())
+            assert rel_err(fs, g["ms_%s_feat_sum" % k]) <= 1e-3
 
 
 # ------------------------------------------------------------------------------------------------ IoU / NMS / decode
@@ -223,6 +294,10 @@ def test_iou_matches_compiled_reference_golden(hip, golden):
 
 
 def test_rotated_nms_vs_oracle(hip):
+    """fd_rotated_nms and rotate_nms_pcdet vs the oracle's greedy sweep.  The two may differ only where a pair's IoU sits
+    within 1e-4 of the threshold (device vs host sin/cos/atan2 differ in the last ulp): whenever the index lists differ,
+    the device result must still be a greedy-NMS result under the host IoU matrix up to such pairs (every kept / dropped
+    decision is checked against the kept boxes before it), and without any near-threshold pair the lists must be equal."""
     from futuredet_amd.nms import rotate_nms_pcdet
     from oracle import model as omodel
     from oracle import ops as oops
@@ -238,17 +313,29 @@ def test_rotated_nms_vs_oracle(hip):
         keep, cnt = hip.rotated_nms(_dev(b), 0.2)
         got = keep[: int(cnt.cpu()[0])].cpu().numpy()
         want = oops.nms(b, 0.2)
+        iou = oops.boxes_iou_bev(b, b) if n else np.zeros((0, 0), np.float32)
+        near = int((np.abs(np.triu(iou, 1) - 0.2) < 1e-4).sum()) if n else 0
         if not np.array_equal(got, want):
-            # only pairs whose IoU sits within 1e-4 of the threshold may flip (device vs host libm)
-            iou = oops.boxes_iou_bev(b, b)
-            assert np.any(np.abs(iou - 0.2) < 1e-4), "NMS differs without a near-threshold pair"
-        scores = torch.from_numpy(rng.random(n).astype(np.float32))
-        b9 = torch.from_numpy(b)
+            assert near > 0, "NMS differs from the oracle although no pair is within 1e-4 of the threshold"
+            bad = greedy_violations(iou, got, 0.2)
+            assert not bad, "fd_rotated_nms (n=%d): %s" % (n, bad[:3])
+        report("fd_rotated_nms n=%d" % n, float(len(set(got.tolist()) ^ set(want.tolist()))), 0.0, "(index differences; %d near-threshold pairs)" % near)
         if n:
-            sel = rotate_nms_pcdet(b9.cuda(), scores.cuda(), 0.2, pre_maxsize=1000, post_max_size=83).cpu()
-            ref = omodel.rotate_nms_pcdet(b9.clone(), scores.clone(), 0.2, 1000, 83)
+            scores = torch.from_numpy(rng.random(n).astype(np.float32))
+            b7 = torch.from_numpy(b)
+            sel = rotate_nms_pcdet(b7.cuda(), scores.cuda(), 0.2, pre_maxsize=1000, post_max_size=83).cpu()
+            ref = omodel.rotate_nms_pcdet(b7.clone(), scores.clone(), 0.2, 1000, 83)
+            assert len(sel) <= 83
             if not torch.equal(sel, ref):
-                assert len(sel) == len(ref) or True
+                # rebuild what the routine hands to the IoU kernel (box_torch_ops.py:256-262) and check every decision
+                order = np.argsort(-scores.numpy(), kind="stable")[:1000]
+                nb = nms_layout(b[order])
+                iou2 = oops.boxes_iou_bev(nb, nb)
+                assert int((np.abs(np.triu(iou2, 1) - 0.2) < 1e-4).sum()) > 0, "rotate_nms_pcdet differs without a near-threshold pair"
+                pos = {int(o): i for i, o in enumerate(order)}
+                kept = [pos[int(i)] for i in sel.tolist()]
+                bad = greedy_violations(iou2, kept, 0.2, limit=83)
+                assert not bad, "rotate_nms_pcdet (n=%d): %s" % (n, bad[:3])
 
 
 TEST_CFG = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], max_per_img=500,
@@ -264,6 +351,19 @@ def _match_detections(got, want, tol=1e-3):
     # 1e-3 relative to the magnitude of each component (exp(dim) and velocities can be large)
     d = (np.abs(got[:, None, :] - want[None, :, :]) / np.maximum(1.0, np.abs(want[None, :, :]))).max(-1)
     return int((d.min(1) > tol).sum() + (d.min(0) > tol).sum())
+
+
+def _attribute(name, got, want, cfg=None):
+    """Every detection without a counterpart must be explained by a near-threshold score or NMS pair (parity_util)."""
+    from oracle import ops as oops
+
+    cfg = cfg or TEST_CFG
+    return attribute_detection_diffs(name, got, want, oops.boxes_iou_bev, cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"])
+
+
+def _rows(res):
+    r = torch.cat([res["box3d_lidar"].float(), res["scores"][:, None].float(), res["label_preds"][:, None].float()], 1)
+    return r.cpu().numpy()
 
 
 @pytest.mark.parametrize("name,T,dense", [("n0", 1, False), ("n3", 7, False), ("n3dtf", 7, True), ("n0big", 1, False)])
@@ -289,18 +389,18 @@ def test_predict_matches_reference_golden(hip, golden, name, T, dense):
         want = np.concatenate([g["%s_out_b%d_boxes" % (name, b)], g["%s_out_b%d_scores" % (name, b)][:, None],
                                g["%s_out_b%d_labels" % (name, b)][:, None].astype(np.float32)], 1)
         got = torch.cat([r["box3d_lidar"], r["scores"][:, None], r["label_preds"][:, None].float()], 1).cpu().numpy()
-        bad = _match_detections(got, want)
-        assert bad <= max(2, 0.01 * (len(got) + len(want))), (name, b, bad, len(got), len(want))
+        bad = _attribute("predict golden %s b%d" % (name, b), got, want)
         if bad == 0:  # same order as the reference when nothing flipped: steps in order, score-descending inside a step
-            assert (np.abs(got - want) / np.maximum(1.0, np.abs(want))).max() <= 1e-3
+            assert_close("predict golden %s b%d rows in order" % (name, b), got, want, 1e-3)
 
 
 # ------------------------------------------------------------------------------------------------ end to end
 @pytest.mark.parametrize("variant", ["forecast_n0", "forecast_n3", "pedestrian_n3_fine", "forecast_n3dtfm"])
 def test_voxelnet_end_to_end_vs_oracle(hip, variant):
     """Whole path on a ~30k-point synthetic cloud (BASELINE configs[0] shape): HIP VoxelNet.forward(example) and
-    forward_points() vs the CPU oracle model with the same seeded weights.  BEV map 1e-3 of scale; detections
-    matched within 1e-3 (boxes) allowing <=2% near-threshold flips."""
+    forward_points() vs the CPU oracle model with the same seeded weights.  BEV map element-wise
+    |d| <= 1e-3 * max(1, |ref|); detections matched within 1e-3 per component, every unmatched one attributed to a
+    near-threshold score / IoU pair (parity_util.attribute_detection_diffs)."""
     from futuredet_amd import build_detector
     from futuredet_amd.collate import collate_kitti_multi, example_to_device
     from futuredet_amd.configs import centerpoint_config
@@ -344,27 +444,28 @@ def test_voxelnet_end_to_end_vs_oracle(hip, variant):
                                      coors=dev_batch["coordinates"], batch_size=2, input_shape=dev_batch["shape"][0]))
         bev_in = torch.stack(dev_batch["bev_map"], dim=1).float() if cfg.BEV_MAP else None
         fast = net.forward_points([_dev(c) for c in clouds], cfg.voxel_generator, bev_map=bev_in, padded=False)
-    scale = float(obev.abs().max())
-    assert float((x.float().cpu() - obev).abs().max()) <= 1e-3 * scale
+    assert_close("e2e 30k %s BEV map (neck output)" % variant, x.float().cpu().numpy(), obev.numpy(), 1e-3)
     for b in range(2):
-        w = torch.cat([want[b]["box3d_lidar"], want[b]["scores"][:, None], want[b]["label_preds"][:, None].float()], 1).numpy()
-        if cfg.DENSE:
-            # seven chained task heads with random weights saturate many logits to a score of exactly 1.0; the order of
-            # such ties (and hence top-k / NMS membership) is not defined, so only unsaturated detections are matched
-            w = w[w[:, 9] < 0.999]
-        for res in (got, fast):
-            gt = torch.cat([res[b]["box3d_lidar"], res[b]["scores"][:, None], res[b]["label_preds"][:, None].float()], 1).cpu().numpy()
+        w = _rows(want[b])
+        for tag, res in (("forward", got), ("forward_points", fast)):
+            gt = _rows(res[b])
             if cfg.DENSE:
-                gt = gt[gt[:, 9] < 0.999]
-            bad = _match_detections(gt, w)
-            assert bad <= max(2, 0.02 * (len(gt) + len(w))), (variant, b, bad, len(gt), len(w))
+                # seven chained task heads with random weights saturate many logits to a score of exactly 1.0; the order of
+                # such ties (and hence top-k / NMS membership, and what those boxes suppress) is not defined, so only
+                # unsaturated detections are matched and the tie cascade is bounded by count instead of attributed
+                gt, wu = gt[gt[:, 9] < 0.999], w[w[:, 9] < 0.999]
+                bad = _match_detections(gt, wu)
+                report("e2e 30k %s %s b%d detections" % (variant, tag, b), float(bad), 0.02 * (len(gt) + len(wu)), "(unsaturated rows)")
+                assert bad <= max(2, 0.02 * (len(gt) + len(wu))), (variant, b, bad, len(gt), len(wu))
+            else:
+                _attribute("e2e 30k %s %s b%d" % (variant, tag, b), gt, w, cfg.test_cfg)
     if cfg.DENSE:  # and the raw head outputs of the chain agree tensor by tensor
         with torch.no_grad():
             op = onet.bbox_head(obev, torch.stack(batch["bev_map"], dim=1).float())
             hp = net.bbox_head(x, bev_in)
         for t in (0, 3, 6):
             for k in op[t]:
-                assert float((hp[t][k].float().cpu() - op[t][k]).abs().max()) <= 1e-3 * max(1.0, float(op[t][k].abs().max())), (t, k)
+                assert_close("e2e 30k %s head t%d %s" % (variant, t, k), hp[t][k].float().cpu().numpy(), op[t][k].numpy(), 1e-3)
 
 
 # ------------------------------------------------------------------------------------------------ dense conv (bf16)
@@ -523,13 +624,13 @@ def test_pillar_encode_and_scatter_match_reference_golden(hip, golden, name, n_l
     f = hip.pillar_encode(_dev(g["voxels"]), _dev(g["num"]), coors, n_dev, geom, _pillar_layers(g, name, n_layers), with_distance=wd)
     want = g[name + "_feats"]
     scale = np.abs(want).max()
-    assert np.abs(f[:M - 7].cpu().numpy() - want[:M - 7]).max() <= 1e-3 * scale
+    assert_close("pillar_encode %s vs reference golden" % name, f[:M - 7].cpu().numpy(), want[:M - 7], 1e-3)
     assert float(f[M - 7:].abs().max()) == 0.0
     f = hip.pillar_encode(_dev(g["voxels"]), _dev(g["num"]), coors, None, geom, _pillar_layers(g, name, n_layers), with_distance=wd)
     canvas = hip.pillar_scatter(f, coors, None, 2, 64, 64)
     assert tuple(canvas.shape) == (2, 64, 64, 64)
     assert np.abs(canvas.sum(1).cpu().numpy() - g[name + "_canvas_sum"]).max() <= 1e-3 * scale * 8
-    assert np.abs(canvas[:, 5].cpu().numpy() - g[name + "_canvas_c5"]).max() <= 1e-3 * scale
+    assert_close("pillar_scatter %s channel 5 vs reference golden" % name, canvas[:, 5].cpu().numpy(), g[name + "_canvas_c5"], 1e-3)
     cl = hip.pillar_scatter(f, coors, None, 2, 64, 64, out_dtype=torch.bfloat16, channels_last=True)
     assert cl.is_contiguous(memory_format=torch.channels_last)
     assert float((cl.float() - canvas).abs().max()) <= 2 ** -8 * scale
@@ -548,7 +649,7 @@ def test_pp_rpn_matches_reference_golden(hip, golden):
     want = g["rpn_out"]
     with torch.no_grad():
         y = rpn(_dev(g["rpn_in"]))
-    assert np.abs(y.float().cpu().numpy() - want).max() <= 1e-3 * np.abs(want).max()
+    assert_close("pp RPN vs reference golden", y.float().cpu().numpy(), want, 1e-3)
 
 
 def test_pp_dense_bf16_plans_vs_torch_modules(hip):
@@ -618,12 +719,15 @@ def test_pointpillars_end_to_end_vs_oracle(hip):
         got = net(dev_batch, return_loss=False)
         fast = net.forward_points([_dev(c) for c in clouds], cfg.voxel_generator, padded=False)
     for b in range(2):
-        w = torch.cat([want[b]["box3d_lidar"], want[b]["scores"][:, None], want[b]["label_preds"][:, None].float()], 1).numpy()
+        w = _rows(want[b])
         assert len(w) > 50
-        for res in (got, fast):
-            gt = torch.cat([res[b]["box3d_lidar"], res[b]["scores"][:, None], res[b]["label_preds"][:, None].float()], 1).cpu().numpy()
-            bad = _match_detections(gt, w)
-            assert bad <= max(2, 0.02 * (len(gt) + len(w))), (b, bad, len(gt), len(w))
+        for tag, res in (("forward", got), ("forward_points", fast)):
+            gt = _rows(res[b])
+            # (the n3dtf chain of this config saturates scores to exactly 1.0 like the VoxelNet n3dtf case: count-bounded)
+            gu, wu = gt[gt[:, 9] < 0.999], w[w[:, 9] < 0.999]
+            bad = _match_detections(gu, wu)
+            report("pointpillars e2e %s b%d detections" % (tag, b), float(bad), 0.02 * (len(gu) + len(wu)), "(unsaturated rows)")
+            assert bad <= max(2, 0.02 * (len(gu) + len(wu))), (b, bad, len(gu), len(wu))
 
 
 def test_spconv_tile_order_is_a_work_sorted_permutation(hip):
@@ -698,7 +802,7 @@ def test_forward_points_empty_and_ragged_batch(hip):
     assert len(solo["scores"]) > 0
     got = torch.cat([batch[1]["box3d_lidar"], batch[1]["scores"][:, None], batch[1]["label_preds"][:, None].float()], 1).cpu().numpy()
     want = torch.cat([solo["box3d_lidar"], solo["scores"][:, None], solo["label_preds"][:, None].float()], 1).cpu().numpy()
-    assert _match_detections(got, want) <= max(2, 0.02 * (len(got) + len(want)))  # (MIOpen may pick another algorithm at B=3)
+    _attribute("ragged batch: sample 1 of 3 vs its single-sample run", got, want, cfg.test_cfg)  # (the dense convs may tile differently at B=3)
     for b in (0, 2):  # an all-zero BEV map still decodes whatever the biases alone produce; it must be finite and bounded
         assert batch[b]["box3d_lidar"].shape[1] == 9 and bool(torch.isfinite(batch[b]["box3d_lidar"]).all())
     none = net.forward_points([empty], cfg.voxel_generator, padded=False)
@@ -744,43 +848,62 @@ def test_c_abi_reports_errors_instead_of_exiting(hip):
         hip.voxelize(torch.rand((10, 5)), [0.5, 0.5, 0.5], [0, 0, 0, 1, 1, 1], 4, 64)  # CPU tensor: no CPU path
 
 
-def test_voxelnet_bf16_end_to_end_vs_fp32_oracle(hip):
-    """BASELINE config 3 precision: bf16 conv features/weights with fp32 accumulation (sparse convs on the bf16 MFMA
-    kernels, RPN + head on the hand-written NHWC conv plan, replayed as a hipGraph) against the fp32 CPU oracle.  bf16
-    carries 8 mantissa bits through ~45 layers: the BEV map must agree within 4e-2 of its scale, and the detections
-    that the oracle scores well clear of the threshold must be found at the same place (0.3 m) by the bf16 path."""
+def _build_pair(variant, class_name="car", seed=7, **cfg_kw):
+    """(cfg, HIP detector on the GPU, CPU oracle detector) with the same seeded weights."""
     from futuredet_amd import build_detector
     from futuredet_amd.configs import centerpoint_config
-    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
+    from futuredet_amd.synth import seeded_state_dict
     from oracle import model as omodel
-    from oracle import ops as oops
 
-    cfg = centerpoint_config("forecast_n3")
+    cfg = centerpoint_config(variant, class_name, **cfg_kw)
     net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
-    sd = seeded_state_dict(net, 7)
+    sd = seeded_state_dict(net, seed)
     net.load_state_dict(sd, strict=False)
     net = net.cuda().eval()
-    net.set_precision(torch.bfloat16)
     onet = omodel.VoxelNet(cfg.model["reader"], cfg.model["backbone"], cfg.model["neck"], cfg.model["bbox_head"],
                            test_cfg=cfg.test_cfg).eval()
-    onet.load_state_dict(sd, strict=False)
-    cloud = synthetic_cloud(seed=0, target_points=30000)
+    missing, unexpected = onet.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    return cfg, net, onet
+
+
+def _grid_of(vg):
+    return np.round((np.array(vg["range"][3:], np.float32) - np.array(vg["range"][:3], np.float32)) / np.array(vg["voxel_size"], np.float32)).astype(np.int64)
+
+
+def _oracle_run(cfg, onet, cloud):
+    """The oracle on one cloud: (voxels, coords(z,y,x), num_points, backbone BEV, neck BEV, detections dict)."""
+    from oracle import ops as oops
+
     vg = cfg.voxel_generator
     v, c, n = oops.points_to_voxel(cloud, vg["voxel_size"], vg["range"], vg["max_points_in_voxel"], True, vg["max_voxel_num"][1])
     ex = dict(voxels=torch.from_numpy(v), coordinates=torch.from_numpy(np.pad(c, ((0, 0), (1, 0)))), num_points=torch.from_numpy(n),
-              num_voxels=torch.tensor([len(n)]), shape=np.array([[1440, 1440, 40]]), metadata=[None])
+              num_voxels=torch.tensor([len(n)]), shape=np.array([_grid_of(vg)]), metadata=[None])
     with torch.no_grad():
-        want = onet(ex)[0]
-        obev = onet.extract_feat(ex)
-        for _ in range(2):  # second call replays the captured graph
-            got = net.forward_points([_dev(cloud)], vg, padded=False)[0]
+        feats = onet.reader(ex["voxels"], ex["num_points"])
+        bb, _ = onet.backbone(feats, ex["coordinates"], 1, ex["shape"][0])
+        bev = onet.neck(bb)
+        det = onet.bbox_head.predict(ex, onet.bbox_head(bev, None), cfg.test_cfg)[0]
+    return v, c, n, bb, bev, det
+
+
+def _hip_maps(net, cfg, v, c, n):
+    """Backbone and neck BEV maps of the HIP modules on given voxels (the device voxelizer is checked bit-exact elsewhere)."""
+    with torch.no_grad():
         feats = net.reader(_dev(v).float(), _dev(n))
-        bev, _ = net.backbone(feats, _dev(np.pad(c, ((0, 0), (1, 0)))), 1, [1440, 1440, 40])
-        x = net.neck(bev)
+        bb, _ = net.backbone(feats, _dev(np.pad(c, ((0, 0), (1, 0)))), 1, [int(g) for g in _grid_of(cfg.voxel_generator)])
+        return bb, net.neck(bb)
+
+
+def _check_bf16_vs_fp32_oracle(tag, got, x, want, obev):
+    """bf16 carries 8 mantissa bits through ~45 layers: the BEV map must agree within 4e-2 of its scale, and the detections
+    that the oracle scores well clear of the threshold must be found at the same place (0.3 m) by the bf16 path."""
     scale = float(obev.abs().max())
-    assert float((x.float().cpu() - obev).abs().max()) <= 4e-2 * scale
+    err = float((x.float().cpu() - obev).abs().max()) / scale
+    report(tag + " bf16 BEV map vs fp32 oracle (of scale)", err, 4e-2)
+    assert err <= 4e-2
     wb, ws, wl = want["box3d_lidar"].numpy(), want["scores"].numpy(), want["label_preds"].numpy()
-    gb, gl = got["box3d_lidar"].cpu().numpy(), got["label_preds"].cpu().numpy()
+    gb, gl = got["box3d_lidar"].float().cpu().numpy(), got["label_preds"].cpu().numpy()
     assert len(gb) > 0.8 * len(wb)
     strong = ws > 0.3
     assert strong.sum() > 20
@@ -788,7 +911,151 @@ def test_voxelnet_bf16_end_to_end_vs_fp32_oracle(hip):
     for b, l in zip(wb[strong], wl[strong]):
         d = np.abs(gb[gl == l][:, :2] - b[:2]).max(1) if (gl == l).any() else np.array([9.0])
         found += d.min() < 0.3
+    report(tag + " bf16 strong detections found", float(strong.sum() - found), 0.1 * strong.sum(), "(missing of %d)" % strong.sum())
     assert found >= 0.9 * strong.sum(), (found, strong.sum())
+
+
+def test_voxelnet_bf16_end_to_end_vs_fp32_oracle(hip):
+    """BASELINE config 3 precision at the 30k-point size: bf16 conv features/weights with fp32 accumulation (sparse convs
+    on the bf16 MFMA kernels, RPN + head on the hand-written NHWC conv plan, replayed as a hipGraph) against the fp32 CPU
+    oracle."""
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, onet = _build_pair("forecast_n3")
+    net.set_precision(torch.bfloat16)
+    cloud = synthetic_cloud(seed=0, target_points=30000)
+    v, c, n, _, obev, want = _oracle_run(cfg, onet, cloud)
+    with torch.no_grad():
+        for _ in range(2):  # second call replays the captured graph
+            got = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
+    _, x = _hip_maps(net, cfg, v, c, n)
+    _check_bf16_vs_fp32_oracle("30k n3", got, x, want, obev)
+
+
+# ------------------------------------------------------------------------------------------------ full size (BASELINE configs 2-5)
+def test_full_size_config2_fp32_vs_oracle(hip):
+    """BASELINE configs[1] (the bench workload: forecast_n0, seed-0 300k-point cloud, fp32): backbone BEV map and neck
+    output element-wise |d| <= 1e-3 * max(1, |ref|) vs the oracle, detections matched with attribution."""
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, onet = _build_pair("forecast_n0")
+    cloud = synthetic_cloud(seed=0, target_points=300000)
+    v, c, n, obb, obev, want = _oracle_run(cfg, onet, cloud)
+    assert len(n) > 150000
+    bb, x = _hip_maps(net, cfg, v, c, n)
+    assert_close("full size config 2 (n0 fp32 300k) backbone BEV", bb.float().cpu().numpy(), obb.numpy(), 1e-3)
+    assert_close("full size config 2 (n0 fp32 300k) neck output", x.float().cpu().numpy(), obev.numpy(), 1e-3)
+    with torch.no_grad():
+        for i in range(2):  # eager + graph replay
+            got = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
+            _attribute("full size config 2 forward_points run %d" % i, _rows(got), _rows(want), cfg.test_cfg)
+
+
+def test_full_size_config3_bf16_vs_oracle(hip):
+    """BASELINE configs[2]: forecast_n3 (7-timestep head), 300k-point cloud, bf16, against the fp32 oracle."""
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, onet = _build_pair("forecast_n3")
+    net.set_precision(torch.bfloat16)
+    cloud = synthetic_cloud(seed=0, target_points=300000)
+    v, c, n, _, obev, want = _oracle_run(cfg, onet, cloud)
+    with torch.no_grad():
+        for _ in range(2):
+            got = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
+    _, x = _hip_maps(net, cfg, v, c, n)
+    _check_bf16_vs_fp32_oracle("full size config 3 (n3 300k)", got, x, want, obev)
+
+
+def test_config4_per_rank_batch8_bf16(hip):
+    """BASELINE configs[3] per-rank workload: forecast_n3, bf16, 8 clouds of 300k points in one batch.  Samples are
+    independent, so the batched result must equal the 8 single-sample runs (attributed matching; bit equality is
+    recorded), and one sample is checked against the fp32 oracle like config 3."""
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, onet = _build_pair("forecast_n3")
+    net.set_precision(torch.bfloat16)
+    clouds = [synthetic_cloud(seed=s, target_points=300000) for s in range(8)]
+    dev_clouds = [_dev(cl) for cl in clouds]
+    with torch.no_grad():
+        for _ in range(2):
+            batch = net.forward_points(dev_clouds, cfg.voxel_generator, padded=False)
+        bitwise = 0
+        for b in range(8):
+            solo = net.forward_points([dev_clouds[b]], cfg.voxel_generator, padded=False)[0]
+            g, w = _rows(batch[b]), _rows(solo)
+            bitwise += int(g.shape == w.shape and np.array_equal(g, w))
+            _attribute("config 4 batch-of-8 sample %d vs its single-sample run" % b, g, w, cfg.test_cfg)
+    report("config 4 samples bit-identical to single-sample runs", float(8 - bitwise), 8.0, "(count of samples that differ in any bit)")
+    v, c, n, _, obev, want = _oracle_run(cfg, onet, clouds[3])
+    _, x = _hip_maps(net, cfg, v, c, n)
+    _check_bf16_vs_fp32_oracle("config 4 sample 3 of the batch", batch[3], x, want, obev)
+
+
+def test_full_size_config5_pedestrian_fine_grid_fp32_vs_oracle(hip):
+    """BASELINE configs[4] single-GPU load: pedestrian forecast_n3, 500k-point cloud, 0.05 m grid (2160 x 2160 x 40,
+    BEV 270 x 270), 400k-voxel cap.  Voxelizer and level-0 rulebook (pair count per tap) bit-exact vs the oracle, BEV
+    maps element-wise 1e-3, detections attributed; the run is repeated to check determinism at this size."""
+    from futuredet_amd.synth import synthetic_cloud
+    from futuredet_amd.voxelize import points_to_voxel
+    from oracle import ops as oops
+
+    cfg, net, onet = _build_pair("forecast_n3", "pedestrian", voxel_size=(0.05, 0.05, 0.2), max_voxel_num=(300000, 400000))
+    vg = cfg.voxel_generator
+    cloud = synthetic_cloud(seed=0, target_points=500000)
+    v, c, n, obb, obev, want = _oracle_run(cfg, onet, cloud)
+    hv, hc, hn = points_to_voxel(cloud, vg["voxel_size"], vg["range"], vg["max_points_in_voxel"], True, vg["max_voxel_num"][1])
+    assert np.array_equal(hc, c) and np.array_equal(hn, n) and np.array_equal(hv, v)
+    report("config 5 voxelizer (500k pts, %d voxels) vs oracle" % len(n), 0.0, 0.0, "(bit-exact)")
+    # level-0 SubM rulebook: same number of pairs per tap as the spconv-1.0 restatement
+    D, H, W = 41, int(_grid_of(vg)[1]), int(_grid_of(vg)[0])
+    idx4 = np.pad(c, ((0, 0), (1, 0))).astype(np.int32)
+    _, _, pnum, _ = oops.rulebook(idx4, (D, H, W), (3, 3, 3), (1, 1, 1), (1, 1, 1), True)
+    src = hip.SparseIndex(1, D, H, W, torch.device("cuda"))
+    n_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    src.mark(_dev(idx4))
+    src.scan(n_dev)
+    src.finalize(int(n_dev.item()))
+    nbr = src.rulebook(src, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    assert src.n == len(n)
+    assert np.array_equal((nbr[:, :src.n] >= 0).sum(1).cpu().numpy(), np.asarray(pnum)), "pairs per tap differ from the oracle"
+    bb, x = _hip_maps(net, cfg, v, c, n)
+    assert_close("full size config 5 (ped n3 fp32 500k, 0.05 m) backbone BEV", bb.float().cpu().numpy(), obb.numpy(), 1e-3)
+    assert_close("full size config 5 (ped n3 fp32 500k, 0.05 m) neck output", x.float().cpu().numpy(), obev.numpy(), 1e-3)
+    with torch.no_grad():
+        outs = [net.forward_points([_dev(cloud)], vg, padded=True) for _ in range(2)]
+        got = net.forward_points([_dev(cloud)], vg, padded=False)[0]
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), "forward_points must be deterministic"
+    _attribute("full size config 5 forward_points", _rows(got), _rows(want), cfg.test_cfg)
+
+
+def test_weights_reload_invalidates_captured_graph(hip):
+    """The neck+head hipGraph and the folded / packed weight caches must not survive load_state_dict: run, load other
+    weights, run again -- the second result must match the oracle with the NEW weights (fp32 and bf16 plans)."""
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
+    from oracle import model as omodel
+
+    cfg, net, _ = _build_pair("forecast_n0", seed=7)
+    cloud = synthetic_cloud(seed=1, target_points=20000)
+    with torch.no_grad():
+        for _ in range(2):
+            net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)
+    sd = seeded_state_dict(net, 11)
+    net.load_state_dict(sd, strict=False)
+    onet = omodel.VoxelNet(cfg.model["reader"], cfg.model["backbone"], cfg.model["neck"], cfg.model["bbox_head"], test_cfg=cfg.test_cfg).eval()
+    onet.load_state_dict(sd, strict=False)
+    _, _, _, _, _, want = _oracle_run(cfg, onet, cloud)
+    with torch.no_grad():
+        got = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
+    _attribute("after load_state_dict (fp32 graph)", _rows(got), _rows(want), cfg.test_cfg)
+    # in-place parameter update (no load_state_dict): caches are keyed on parameter versions
+    with torch.no_grad():
+        net.bbox_head.shared_conv[0].weight.mul_(0.5)
+        sd2 = {k: v.clone() for k, v in net.state_dict().items()}
+        onet.load_state_dict({k: v.cpu() for k, v in sd2.items()}, strict=False)
+        _, _, _, _, _, want2 = _oracle_run(cfg, onet, cloud)
+        got2 = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
+    _attribute("after an in-place weight update (fp32 graph)", _rows(got2), _rows(want2), cfg.test_cfg)
 
 
 def test_full_size_backbone_is_deterministic_and_linear(hip):

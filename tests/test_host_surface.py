@@ -103,6 +103,20 @@ def test_det3d_alias_names():
     assert C2 is Config
     cfg = centerpoint_config("forecast_n0")
     assert get_downsample_factor(cfg.model) == 8
+    # the import block of the reference's inference entry point (tools/dist_test.py:19-32), minus third-party modules
+    from det3d import torchie  # noqa: F401
+    from det3d.datasets import build_dataloader, build_dataset  # noqa: F401
+    from det3d.torchie.apis import (batch_processor, build_optimizer, get_root_logger, init_dist, set_random_seed,  # noqa: F401
+                                    train_detector)
+    from det3d.torchie.trainer import get_dist_info, load_checkpoint  # noqa: F401
+    from det3d.torchie.trainer.utils import all_gather, synchronize
+
+    assert get_dist_info() == (0, 1) and all_gather({"a": 1}) == [{"a": 1}]
+    synchronize()
+    with pytest.raises(NotImplementedError):
+        train_detector()
+    with pytest.raises(NotImplementedError):
+        batch_processor(None, {}, True)
 
 
 def test_state_dict_keys_match_reference(golden):
@@ -170,7 +184,7 @@ def test_c_abi_exports_every_declared_symbol():
     nm = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (fd_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
-    assert L.fd_abi_version() == 1
+    assert L.fd_abi_version() == 2
     assert L.fd_index_num_cols(2, 180, 180) == 2 * 23 * 23 * 64
     assert L.fd_voxelize_workspace_bytes(1000, 100) > 0 and L.fd_nms_workspace_bytes(1000) >= 1000 * 16 * 8
 
@@ -237,6 +251,10 @@ def _dist_worker(rank, world, port, n_samples, q):
         k = (gi % post) + 1
         ok &= d["box3d_lidar"].shape == (S * k, 9) and bool((d["box3d_lidar"] == float(gi)).all())
         ok &= d["label_preds"].tolist() == [s for s in range(S) for _ in range(k)]
+    # the reference-contract helpers (trainer/utils.py:100-155): barrier + picklable-object gather, one entry per rank
+    dist_infer.synchronize()
+    objs = dist_infer.all_gather({"rank": r, "tokens": mine})
+    ok &= dist_infer.get_dist_info() == (r, w) and [o["rank"] for o in objs] == list(range(w)) and objs[r]["tokens"] == mine
     q.put((rank, ok, mine))
     torch.distributed.destroy_process_group()
 
