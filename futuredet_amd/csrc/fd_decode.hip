@@ -19,103 +19,162 @@ namespace {
 constexpr int kSelThreads = 1024;
 constexpr int kMaxPre = 4096;  // nms_pre_max_size bound (64 lanes x 64 bits in the sweep)
 
-// ---------------------------------------------------------------- rotated IoU (iou3d_nms_kernel.cu:14-234)
-struct Pt { float x, y; };
-__device__ inline float cross2(Pt a, Pt b) { return a.x * b.y - a.y * b.x; }
-__device__ inline float cross3(Pt p1, Pt p2, Pt p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
-__device__ inline int check_rect_cross(Pt p1, Pt p2, Pt q1, Pt q2) {
-    return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
-           fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
-}
-__device__ inline int check_in_box2d(const float *box, Pt p) {
-    const float MARGIN = 1e-2f;
-    float cx = box[0], cy = box[1];
-    float ac = cosf(-box[6]), as = sinf(-box[6]);
-    float rx = (p.x - cx) * ac + (p.y - cy) * (-as);
-    float ry = (p.x - cx) * as + (p.y - cy) * ac;
-    return (fabsf(rx) < box[3] / 2 + MARGIN && fabsf(ry) < box[4] / 2 + MARGIN);
-}
-__device__ inline int intersection(Pt p1, Pt p0, Pt q1, Pt q0, Pt &ans) {
-    const float EPS = 1e-8f;
-    if (check_rect_cross(p0, p1, q0, q1) == 0) return 0;
-    float s1 = cross3(q0, p1, p0), s2 = cross3(p1, q1, p0), s3 = cross3(p0, q1, q0), s4 = cross3(q1, p1, q0);
-    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
-    float s5 = cross3(q1, p1, p0);
-    if (fabsf(s5 - s1) > EPS) {
-        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
-        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
-    } else {
-        float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
-        float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
-        float D = a0 * b1 - a1 * b0;
-        ans.x = (b0 * c1 - b1 * c0) / D;
-        ans.y = (a1 * c0 - a0 * c1) / D;
-    }
-    return 1;
-}
-__device__ inline void rotate_around_center(Pt c, float ac, float as, Pt &p) {
-    float nx = (p.x - c.x) * ac + (p.y - c.y) * (-as) + c.x;
-    float ny = (p.x - c.x) * as + (p.y - c.y) * ac + c.y;
-    p.x = nx; p.y = ny;
-}
-__device__ inline int point_cmp(Pt a, Pt b, Pt c) { return atan2f(a.y - c.y, a.x - c.x) > atan2f(b.y - c.y, b.x - c.x); }
+// ---------------------------------------------------------------- rotated BEV IoU
+// Same quantity as det3d/ops/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (overlap polygon of two rotated rectangles =
+// edge/edge crossing points + corners of one lying inside the other, ordered by angle around their mean, fan area),
+// organised differently:
+//   * everything that depends on ONE box -- sin/cos of the yaw, the four rotated corners, half extents, area, the
+//     half diagonal used for far-pair rejection -- is computed once per box into a 64-byte Footprint (the reference
+//     recomputes it for every pair: 10 sincos + 8 corner rotations per pair, here none);
+//   * an edge/edge test evaluates four "side" values (signed area of a point against an edge line through its origin
+//     and precomputed direction) instead of five cross products: side(q0), side(q1) against A's edge and side(p0),
+//     side(p1) against B's edge.  Two of the reference's products are exact negations of these
+//     (fl(ab - cd) = -fl(cd - ab)), so the strict-crossing decision and the crossing point are bit-identical;
+//   * the angular order is an insertion sort on angles computed once per point (the reference bubble-sorts with two
+//     atan2f per comparison); both sorts are stable with the same strict comparison, hence the same order.
+// What is deliberately kept, because tests/golden/iou.npz (the compiled reference) and the NMS decisions at the
+// threshold depend on rounding: the order in which points enter the list (it is the summation order of the mean),
+// the operation order inside each expression, float32 throughout, no fma contraction (-ffp-contract=off).
+struct Footprint {
+    float vx[4], vy[4];  // rotated corners, counter-clockwise from (-hx,-hy)
+    float cx, cy, co, si; // centre, cos / sin of the yaw
+    float hx, hy, area, reach;  // half extents, w*l, half diagonal
+};
 
-__device__ float box_overlap(const float *box_a, const float *box_b) {
-    float a_angle = box_a[6], b_angle = box_b[6];
-    float a_dx_half = box_a[3] / 2, b_dx_half = box_b[3] / 2, a_dy_half = box_a[4] / 2, b_dy_half = box_b[4] / 2;
-    float a_x1 = box_a[0] - a_dx_half, a_y1 = box_a[1] - a_dy_half, a_x2 = box_a[0] + a_dx_half, a_y2 = box_a[1] + a_dy_half;
-    float b_x1 = box_b[0] - b_dx_half, b_y1 = box_b[1] - b_dy_half, b_x2 = box_b[0] + b_dx_half, b_y2 = box_b[1] + b_dy_half;
-    Pt center_a = {box_a[0], box_a[1]}, center_b = {box_b[0], box_b[1]};
-    Pt ca[5] = {{a_x1, a_y1}, {a_x2, a_y1}, {a_x2, a_y2}, {a_x1, a_y2}, {0, 0}};
-    Pt cb[5] = {{b_x1, b_y1}, {b_x2, b_y1}, {b_x2, b_y2}, {b_x1, b_y2}, {0, 0}};
-    float a_cos = cosf(a_angle), a_sin = sinf(a_angle), b_cos = cosf(b_angle), b_sin = sinf(b_angle);
-    for (int k = 0; k < 4; ++k) {
-        rotate_around_center(center_a, a_cos, a_sin, ca[k]);
-        rotate_around_center(center_b, b_cos, b_sin, cb[k]);
+__device__ inline Footprint make_footprint(const float *b /*[x,y,z,dx,dy,dz,yaw]*/) {
+    Footprint f;
+    f.cx = b[0]; f.cy = b[1];
+    f.hx = b[3] / 2; f.hy = b[4] / 2;
+    f.co = cosf(b[6]); f.si = sinf(b[6]);
+    f.area = b[3] * b[4];
+    f.reach = 0.5f * sqrtf(b[3] * b[3] + b[4] * b[4]);
+    const float lo_x = f.cx - f.hx, hi_x = f.cx + f.hx, lo_y = f.cy - f.hy, hi_y = f.cy + f.hy;
+    const float ux[4] = {lo_x, hi_x, hi_x, lo_x}, uy[4] = {lo_y, lo_y, hi_y, hi_y};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // rotation about the centre: (dx*c - dy*s, dx*s + dy*c) + centre
+        const float dx = ux[k] - f.cx, dy = uy[k] - f.cy;
+        f.vx[k] = dx * f.co + dy * (-f.si) + f.cx;
+        f.vy[k] = dx * f.si + dy * f.co + f.cy;
     }
-    ca[4] = ca[0]; cb[4] = cb[0];
-    Pt cross_points[16];
-    Pt poly_center = {0, 0};
-    int cnt = 0;
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            Pt ans;
-            if (intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], ans)) {
-                cross_points[cnt] = ans;
-                poly_center.x = poly_center.x + ans.x;
-                poly_center.y = poly_center.y + ans.y;
-                cnt++;
-            }
-        }
-    for (int k = 0; k < 4; ++k) {
-        if (check_in_box2d(box_a, cb[k])) {
-            poly_center.x = poly_center.x + cb[k].x; poly_center.y = poly_center.y + cb[k].y;
-            cross_points[cnt] = cb[k]; cnt++;
-        }
-        if (check_in_box2d(box_b, ca[k])) {
-            poly_center.x = poly_center.x + ca[k].x; poly_center.y = poly_center.y + ca[k].y;
-            cross_points[cnt] = ca[k]; cnt++;
-        }
-    }
-    poly_center.x /= cnt;
-    poly_center.y /= cnt;
-    for (int j = 0; j < cnt - 1; ++j)
-        for (int i = 0; i < cnt - j - 1; ++i)
-            if (point_cmp(cross_points[i], cross_points[i + 1], poly_center)) {
-                Pt t = cross_points[i]; cross_points[i] = cross_points[i + 1]; cross_points[i + 1] = t;
-            }
-    float area = 0;
-    for (int k = 0; k < cnt - 1; ++k) {
-        Pt u = {cross_points[k].x - cross_points[0].x, cross_points[k].y - cross_points[0].y};
-        Pt v = {cross_points[k + 1].x - cross_points[0].x, cross_points[k + 1].y - cross_points[0].y};
-        area += cross2(u, v);
-    }
-    return (float)(fabsf(area) / 2.0);
+    return f;
 }
-__device__ inline float iou_bev(const float *box_a, const float *box_b) {
-    float sa = box_a[3] * box_a[4], sb = box_b[3] * box_b[4];
-    float s_overlap = box_overlap(box_a, box_b);
-    return s_overlap / fmaxf(sa + sb - s_overlap, 1e-8f);
+
+// signed area of (point - origin) against direction d: > 0 on one side of the line, < 0 on the other
+__device__ inline float side_of(float px, float py, float ox, float oy, float dx, float dy) { return (px - ox) * dy - dx * (py - oy); }
+
+// is (px,py) inside rectangle f grown by the 1e-2 margin?  (un-rotate about the centre, compare with the half extents)
+__device__ inline bool inside_margin(const Footprint &f, float px, float py) {
+    const float dx = px - f.cx, dy = py - f.cy;
+    const float u = dx * f.co + dy * f.si;   // cos(-yaw) = co, -sin(-yaw) = si
+    const float v = dy * f.co - dx * f.si;   // dx*sin(-yaw) + dy*cos(-yaw), same rounding
+    return fabsf(u) < f.hx + 1e-2f && fabsf(v) < f.hy + 1e-2f;
+}
+
+constexpr int kMaxPoly = 24;  // 16 edge pairs can cross + 8 corners can be inside (never all at once)
+
+__device__ float footprint_overlap(const Footprint &A, const Footprint &B) {
+    float px[kMaxPoly], py[kMaxPoly], ang[kMaxPoly];
+    float sum_x = 0.f, sum_y = 0.f;
+    int n = 0;
+    // ---- crossing points, A's edges outer, B's edges inner
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float ax = A.vx[i], ay = A.vy[i], ax1 = A.vx[(i + 1) & 3], ay1 = A.vy[(i + 1) & 3];
+        const float ex = ax1 - ax, ey = ay1 - ay;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float bx = B.vx[j], by = B.vy[j], bx1 = B.vx[(j + 1) & 3], by1 = B.vy[(j + 1) & 3];
+            // the axis-aligned extents of the two edges must overlap (this also shields the sign tests below from
+            // rounding when the edges are far apart but nearly collinear)
+            if (!(fminf(ax, ax1) <= fmaxf(bx, bx1) && fminf(bx, bx1) <= fmaxf(ax, ax1) && fminf(ay, ay1) <= fmaxf(by, by1) &&
+                  fminf(by, by1) <= fmaxf(ay, ay1)))
+                continue;
+            const float fx = bx1 - bx, fy = by1 - by;
+            const float a0 = side_of(bx, by, ax, ay, ex, ey), a1 = side_of(bx1, by1, ax, ay, ex, ey);   // B's end points against A's edge
+            const float b0 = side_of(ax, ay, bx, by, fx, fy), b1 = side_of(ax1, ay1, bx, by, fx, fy);   // A's end points against B's edge
+            if (!(a0 * (-a1) > 0.f && b0 * (-b1) > 0.f)) continue;  // both pairs strictly on opposite sides
+            float qx, qy;
+            const float den = a1 - a0;
+            if (fabsf(den) > 1e-8f) {  // point dividing B's edge in the ratio of the two side values
+                qx = (a1 * bx - a0 * bx1) / den;
+                qy = (a1 * by - a0 * by1) / den;
+            } else {  // degenerate ratio: intersect the two implicit lines l*x + m*y + c = 0 by Cramer's rule
+                const float la = ay - ay1, ma = ax1 - ax, ca = ax * ay1 - ax1 * ay;
+                const float lb = by - by1, mb = bx1 - bx, cb = bx * by1 - bx1 * by;
+                const float det = la * mb - lb * ma;
+                qx = (ma * cb - mb * ca) / det;
+                qy = (lb * ca - la * cb) / det;
+            }
+            px[n] = qx; py[n] = qy; ++n;
+            sum_x = sum_x + qx; sum_y = sum_y + qy;
+        }
+    }
+    // ---- corners of one rectangle inside the other, alternating B's k-th and A's k-th
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (inside_margin(A, B.vx[k], B.vy[k])) {
+            sum_x = sum_x + B.vx[k]; sum_y = sum_y + B.vy[k];
+            px[n] = B.vx[k]; py[n] = B.vy[k]; ++n;
+        }
+        if (inside_margin(B, A.vx[k], A.vy[k])) {
+            sum_x = sum_x + A.vx[k]; sum_y = sum_y + A.vy[k];
+            px[n] = A.vx[k]; py[n] = A.vy[k]; ++n;
+        }
+    }
+    if (n < 3) return 0.f;  // no polygon (the fan below is empty or degenerate: area exactly 0)
+    const float mx = sum_x / n, my = sum_y / n;
+    // ---- angular order around the mean point: stable insertion sort, ascending, strict comparison
+    for (int k = 0; k < n; ++k) ang[k] = atan2f(py[k] - my, px[k] - mx);
+    for (int k = 1; k < n; ++k) {
+        const float a = ang[k], x = px[k], y = py[k];
+        int m = k;
+        while (m > 0 && ang[m - 1] > a) {
+            ang[m] = ang[m - 1]; px[m] = px[m - 1]; py[m] = py[m - 1];
+            --m;
+        }
+        ang[m] = a; px[m] = x; py[m] = y;
+    }
+    // ---- fan around the first vertex
+    float twice = 0.f;
+    for (int k = 0; k < n - 1; ++k) {
+        const float ux = px[k] - px[0], uy = py[k] - py[0], wx = px[k + 1] - px[0], wy = py[k + 1] - py[0];
+        twice += ux * wy - uy * wx;
+    }
+    return fabsf(twice) * 0.5f;
+}
+
+__device__ inline float footprint_iou(const Footprint &A, const Footprint &B) {
+    const float ov = footprint_overlap(A, B);
+    return ov / fmaxf(A.area + B.area - ov, 1e-8f);
+}
+
+// one Footprint per box, stored as four float4 planes ([plane][box]) so a wave's 64 column boxes load coalesced
+__device__ inline void store_footprint(float4 *planes, int64_t n_total, int64_t i, const Footprint &f) {
+    planes[i] = make_float4(f.vx[0], f.vy[0], f.vx[1], f.vy[1]);
+    planes[n_total + i] = make_float4(f.vx[2], f.vy[2], f.vx[3], f.vy[3]);
+    planes[2 * n_total + i] = make_float4(f.cx, f.cy, f.co, f.si);
+    planes[3 * n_total + i] = make_float4(f.hx, f.hy, f.area, f.reach);
+}
+__device__ inline Footprint load_footprint(const float4 *planes, int64_t n_total, int64_t i) {
+    const float4 p0 = planes[i], p1 = planes[n_total + i], p2 = planes[2 * n_total + i], p3 = planes[3 * n_total + i];
+    Footprint f;
+    f.vx[0] = p0.x; f.vy[0] = p0.y; f.vx[1] = p0.z; f.vy[1] = p0.w;
+    f.vx[2] = p1.x; f.vy[2] = p1.y; f.vx[3] = p1.z; f.vy[3] = p1.w;
+    f.cx = p2.x; f.cy = p2.y; f.co = p2.z; f.si = p2.w;
+    f.hx = p3.x; f.hy = p3.y; f.area = p3.z; f.reach = p3.w;
+    return f;
+}
+
+__global__ void __launch_bounds__(256) footprint_kernel(const float *__restrict__ boxes, const int *__restrict__ counts, int n_max, int G,
+                                                        float4 *__restrict__ planes) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)G * n_max) return;
+    const int g = (int)(t / n_max), i = (int)(t - (int64_t)g * n_max);
+    if (counts && i >= counts[g]) return;
+    float b[7];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) b[d] = boxes[t * 7 + d];
+    store_footprint(planes, (int64_t)G * n_max, t, make_footprint(b));
 }
 
 // ---------------------------------------------------------------- stage 1: score keys
@@ -312,11 +371,11 @@ __global__ void __launch_bounds__(kSelThreads) dec_select(const unsigned *__rest
 
 // ---------------------------------------------------------------- stage 3: IoU mask words (upper triangle)
 // One wave per (row, 64-column block): lane = column, so the 64-bit mask word of iou3d_nms_kernel.cu:296-305 is a
-// single wave ballot.  Pairs whose centres are farther apart than the two half-diagonals (+0.1 m, which covers
-// the reference's 1e-2 corner-inside MARGIN) cannot produce an intersection point or an inside corner, so the
-// reference routine returns exactly 0 for them; they skip the geometry.
-__global__ void __launch_bounds__(256) nms_mask(const float *__restrict__ boxes_all, const int *__restrict__ counts, int n_max, int col_blocks,
-                                                float thr, unsigned long long *__restrict__ mask_all) {
+// single wave ballot.  The row's footprint is wave-uniform, the columns' footprints are four coalesced float4 loads.
+// Pairs whose centres are farther apart than the two half-diagonals (+0.1 m, which covers the 1e-2 corner-inside
+// margin) cannot produce a crossing point or an inside corner, so their overlap is exactly 0; they skip the geometry.
+__global__ void __launch_bounds__(256) nms_mask(const float4 *__restrict__ planes, int64_t n_total, const int *__restrict__ counts, int n_max,
+                                                int col_blocks, float thr, unsigned long long *__restrict__ mask_all) {
     const int g = blockIdx.z, cb = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -324,19 +383,14 @@ __global__ void __launch_bounds__(256) nms_mask(const float *__restrict__ boxes_
     if (row >= n) return;
     const int rb = row >> 6;
     if (cb < rb || cb * 64 >= n) return;  // the sweep never reads words left of the diagonal (iou3d_nms.cpp:127)
-    const float *boxes = boxes_all + (int64_t)g * n_max * 7;
-    float cur[7], oth[7];
-#pragma unroll
-    for (int d = 0; d < 7; ++d) cur[d] = boxes[(int64_t)row * 7 + d];
+    const int64_t base = (int64_t)g * n_max;
     const int col = cb * 64 + lane;
     bool hit = false;
     if (col < n && col > row) {
-#pragma unroll
-        for (int d = 0; d < 7; ++d) oth[d] = boxes[(int64_t)col * 7 + d];
-        const float dx = cur[0] - oth[0], dy = cur[1] - oth[1];
-        const float ra = 0.5f * sqrtf(cur[3] * cur[3] + cur[4] * cur[4]), rb2 = 0.5f * sqrtf(oth[3] * oth[3] + oth[4] * oth[4]);
-        const float reach = ra + rb2 + 0.1f;
-        if (dx * dx + dy * dy <= reach * reach) hit = iou_bev(cur, oth) > thr;
+        const Footprint cur = load_footprint(planes, n_total, base + row), oth = load_footprint(planes, n_total, base + col);
+        const float dx = cur.cx - oth.cx, dy = cur.cy - oth.cy;
+        const float reach = cur.reach + oth.reach + 0.1f;
+        if (dx * dx + dy * dy <= reach * reach) hit = footprint_iou(cur, oth) > thr;
     }
     const unsigned long long t = __ballot(hit);
     if (lane == 0) mask_all[((int64_t)g * n_max + row) * col_blocks + cb] = t;
@@ -409,11 +463,11 @@ __global__ void __launch_bounds__(256) iou_pairs(const float *__restrict__ a, in
     int i = (int)(t / nb), j = (int)(t - (int64_t)i * nb);
     float ba[7], bb[7];
     for (int d = 0; d < 7; ++d) { ba[d] = a[i * 7 + d]; bb[d] = b[j * 7 + d]; }
-    out[t] = iou_bev(ba, bb);
+    out[t] = footprint_iou(make_footprint(ba), make_footprint(bb));
 }
 
 struct DecWs {
-    size_t keys, sel_boxes, nms_boxes, sel_scores, sel_cell, sel_count, mask, keep, total;
+    size_t keys, sel_boxes, nms_boxes, sel_scores, sel_cell, sel_count, mask, keep, foot, total;
     int col_blocks, npad;
 };
 DecWs dec_layout(int G, int HW, int pre_max, int post_max) {
@@ -431,6 +485,7 @@ DecWs dec_layout(int G, int HW, int pre_max, int post_max) {
     w.sel_count = take(sizeof(int) * (size_t)G);
     w.mask = take(sizeof(unsigned long long) * (size_t)G * pre_max * w.col_blocks);
     w.keep = take(sizeof(int) * (size_t)G * post_max);
+    w.foot = take(sizeof(Footprint) * (size_t)G * pre_max);
     w.total = off;
     return w;
 }
@@ -472,7 +527,10 @@ extern "C" int fd_centerpoint_decode(const float *hm, int64_t hm_gs, const float
     const size_t lds = (size_t)w.npad * 8 + 4096 * 4 + 32 * 4;
     hipLaunchKernelGGL(dec_select, dim3(G), dim3(kSelThreads), lds, stream, keys, reg, reg_gs, height, h_gs, dim, dim_gs, rot, rot_gs, c, w.npad,
                        sel_boxes, nms_boxes, sel_scores, sel_cell, sel_count);
-    hipLaunchKernelGGL(nms_mask, dim3((c.pre_max + 3) / 4, w.col_blocks, G), dim3(256), 0, stream, nms_boxes, sel_count, c.pre_max, w.col_blocks,
+    float4 *foot = (float4 *)(ws + w.foot);
+    const int64_t n_total = (int64_t)G * c.pre_max;
+    hipLaunchKernelGGL(footprint_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, stream, nms_boxes, sel_count, c.pre_max, G, foot);
+    hipLaunchKernelGGL(nms_mask, dim3((c.pre_max + 3) / 4, w.col_blocks, G), dim3(256), 0, stream, foot, n_total, sel_count, c.pre_max, w.col_blocks,
                        c.iou_thr, mask);
     hipLaunchKernelGGL(nms_sweep, dim3(G), dim3(64), 0, stream, mask, sel_count, c.pre_max, w.col_blocks, c.post_max, keep, c.post_max, out_count);
     hipLaunchKernelGGL(dec_gather, dim3(G), dim3(128), 0, stream, keep, out_count, c.post_max, c.pre_max, sel_boxes, sel_scores, sel_cell,
@@ -483,7 +541,8 @@ extern "C" int fd_centerpoint_decode(const float *hm, int64_t hm_gs, const float
 extern "C" size_t fd_nms_workspace_bytes(int n) {
     if (n <= 0) return 256;
     size_t cb = (size_t)(n + 63) / 64;
-    return fd::align_up(sizeof(unsigned long long) * (size_t)n * cb, 256) + fd::align_up(sizeof(int) * (size_t)n, 256);
+    return fd::align_up(sizeof(unsigned long long) * (size_t)n * cb, 256) + fd::align_up(sizeof(int) * (size_t)n, 256) +
+           fd::align_up(sizeof(Footprint) * (size_t)n, 256);
 }
 
 extern "C" int fd_rotated_nms(const float *boxes7, int n, float thresh, int64_t *keep, int32_t *out_count, void *workspace,
@@ -502,7 +561,9 @@ extern "C" int fd_rotated_nms(const float *boxes7, int n, float thresh, int64_t 
     const int cb = (n + 63) / 64;
     unsigned long long *mask = (unsigned long long *)workspace;
     int *keep32 = (int *)((char *)workspace + fd::align_up(sizeof(unsigned long long) * (size_t)n * cb, 256));
-    hipLaunchKernelGGL(nms_mask, dim3((n + 3) / 4, cb, 1), dim3(256), 0, stream, boxes7, (const int *)nullptr, n, cb, thresh, mask);
+    float4 *foot = (float4 *)((char *)keep32 + fd::align_up(sizeof(int) * (size_t)n, 256));
+    hipLaunchKernelGGL(footprint_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, boxes7, (const int *)nullptr, n, 1, foot);
+    hipLaunchKernelGGL(nms_mask, dim3((n + 3) / 4, cb, 1), dim3(256), 0, stream, foot, (int64_t)n, (const int *)nullptr, n, cb, thresh, mask);
     hipLaunchKernelGGL(nms_sweep, dim3(1), dim3(64), 0, stream, mask, (const int *)nullptr, n, cb, n, keep32, n, out_count);
     hipLaunchKernelGGL(keep_to_i64, dim3((n + 255) / 256), dim3(256), 0, stream, keep32, out_count, n, (long long *)keep);
     return fd::check_launch("fd_rotated_nms");
