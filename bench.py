@@ -9,7 +9,11 @@ One "step" = one pass of the hot path over one batch of synthetic 10-sweep cloud
 voxelize(+mean) -> sparse indexes/rulebooks -> 21 sparse convs -> densify -> RPN -> CenterHead -> decode + rotated
 NMS -> detections copied to the host.  Workload at N=1: BASELINE.json configs[1] (forecast_n0 cars, one 300k-point
 cloud, fp32).  Consecutive steps process DIFFERENT clouds (a pool of --pool seeds, all staged in HBM before the clock
-starts), so no step finds its own rulebooks / features warm in L2 or the Infinity Cache.
+starts), so no step finds its own rulebooks / features warm in L2 or the Infinity Cache.  Up to --inflight (default 2)
+forward passes are in flight per GPU, each on its own HIP stream with its own workspaces and its own captured neck+head
+graph: while the host waits for one sweep's five level counts or its detections, the other sweep's kernels keep the GPU
+busy and fill the tails of each other's launches.  Every step still runs start to finish inside the timed region;
+ms_per_step is the throughput figure (time / steps), a single sweep's latency is that of --inflight 1.
 Samples are independent, so ranks shard them with no data-path collective: by default every rank processes --batch
 clouds per step (weak scaling); ``--config 4`` is BASELINE configs[3], a global batch of 64 clouds (seeds 0..63) split
 rank-strided like DistributedSampler(shuffle=False) and run in micro-batches of 8 (strong scaling).  Every step's
@@ -63,6 +67,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="clouds per rank per forward pass")
     ap.add_argument("--global-batch", type=int, default=0, help=">0: a step = this many clouds in total, split over the ranks (strong scaling)")
     ap.add_argument("--pool", type=int, default=4, help="distinct clouds per rank to rotate through (weak-scaling mode)")
+    ap.add_argument("--inflight", type=int, default=2, help="forward passes in flight per GPU, each on its own HIP stream (1 = strictly serial)")
     ap.add_argument("--channels-last", type=int, default=-1)
     ap.add_argument("--voxel-xy", type=float, default=0.075, help="x/y voxel size (0.05 = the finer grid of BASELINE configs[4])")
     ap.add_argument("--max-voxels", type=int, default=160000)
@@ -252,76 +257,105 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def run_step(si, from_host=None):
-        """One step: every micro-batch of the schedule -> detections on the host, gathered across ranks."""
-        outs = []
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))]
+    n_fwd = [0]
+    pinned = {}  # ring of pinned result buffers (a slot is free again long before the ring wraps: results are retired in order)
+    ring = 2 * (len(schedule(0)) + len(streams))
+
+    def enqueue_step(si, from_host=None):
+        """Enqueues every micro-batch of step si (each forward pass on the next stream of the ring) and the async copy of
+        its detections to pinned host memory; returns the handles retire_step() waits on."""
+        parts = []
         for mb in schedule(si):
-            clouds = [resident[s] for s in seeds[mb]] if from_host is None else from_host(si, mb)
-            prof.begin(mb)
-            p, c = forward(clouds)
-            outs.append((p, c))
-        p = torch.cat([o[0] for o in outs], 0) if len(outs) > 1 else outs[0][0]
-        c = torch.cat([o[1] for o in outs], 0) if len(outs) > 1 else outs[0][1]
-        if world > 1:  # every step's results reach every rank (one fixed-shape all_gather), then the host
-            if one_dev:
-                p, c = dist_infer.gather_results(p.cpu(), c.cpu())
+            st = streams[n_fwd[0] % len(streams)]
+            n_fwd[0] += 1
+            with torch.cuda.stream(st):
+                clouds = [resident[s] for s in seeds[mb]] if from_host is None else from_host(si, mb, st)
+                prof.begin(mb)
+                p, c = forward(clouds)
+                if world > 1 and not one_dev:
+                    parts.append((p, c, None, st))
+                else:
+                    slot = n_fwd[0] % ring
+                    if slot not in pinned or pinned[slot][0].shape != p.shape:
+                        pinned[slot] = (torch.empty(p.shape, dtype=p.dtype, pin_memory=True), torch.empty(c.shape, dtype=c.dtype, pin_memory=True))
+                    hp, hc = pinned[slot]
+                    hp.copy_(p, non_blocking=True)
+                    hc.copy_(c, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    parts.append((hp, hc, ev, st))
+        return parts
+
+    def retire_step(parts):
+        """Detections of one step on the host (and, with several ranks, gathered to every rank by one fixed-shape all_gather)."""
+        ps, cs = [], []
+        for p, c, ev, st in parts:
+            if ev is not None:
+                ev.synchronize()
             else:
-                p, c = dist_infer.gather_results(p, c)
-        return p.cpu(), c.cpu()
+                torch.cuda.current_stream(dev).wait_stream(st)
+            ps.append(p)
+            cs.append(c)
+        p = torch.cat(ps, 0) if len(ps) > 1 else ps[0]
+        c = torch.cat(cs, 0) if len(cs) > 1 else cs[0]
+        if world > 1:
+            p, c = dist_infer.gather_results(p, c)
+        return p.cpu().clone(), c.cpu().clone()
+
+    def run_steps(first, count, from_host=None, on_enqueue=None):
+        """Steps first .. first+count-1 with at most len(streams) forward passes in flight; returns the last step's result."""
+        window, last = [], None
+        depth = max(1, len(streams) // max(1, len(schedule(first))))  # steps in flight (a step may hold several passes)
+        for si in range(first, first + count):
+            if on_enqueue is not None:
+                on_enqueue(si)
+            window.append(enqueue_step(si, from_host))
+            if len(window) > depth - 1:
+                last = retire_step(window.pop(0))
+        while window:
+            last = retire_step(window.pop(0))
+        return last
+
+    def set_prof(si):
+        # the per-launch HIP events of the roofline measurement are taken on every PROF_EVERY-th step of the timed region:
+        # an event pair costs ~5 us of queue time per launch (21 launches per step), which would otherwise be charged to
+        # every step of the headline number
+        prof.enabled = (si % PROF_EVERY == 0)
 
     with torch.no_grad():
-        for si in range(args.warmup):
-            run_step(si)
+        for st in streams:  # set-up, not a warm-up step: every stream captures its neck+head graph and sizes its workspaces
+            with torch.cuda.stream(st):
+                forward([resident[s] for s in seeds[0]])
+        torch.cuda.synchronize()
+        run_steps(0, args.warmup)
         sync_all()
         t0 = time.perf_counter()
-        for si in range(args.steps):
-            # the per-launch HIP events of the roofline measurement are taken on every PROF_EVERY-th step of the timed
-            # region: an event pair costs ~5 us of queue time per launch (21 launches per step), which would otherwise
-            # be charged to every step of the headline number
-            prof.enabled = (si % PROF_EVERY == 0)
-            host_p, host_c = run_step(si)
+        host_p, host_c = run_steps(0, args.steps, on_enqueue=set_prof)
         sync_all()
         dt = time.perf_counter() - t0
         prof.enabled = False
 
-        # ---- second leg: the same K steps with every cloud starting in pinned host memory (H2D inside the clock)
+        # ---- second leg: the same K steps with every cloud starting in pinned host memory (H2D inside the clock, issued
+        #      on the pass's own stream right in front of its voxelizer; the other stream's kernels overlap the copy)
         dt_host = None
         if not args.no_host_leg:
-            copy_stream = torch.cuda.Stream(device=dev)
-            staging = {}  # (parity, slot) -> device buffers; the next step's clouds are uploaded while this one computes
+            staging = {}
 
-            def upload(si):
-                bufs = []
-                with torch.cuda.stream(copy_stream):
-                    for mb in schedule(si):
-                        row = []
-                        for j, s in enumerate(seeds[mb]):
-                            key = (si & 1, mb, j)
-                            if key not in staging or staging[key].shape != host[s].shape:
-                                staging[key] = torch.empty_like(host[s], device=dev)
-                            staging[key].copy_(host[s], non_blocking=True)
-                            row.append(staging[key])
-                        bufs.append(row)
-                    ev = torch.cuda.Event()
-                    ev.record(copy_stream)
-                return bufs, ev
+            def from_host(si, mb, st):
+                row = []
+                for j, s in enumerate(seeds[mb]):
+                    key = (st.cuda_stream, j)
+                    if key not in staging or staging[key].shape != host[s].shape:
+                        staging[key] = torch.empty_like(host[s], device=dev)
+                    staging[key].copy_(host[s], non_blocking=True)
+                    row.append(staging[key])
+                return row
 
-            pending = {}
-
-            def from_host(si, mb):
-                bufs, ev = pending[si]
-                torch.cuda.current_stream(dev).wait_event(ev)
-                return bufs[schedule(si).index(mb)]
-
+            run_steps(0, min(2, args.steps), from_host)  # allocate the staging buffers outside the clock
             sync_all()
             t1 = time.perf_counter()
-            pending[0] = upload(0)
-            for si in range(args.steps):
-                if si + 1 < args.steps:
-                    copy_stream.wait_stream(torch.cuda.current_stream(dev))  # its staging parity was last read two steps ago
-                    pending[si + 1] = upload(si + 1)
-                run_step(si, from_host)
-                pending.pop(si)
+            run_steps(0, args.steps, from_host)
             sync_all()
             dt_host = time.perf_counter() - t1
 
@@ -341,8 +375,8 @@ def main():
         "config": {"workload": "%s %ss, %d-pt synthetic 10-sweep clouds, %s, %s+RPN+CenterHead, %s; timed region = clouds resident in HBM -> "
                                "detections on the host (value_host_to_host: clouds start in pinned host memory)"
                                % (args.variant, args.class_name, n_pts,
-                                  ("global batch %d over %d rank(s), micro-batch %d" % (args.global_batch, world, B)) if strong
-                                  else ("%d per GPU per step, %d distinct clouds per GPU in rotation" % (B, len(seeds))),
+                                  ("global batch %d over %d rank(s), micro-batch %d, %d passes in flight per GPU" % (args.global_batch, world, B, len(streams))) if strong
+                                  else ("%d per GPU per step, %d distinct clouds per GPU in rotation, %d passes in flight per GPU" % (B, len(seeds), len(streams))),
                                   "PointPillars(PillarFeatureNet+Scatter)" if is_pp else "VoxelNet+SpMiddleResNetFHD", args.dtype),
                    "parallelism": "sample-sharded x%d (no data-path collective; one fixed-shape all_gather of the detections per step)" % world,
                    "detections_last_step": int(host_c.sum())},

@@ -12,8 +12,8 @@ namespace fd {
 
 void set_error(const char *fmt, ...);
 int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
-                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, const int *tile_order,
-                                hipStream_t stream);
+                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, const int *ranges,
+                                int n_ranges, hipStream_t stream);
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
@@ -45,7 +45,7 @@ int device_cu_count();  // compute units of the current device, cached per devic
 bool ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done);
 // Tuning / test knobs (fd_tuning_set; initial values are read ONCE from the FD_* environment variables when the
 // library is loaded).  0 = the built-in heuristic.
-enum TuneKey { kTuneSpconvRG = 0, kTuneSpconvV1, kTuneSpconvBf16V1, kTuneV2Depth, kTuneV2TM, kTuneV2LdsPad, kTuneConvNT, kTuneCount };
+enum TuneKey { kTuneSpconvRG = 0, kTuneSpconvV1, kTuneSpconvBf16V1, kTuneV2Depth, kTuneV2TM, kTuneV2LdsPad, kTuneConvNT, kTuneV2RangesPerCU, kTuneV2Uniform, kTuneCount };
 int tuning(TuneKey key);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

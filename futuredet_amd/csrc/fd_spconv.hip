@@ -424,17 +424,18 @@ extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, i
 }
 
 extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *wpacked, const float *bias, const void *residual, int relu,
-                               const int32_t *nbr, int64_t nbr_stride, const int32_t *tile_order, int K, int64_t n_out, int cin, int cout,
-                               int dtype, void *out_feats, fd_stream_t stream) {
+                               const int32_t *nbr, int64_t nbr_stride, const int32_t *ranges, int n_ranges, int K, int64_t n_out, int cin,
+                               int cout, int dtype, void *out_feats, fd_stream_t stream) {
     FD_REQUIRE(K >= 1 && K <= kMaxTaps, "fd_spconv_apply: K must be in [1,27]");
     FD_REQUIRE(dtype == 0 || dtype == 1, "fd_spconv_apply: dtype must be 0 (f32) or 1 (bf16)");
     FD_REQUIRE(n_out >= 0 && n_out <= nbr_stride && n_out < (1ll << 31), "fd_spconv_apply: n_out out of range");
+    FD_REQUIRE(n_ranges >= 0 && (ranges == nullptr || n_ranges >= 1), "fd_spconv_apply: ranges needs n_ranges >= 1");
     if (n_out == 0) return FD_OK;  // an empty active set (empty cloud): nothing to compute, buffers may be null
     FD_REQUIRE(in_feats && wpacked && nbr && out_feats, "fd_spconv_apply: null argument");
     if (dtype == 0 && !fd::tuning(fd::kTuneSpconvV1)) {
         // fp32 is MFMA-bound: the pair-compacting kernel (fd_spconv_v2.hip) feeds the matrix core no zero rows
         if (fd::spconv_f32_compact_dispatch((const float *)in_feats, wpacked, bias, (const float *)residual, relu, nbr, nbr_stride, K, n_in,
-                                            (int)n_out, cin, cout, (float *)out_feats, tile_order, fd::as_stream(stream)))
+                                            (int)n_out, cin, cout, (float *)out_feats, ranges, n_ranges, fd::as_stream(stream)))
             return fd::check_launch("fd_spconv_apply(compact)");
     }
     if (dtype == 1 && cin >= 32 && cout >= 64 && !fd::tuning(fd::kTuneSpconvBf16V1) && n_in * cin * 2 < (1ll << 31)) {

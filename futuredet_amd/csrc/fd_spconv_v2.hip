@@ -5,12 +5,21 @@
 // pairs exist, and a 16-row output group almost never lacks a tap entirely, so the register-resident
 // output-stationary kernel (fd_spconv.hip) spends 40-80 % of its MFMAs on zeros.  This kernel removes them:
 //
-//   * a workgroup owns TM = 128 consecutive output rows (spatially sorted, so their inputs are close);
+//   * a workgroup owns one RANGE of consecutive output rows (spatially sorted, so their inputs are close) and walks it
+//     in chunks of at most TM = 128 rows.  Ranges are either equal row counts or, for rulebooks shared by several
+//     convolutions, equal WORK (fd_spconv_ranges: MFMA groups per 32-row block, prefix sum, quantiles), and there is a
+//     whole number of them per compute unit: no tail round, no heavy / light tile lottery, and -- unlike a work-sorted
+//     tile permutation -- neighbouring workgroups still gather neighbouring input rows.  While a chunk's MFMAs run,
+//     the next chunk's rulebook slice is already on its way into registers;
 //   * the rulebook tile [K][TM] is staged in LDS and compacted IN PLACE per tap with wave ballots /
 //     prefix popcounts into lists of (input row << 8 | local output row) entries, tails filled with -1 --
 //     the "LDS-staged rulebook tile";
-//   * accumulators for the whole tile live in LDS ([TM + 1][COUT] fp32, 64 KB at COUT = 128; row TM is a
-//     scratch row that absorbs the padding lanes so the accumulator traffic needs no exec masking);
+//   * accumulators for the whole chunk live in LDS ([TM + 1][COUT] fp32, 64 KB at COUT = 128; row TM is a
+//     scratch row that absorbs the padding lanes so the accumulator traffic needs no exec masking).  The MFMA is
+//     issued TRANSPOSED (A operand = weight fragment, B operand = gathered rows): lane (pair j, quad q) then holds four
+//     consecutive output channels of pair j's row, so one 16-byte LDS read and one 16-byte write per 16-column block
+//     move the accumulators (the untransposed layout needs four 4-byte accesses each way and four row addresses);
+//     16-byte slots are XOR-swizzled by the row so the 16 rows of a lane group land on distinct banks;
 //   * each wave owns a column slice of the tile (and, for narrow COUT, a row subset) and walks a flattened
 //     work list of (tap, 16-pair group) items: gather the 16 input rows straight into MFMA A-fragment layout
 //     (one 16-byte bounds-checked buffer load per lane and 16-channel chunk, prefetched DEPTH items ahead with
@@ -28,12 +37,31 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxTaps = 27;
 
+// Phase timeline for tuning builds only (tools/probes/build_trace.sh compiles this file with -DFD_V2_TRACE into a
+// separate library; the product library contains none of it): thread 0 of every workgroup stamps s_memtime at the
+// phase boundaries of its first chunk.
+#ifdef FD_V2_TRACE
+__device__ unsigned long long *g_trace;
+#define FD_T(i)                                                                                  \
+    do {                                                                                         \
+        if (threadIdx.x == 0 && g_trace) g_trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define FD_TV(i, v)                                                                    \
+    do {                                                                               \
+        if (threadIdx.x == 0 && g_trace) g_trace[(size_t)blockIdx.x * 16 + (i)] = (v); \
+    } while (0)
+#else
+#define FD_T(i)
+#define FD_TV(i, v)
+#endif
+
 
 template <int CIN, int COUT, int TM, int DEPTH>
 __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restrict__ in, const float4 *__restrict__ wp,
                                                           const float *__restrict__ bias, const float *__restrict__ residual, int relu,
                                                           const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
-                                                          float *__restrict__ out, unsigned in_bytes, const int *__restrict__ tile_order) {
+                                                          float *__restrict__ out, unsigned in_bytes, const int *__restrict__ ranges,
+                                                          int rows_per_range) {
     constexpr int NB = COUT / 16, NC = CIN / 16;
     constexpr int WC = NB == 8 ? 4 : (NB >= 2 ? 2 : 1);  // column splits across the 4 waves (64 columns: 2 x 32)
     constexpr int NBW = NB / WC;          // 16-column blocks per wave
@@ -54,19 +82,68 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     int *s_pad = reinterpret_cast<int *>(s_cnt + 112);                                      // 16 padding entries (tail of the work list)
     float *s_acc = reinterpret_cast<float *>(s_pad + 16);                                   // [TM + 1][COUT], 16-byte aligned for TM = 64 and 128
 
-    // tiles differ in work by up to 2x (dense regions near the sensor): the optional order puts heavy tiles first and
-    // pairs them with light ones on a CU (fd_spconv_tile_order); without it tiles run in index order.
-    const int tile = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
-    const int row0 = tile * TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int t = tid; t < K * TM; t += 256) {
-        int k = t / TM, r = t - k * TM;
-        int64_t o = (int64_t)row0 + r;
-        s_list[t] = (o < nbr_stride) ? nbr[(int64_t)k * nbr_stride + o] : -1;
+    // ---- this workgroup's row range, cut into equal chunks of at most TM rows (multiples of 16)
+    int r_begin, r_end;
+    if (ranges) {
+        r_begin = ranges[blockIdx.x];
+        r_end = ranges[blockIdx.x + 1];
+    } else {
+        const int64_t b = (int64_t)blockIdx.x * rows_per_range;
+        r_begin = (int)(b < n_out ? b : n_out);
+        r_end = (int)(b + rows_per_range < n_out ? b + rows_per_range : n_out);
+    }
+    if (r_end > n_out) r_end = n_out;
+    if (r_begin >= r_end) return;
+    FD_T(0);
+    const int n_chunks = (r_end - r_begin + TM - 1) / TM;
+    const int chunk_rows = (((r_end - r_begin + n_chunks - 1) / n_chunks) + 15) & ~15;
+    // rulebook slice of a chunk, one register per 256 entries; loads are branch-free (clamped address, select on use)
+    constexpr int NPRE = (kMaxTaps * TM + 255) / 256;
+    int pre[NPRE];
+    auto fetch_slice = [&](int row0) {
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int t = tid + i * 256;
+            int k = t / TM;
+            const int r = t - k * TM;
+            k = k < K ? k : K - 1;
+            int64_t o = (int64_t)row0 + r;
+            o = o < nbr_stride ? o : nbr_stride - 1;
+            pre[i] = nbr[(int64_t)k * nbr_stride + o];
+        }
+    };
+    fetch_slice(r_begin);
+
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int wc = wave % WC, wr = TS == 1 ? wave / WC : 0, ts = TS == 1 ? 0 : wave / WC;
+    const int cb = wc * NBW * 16;
+    constexpr int kRowShift = COUT == 16 ? 6 : COUT == 32 ? 7 : COUT == 64 ? 8 : 9;  // log2(COUT * 4)
+    static_assert((COUT * 4) == (1 << kRowShift), "COUT must be 16, 32, 64 or 128");
+    // 16-byte slot swizzle of the accumulator tile: slot ^= f(row) so that 16 different rows at one column slot spread
+    // over the 16 slots of a 256-byte bank row (COUT 64/128: row & 15; 32: two rows per bank row; 16: four)
+    constexpr int kSwzShift = COUT >= 64 ? 0 : COUT == 32 ? 1 : 2;
+    constexpr unsigned kSwzMask = COUT >= 64 ? 15u : COUT == 32 ? 7u : 3u;
+    unsigned char *acc_bytes = reinterpret_cast<unsigned char *>(s_acc + ts * (TM + 1) * COUT);  // this wave's tile copy
+    const unsigned slot0 = (unsigned)(cb >> 2) + (unsigned)lq;  // 16-byte slot of this lane's 4 channels in block nw = 0
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
+    unsigned short *items = s_items + wave * kMaxItems;
+
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+    const int row0 = r_begin + chunk * chunk_rows;
+    const int n_rows = (r_end - row0) < chunk_rows ? (r_end - row0) : chunk_rows;
+    if (n_rows <= 0) break;
+    // ---- stage the prefetched slice, clear the accumulators
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+        const int t = tid + i * 256;
+        const int r = t % TM;
+        if (t < K * TM) s_list[t] = r < n_rows ? pre[i] : -1;
     }
     for (int t = tid; t < TS * (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < 16) s_pad[tid] = kPad;
     __syncthreads();
+    if (chunk == 0) FD_T(1);
     // ---- in-place compaction: wave w takes taps w, w+4, ...; tails are filled with kPad
     for (int k = wave; k < K; k += 4) {
 #pragma unroll
@@ -96,16 +173,11 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         }
     }
     __syncthreads();
+    if (chunk == 0) FD_T(2);
+    // the next chunk's slice travels while this chunk computes
+    if (chunk + 1 < n_chunks) fetch_slice(row0 + chunk_rows);
 
-    const int lrow = lane & 15, lq = lane >> 4;
-    const int wc = wave % WC, wr = TS == 1 ? wave / WC : 0, ts = TS == 1 ? 0 : wave / WC;
-    const int cb = wc * NBW * 16;
-    constexpr int kRowShift = COUT == 16 ? 6 : COUT == 32 ? 7 : COUT == 64 ? 8 : 9;  // log2(COUT * 4)
-    static_assert((COUT * 4) == (1 << kRowShift), "COUT must be 16, 32, 64 or 128");
-    unsigned char *acc_bytes = reinterpret_cast<unsigned char *>(s_acc + ts * (TM + 1) * COUT);  // this wave's tile copy
-    const unsigned lane_off = (unsigned)(cb + lrow) * 4u;
     // ---- flattened work list of this wave: one item = 16 compacted pairs of one tap, code = (tap << 3) | group
-    unsigned short *items = s_items + wave * kMaxItems;
     int n_items;
     unsigned long long tapmask;
     {
@@ -129,9 +201,8 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     // slot past the end of the work list gets an out-of-range offset and reads zeros, so prefetch AND compute are
     // branch-free (exec-masked loads forced vmcnt(0), i.e. no overlap at all; branches around the MFMAs kept the
     // compiler from interleaving the bookkeeping VALU/LDS work with them).
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
     int k_r[DEPTH];
-    i32x4 rows_r[DEPTH];  // entries of the 4 accumulator rows this lane touches (group rows 4*lq .. 4*lq+3)
+    int row_r[DEPTH];  // list entry of pair `lrow` of the item: input row << 8 | local output row
     u32x4 a_r[DEPTH][NC];
     // Bookkeeping is kept off the vector ALU (it competes with the MFMAs for issue slots): the item code is
     // wave-uniform (scalar registers), and a list entry needs no compare/select -- the padding entry kPad has all
@@ -149,7 +220,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     // A wave owns its accumulator elements and LDS operations of a wave execute in order, so the sums are formed in a
     // fixed order (taps ascending): deterministic.
     auto stage_a0 = [&](int it) -> int { return (int)items[it < n_items ? it : 0]; };
-    auto stage_a1 = [&](int it, int code_v, int &kk, int &e, i32x4 &rows) {
+    auto stage_a1 = [&](int it, int code_v, int &kk, int &e) {
         const bool v = it < n_items;  // uniform (n_items is in a scalar register)
         const int code = __builtin_amdgcn_readfirstlane(code_v);
         const int ks = v ? (code >> 3) : 0;
@@ -157,15 +228,11 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         // past the end of the work list the (scalar) list pointer selects a block of 16 padding entries: no per-lane select
         const int *lst = v ? s_list + ks * TM + wr * RW + ((code & 7) << 4) : s_pad;
         e = lst[lrow];
-        rows = *reinterpret_cast<const i32x4 *>(lst + lq * 4);
     };
-    auto stage_b = [&](int kk, int e, const i32x4 &rows_in, i32x4 &rows, u32x4(&a)[NC]) -> unsigned {
-        rows = rows_in;
+    auto gather_offset = [&](int e) -> unsigned {
         // byte offset of the input row = (e >> 8) * CIN * 4, computed on the masked entry without a multiply
         const unsigned hi = (unsigned)e & 0xffffff00u;
-        const unsigned voff = (CIN >= 64 ? hi << (CIN == 128 ? 1 : 0) : hi >> (CIN == 32 ? 1 : 2)) + (unsigned)(lq * 16);
-        (void)a;
-        return voff;
+        return (CIN >= 64 ? hi << (CIN == 128 ? 1 : 0) : hi >> (CIN == 32 ? 1 : 2)) + (unsigned)(lq * 16);
     };
     auto gather_chunk = [&](unsigned voff, int c) { return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + c * 64, 0, 0); };
     auto load_b = [&](int k, float4(&dst)[NC][NBW]) {
@@ -183,49 +250,55 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     float4 b[NC][NBW];
     static_assert(DEPTH >= 2, "the slot freed by the previous item is refilled during the current item's MFMAs");
     int k_s, e_s, code_s;
-    i32x4 rows_s;
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) {
-        stage_a1(d, stage_a0(d), k_s, e_s, rows_s);
-        const unsigned vo = stage_b(k_s, e_s, rows_s, rows_r[d], a_r[d]);
+        stage_a1(d, stage_a0(d), k_s, e_s);
+        const unsigned vo = gather_offset(e_s);
 #pragma unroll
         for (int c = 0; c < NC; ++c) a_r[d][c] = gather_chunk(vo, c);
         k_r[d] = k_s;
+        row_r[d] = e_s;
     }
     k_r[DEPTH - 1] = -1;
-    stage_a1(DEPTH - 1, stage_a0(DEPTH - 1), k_s, e_s, rows_s);  // staged for the first loop iteration
+    row_r[DEPTH - 1] = kPad;
+    stage_a1(DEPTH - 1, stage_a0(DEPTH - 1), k_s, e_s);  // staged for the first loop iteration
     code_s = stage_a0(DEPTH);
-    if (n_items > 0) load_b(k_r[0], b);  // weights of the first tap (the only exposed weight latency of the tile)
+    if (n_items > 0) load_b(k_r[0], b);  // weights of the first tap (the only exposed weight latency of the chunk)
+    if (chunk == 0) { FD_T(3); FD_TV(8, (unsigned long long)n_items); FD_TV(9, (unsigned long long)n_chunks); FD_TV(10, (unsigned long long)n_rows);
+                      FD_TV(11, (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11))); FD_TV(12, (unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11))); }
+    FD_TV(13, (unsigned long long)(g_trace ? g_trace[(size_t)blockIdx.x * 16 + 13] : 0) + (unsigned long long)n_items);
 
+    // transposed product: A operand = weight fragment (row index = output channel), B operand = gathered rows (column
+    // index = pair), so acc[nw] of lane (pair lrow, quad lq) = out[pair][cb + 16 nw + 4 lq .. + 3]
     auto mfma_chunk = [&](const u32x4 &a4, const float4(&bc)[NBW], f32x4(&acc)[NACC]) {
         const float4 av = __builtin_bit_cast(float4, a4);
 #pragma unroll
-        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bc[nw].x, acc[nw], 0, 0, 0);
+        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[nw].x, av.x, acc[nw], 0, 0, 0);
 #pragma unroll
-        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bc[nw].y, acc[nw], 0, 0, 0);
+        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[nw].y, av.y, acc[nw], 0, 0, 0);
 #pragma unroll
-        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bc[nw].z, acc[nw], 0, 0, 0);
+        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[nw].z, av.z, acc[nw], 0, 0, 0);
 #pragma unroll
-        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bc[nw].w, acc[nw], 0, 0, 0);
+        for (int nw = 0; nw < NBW; ++nw) acc[nw] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[nw].w, av.w, acc[nw], 0, 0, 0);
     };
 
     for (int i0 = 0; i0 < n_items; i0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            // accumulator rows: the row field of a padding entry is the scratch row TM
-            // (byte offsets: one AND and one shift-add per row; the lane's column offset is loop invariant)
-            unsigned aoff[4];
+            // accumulator row of this lane's pair (the row field of a padding entry is the scratch row TM): one swizzled
+            // 16-byte slot per 16-column block
+            const unsigned arow = (unsigned)row_r[d] & 255u;
+            const unsigned abase = arow << kRowShift, aswz = (arow >> kSwzShift) & kSwzMask;
+            unsigned aoff[NBW];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) aoff[r] = (((unsigned)rows_r[d][r] & 255u) << kRowShift) + lane_off;
+            for (int nw = 0; nw < NBW; ++nw) aoff[nw] = abase + (((slot0 + 4u * nw) ^ aswz) << 4);
             // The old accumulator values are requested first and are the C operand of the MFMA chain: the matrix pipe
             // does the accumulation and D goes back to LDS untouched -- no vector-ALU work on the accumulators at all
             // (VALU instructions of one wave barely overlap the MFMAs of the other waves of its SIMD, so every VALU
             // instruction saved per item is matrix-pipe time gained).  The bookkeeping below covers the LDS latency.
             f32x4 acc[NACC];
 #pragma unroll
-            for (int nw = 0; nw < NBW; ++nw)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[nw][r] = *reinterpret_cast<const float *>(acc_bytes + aoff[r] + nw * 64);
+            for (int nw = 0; nw < NBW; ++nw) acc[nw] = *reinterpret_cast<const f32x4 *>(acc_bytes + aoff[nw]);
             // refill the slot freed by the previous item BEFORE this item's MFMAs (left to itself hipcc sinks the loads
             // below the MFMA block and waits vmcnt(0) for them at the top of the next item), then advance the two
             // bookkeeping stages; their results are first touched in the next iteration.
@@ -233,9 +306,10 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
             unsigned vo;
             {
                 const int it = i0 + d + DEPTH - 1;
-                vo = stage_b(k_s, e_s, rows_s, rows_r[dn], a_r[dn]);
+                vo = gather_offset(e_s);
                 k_r[dn] = k_s;
-                stage_a1(it + 1, code_s, k_s, e_s, rows_s);
+                row_r[dn] = e_s;
+                stage_a1(it + 1, code_s, k_s, e_s);
                 code_s = stage_a0(it + 2);
             }
             const int knext = k_r[(d + 1) % DEPTH];                 // tap of the next item (-1 past the end), wave-uniform
@@ -271,23 +345,23 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
                 }
             }
 #pragma unroll
-            for (int nw = 0; nw < NBW; ++nw)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) *reinterpret_cast<float *>(acc_bytes + aoff[r] + nw * 64) = acc[nw][r];
+            for (int nw = 0; nw < NBW; ++nw) *reinterpret_cast<f32x4 *>(acc_bytes + aoff[nw]) = acc[nw];
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (chunk == 0) FD_T(4);
     __syncthreads();
-    // ---- epilogue: whole tile, float4 per thread, rows contiguous
+    if (chunk == 0) FD_T(5);
+    // ---- epilogue: whole chunk, float4 per thread, rows contiguous in global memory (swizzled slots in LDS)
     constexpr int C4 = COUT / 4;
-    for (int t = tid; t < TM * C4; t += 256) {
+    for (int t = tid; t < n_rows * C4; t += 256) {
         const int r = t / C4, c4 = t - r * C4;
         const int row = row0 + r;
-        if (row >= n_out) break;
-        float4 v = reinterpret_cast<const float4 *>(s_acc)[t];
+        const int ts4 = r * C4 + (c4 ^ (int)(((unsigned)r >> kSwzShift) & kSwzMask));
+        float4 v = reinterpret_cast<const float4 *>(s_acc)[ts4];
 #pragma unroll
         for (int q = 1; q < TS; ++q) {
-            const float4 v2 = reinterpret_cast<const float4 *>(s_acc + q * (TM + 1) * COUT)[t];
+            const float4 v2 = reinterpret_cast<const float4 *>(s_acc + q * (TM + 1) * COUT)[ts4];
             v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
         }
         if (bias) {
@@ -301,21 +375,35 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         reinterpret_cast<float4 *>(out + (int64_t)row * COUT)[c4] = v;
     }
+    __syncthreads();  // the next chunk re-uses the list and the accumulator tile
+    if (chunk == 0) FD_T(6);
+    }  // chunk loop
+    FD_T(7);
+}
+
+constexpr size_t lds_bytes(int tm, int cout) {
+    return sizeof(int) * kMaxTaps * tm + sizeof(unsigned short) * 4 * kMaxTaps * (tm / 16) + 112 + 64 +
+           sizeof(float) * (tm + 1) * cout * (cout == 32 || cout == 64 ? 2 : 1);
+}
+
+// LDS request of one workgroup.  Occupancy is not a lever here: MFMA and non-MFMA instructions of the waves sharing a
+// SIMD execute almost serially (128 channels: one workgroup per CU is only 9 % slower than two), and for the 64->64
+// layers two workgroups per CU beat the three that would fit (300 -> 278 us: less contention in the gather path), so
+// their request is rounded up to just over a third of the CU's 160 KB.
+inline size_t lds_request(int cin, int cout, int tm) {
+    const size_t lds = lds_bytes(tm, cout);
+    const size_t pad = (size_t)fd::tuning(fd::kTuneV2LdsPad);  // occupancy experiments
+    if (pad) return lds + pad;
+    return (cin == 64 && cout == 64 && tm == 128 && lds < 56 * 1024) ? (size_t)56 * 1024 : lds;
 }
 
 template <int CIN, int COUT, int TM, int DEPTH>
 int launch_compact(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
-                   int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, const int *tile_order, hipStream_t stream) {
-    const size_t lds = sizeof(int) * kMaxTaps * TM + sizeof(unsigned short) * 4 * kMaxTaps * (TM / 16) + 112 + 64 + sizeof(float) * (TM + 1) * COUT * (COUT == 32 || COUT == 64 ? 2 : 1);
-    const size_t lds_pad = (size_t)fd::tuning(fd::kTuneV2LdsPad);  // occupancy experiments
-    // Occupancy is not a lever here: MFMA and non-MFMA instructions of the waves sharing a SIMD execute almost serially
-    // (128 channels: one workgroup per CU is only 9 % slower than two), and for the 64->64 layers two workgroups per
-    // CU beat the three that would fit (300 -> 278 us: less contention in the gather path), so their LDS request is
-    // rounded up to just over a third of the CU's 160 KB.
-    const size_t lds_req = (CIN == 64 && COUT == 64 && TM == 128 && !lds_pad ? (lds > 56 * 1024 ? lds : (size_t)56 * 1024) : lds) + lds_pad;
+                   int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, const int *ranges, int n_ranges, hipStream_t stream) {
+    const size_t lds_req = lds_request(CIN, COUT, TM);
     static std::atomic<uint64_t> lds_set{0};  // devices on which this instantiation has its LDS limit raised
     auto kern = spconv_f32_compact<CIN, COUT, TM, DEPTH>;
-    if (lds_pad) {  // tuning runs change the request between calls: set it every time
+    if (fd::tuning(fd::kTuneV2LdsPad)) {  // tuning runs change the request between calls: set it every time
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
@@ -323,91 +411,141 @@ int launch_compact(const float *in, const void *wp, const float *bias, const flo
     } else if (!fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_req, lds_set)) {
         return 0;
     }
-    dim3 grid((unsigned)((n_out + TM - 1) / TM));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds_req, stream, in, (const float4 *)wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, tile_order);
+    int rows_per = 0;
+    if (!ranges) {  // equal row counts (multiples of 16): n_ranges == 0 -> one TM-row tile per workgroup
+        if (n_ranges <= 0) n_ranges = (n_out + TM - 1) / TM;
+        rows_per = (((n_out + n_ranges - 1) / n_ranges) + 15) & ~15;
+        n_ranges = (n_out + rows_per - 1) / rows_per;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_ranges), dim3(256), lds_req, stream, in, (const float4 *)wp, bias, residual, relu, nbr, nbr_stride, K,
+                       n_out, out, in_bytes, ranges, rows_per);
     return 1;
 }
 
-// ---------------------------------------------------------------------------------------------- tile order
-// work of a 128-row tile = number of 16-pair MFMA groups = sum over taps of ceil(valid rows / 16)
-__global__ void __launch_bounds__(256) tile_work_kernel(const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_tiles, unsigned *__restrict__ keys) {
-    // one workgroup per tile; wave w counts taps w, w+4, ... with two 64-row ballots each (no barrier per tap)
-    const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ int s_work[4];
-    int work = 0;
-    const int64_t o0 = (int64_t)tile * 128 + lane, o1 = o0 + 64;
-    for (int k = wave; k < K; k += 4) {
-        const int *row = nbr + (int64_t)k * nbr_stride;
-        const bool v0 = o0 < nbr_stride && row[o0] >= 0;
-        const bool v1 = o1 < nbr_stride && row[o1] >= 0;
-        work += (__popcll(__ballot(v0)) + __popcll(__ballot(v1)) + 15) >> 4;
+// ---------------------------------------------------------------------------------------------- work-balanced ranges
+// work of an 8-row block in 1/32 of a 16-pair MFMA group: 2 per pair, + 1 per (block, tap) that has pairs (its share of
+// the list padding: half a group per tap and 128-row chunk), + 4 for the per-row cost of prologue / epilogue.
+// One wave covers 64 rows = 8 blocks with one ballot per tap; lane i < 8 accumulates block i.
+constexpr int kWorkRows = 8;
+__global__ void __launch_bounds__(256) block_work_kernel(const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out, int n_blocks,
+                                                         unsigned *__restrict__ work) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t o = wave * 64 + lane;
+    if (wave * 8 >= n_blocks) return;
+    unsigned w = 4u;
+    for (int k = 0; k < K; ++k) {
+        const bool v = o < n_out && nbr[(int64_t)k * nbr_stride + o] >= 0;
+        const unsigned long long m = __ballot(v);
+        const unsigned byte = (unsigned)(m >> (8 * (lane & 7))) & 0xffu;
+        w += (unsigned)__popc(byte) * 2u + (byte ? 1u : 0u);
     }
-    if (lane == 0) s_work[wave] = work;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        work = s_work[0] + s_work[1] + s_work[2] + s_work[3];
-        keys[tile] = ((unsigned)work << 20) | (0xfffffu - (unsigned)tile);  // sort key: work desc, tile asc
-    }
+    if (lane < 8 && wave * 8 + lane < n_blocks) work[wave * 8 + lane] = w;
 }
 
-// single workgroup: counting sort by work (at most 27 * 8 = 216 distinct values), heaviest first, then the CU
-// pairing rule.  Ties are placed in arrival order of the atomics: the order only steers scheduling, results do not
-// depend on it.
-__global__ void __launch_bounds__(1024) tile_sort_kernel(const unsigned *__restrict__ keys, int n_tiles, int n_cu, int *__restrict__ sorted,
-                                                         int *__restrict__ order) {
-    __shared__ int s_hist[256], s_start[256];
-    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+// single workgroup: prefix over the block works, range j = blocks whose work midpoint falls into the j-th of n_ranges
+// equal slices of the total.  Boundaries are multiples of 8 rows; a range may be empty (one block heavier than a slice).
+__global__ void __launch_bounds__(1024) range_split_kernel(const unsigned *__restrict__ work, int n_blocks, int n_out, int n_ranges,
+                                                           int *__restrict__ ranges) {
+    __shared__ unsigned long long s_part[1024];
+    __shared__ unsigned long long s_total;
+    const int tid = threadIdx.x;
+    const int per = (n_blocks + 1023) / 1024;
+    const int b0 = tid * per, b1 = min(n_blocks, b0 + per);
+    unsigned long long sum = 0;
+    for (int b = b0; b < b1; ++b) sum += work[b];
+    s_part[tid] = sum;
     __syncthreads();
-    for (int i = threadIdx.x; i < n_tiles; i += 1024) atomicAdd(&s_hist[min((int)(keys[i] >> 20), 255)], 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int w = 255; w >= 0; --w) { s_start[w] = acc; acc += s_hist[w]; }
+    // Hillis-Steele inclusive scan over the 1024 partial sums
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned long long v = tid >= off ? s_part[tid - off] : 0ull;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
     }
+    if (tid == 1023) s_total = s_part[1023];
     __syncthreads();
-    for (int i = threadIdx.x; i < n_tiles; i += 1024) {
-        const int w = min((int)(keys[i] >> 20), 255);
-        sorted[atomicAdd(&s_start[w], 1)] = i;
+    const unsigned long long total = s_total > 0 ? s_total : 1ull;
+    unsigned long long run = s_part[tid] - sum;  // exclusive prefix of this thread's first block
+    auto range_of = [&](unsigned long long ex, unsigned w) -> int {
+        const unsigned long long r = ((2ull * ex + w) * (unsigned long long)n_ranges) / (2ull * total);
+        return (int)(r < (unsigned long long)n_ranges ? r : (unsigned long long)(n_ranges - 1));
+    };
+    int prev = -1;  // range of the block before b0 (-1 in front of block 0: every range up to the first one starts at row 0)
+    if (b0 > 0 && b0 < n_blocks) prev = range_of(run - work[b0 - 1], work[b0 - 1]);
+    for (int b = b0; b < b1; ++b) {
+        const unsigned w = work[b];
+        const int rg = range_of(run, w);
+        for (int j = prev + 1; j <= rg; ++j) ranges[j] = b * kWorkRows;
+        prev = rg;
+        run += w;
     }
-    __syncthreads();
-    __threadfence_block();
-    // all tiles resident at once (<= 2 per CU): workgroups b and b + n_cu tend to share a CU, so the heaviest n_cu tiles
-    // go first and are followed by the rest lightest-first; otherwise plain heaviest-first (greedy LPT by the dispatcher)
-    const bool pair = n_tiles <= 2 * n_cu;
-    const int nh = n_tiles < n_cu ? n_tiles : n_cu;
-    for (int i = threadIdx.x; i < n_tiles; i += 1024) {
-        const int src = (!pair || i < nh) ? i : n_tiles - 1 - (i - nh);
-        order[i] = sorted[src];
+    if (b1 == n_blocks && b0 < n_blocks) {  // the thread owning the last block closes the table
+        for (int j = prev + 1; j <= n_ranges; ++j) ranges[j] = n_out;
     }
+    if (n_blocks == 0 && tid == 0)
+        for (int j = 0; j <= n_ranges; ++j) ranges[j] = 0;
 }
 
 }  // namespace
 
-extern "C" int fd_spconv_tile_order(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int32_t *order, void *workspace,
-                                    size_t workspace_bytes, fd_stream_t stream_) {
-    FD_REQUIRE(nbr && order && workspace, "fd_spconv_tile_order: null argument");
-    const int64_t n_tiles = (n_out + 127) / 128;
-    FD_REQUIRE(n_tiles >= 1 && n_tiles < (1 << 20), "fd_spconv_tile_order: supports up to 2^20 tiles of 128 rows (got %lld)", (long long)n_tiles);
-    FD_REQUIRE(workspace_bytes >= 2 * sizeof(unsigned) * (size_t)n_tiles, "fd_spconv_tile_order: workspace too small");
-    hipStream_t stream = fd::as_stream(stream_);
+#ifdef FD_V2_TRACE
+extern "C" int fd_debug_set_trace(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#endif
+
+// How many ranges fd_spconv_apply wants for a layer shape (measured on MI355X, 300k-point cloud, tools/spconv_bench.py):
+//   * Cout >= 64 (MFMA-bound, two workgroups resident per CU): exactly one range per resident workgroup slot, equal
+//     WORK -- every CU gets the same number of MFMA groups and finishes together (64->64: 229 -> 200 us, 128->128:
+//     320 -> 308 us); more, shorter ranges lose that (greedy dispatch leaves up to one range of imbalance per CU);
+//   * narrower layers are bound by the per-row skeleton (prologue / compaction / epilogue), three to six workgroups
+//     are resident per CU and overlap each other's phases: about one 128-row chunk per range, rounded up to a whole
+//     number of ranges per CU, equal ROWS (equal-work ranges put several chunks of a sparse region behind each other
+//     in one workgroup: 16->16 28 -> 56 us).
+extern "C" int fd_spconv_num_ranges(int64_t n_out, int cin, int cout, int dtype) {
+    if (n_out <= 0 || dtype != 0) return 0;
     const int n_cu = fd::device_cu_count();
-    unsigned *keys = (unsigned *)workspace;
-    int *sorted = (int *)(keys + n_tiles);
-    hipLaunchKernelGGL(tile_work_kernel, dim3((unsigned)n_tiles), dim3(256), 0, stream, nbr, nbr_stride, K, (int)n_tiles, keys);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(1), dim3(1024), 0, stream, keys, (int)n_tiles, n_cu, sorted, order);
-    return fd::check_launch("fd_spconv_tile_order");
+    const int64_t tiles = (n_out + 127) / 128;
+    const int mult = fd::tuning(fd::kTuneV2RangesPerCU);  // tuning override
+    int64_t per_cu;
+    if (mult) per_cu = mult;
+    else if (cout >= 64) per_cu = (int64_t)((160 * 1024) / lds_request(cin, cout, 128));
+    else per_cu = (tiles + n_cu - 1) / n_cu;
+    if (per_cu < 1) per_cu = 1;
+    return (int)(per_cu * n_cu);
+}
+
+// 1 when the layer shape profits from equal-work ranges (fd_spconv_ranges), 0 when equal rows are the better split
+extern "C" int fd_spconv_wants_balanced_ranges(int cin, int cout, int dtype) { return dtype == 0 && cout >= 64 && !fd::tuning(fd::kTuneV2Uniform); }
+
+extern "C" size_t fd_spconv_ranges_workspace_bytes(int64_t n_out) {
+    return fd::align_up(sizeof(unsigned) * (size_t)((n_out + kWorkRows - 1) / kWorkRows + 8), 256);
+}
+
+extern "C" int fd_spconv_ranges(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int n_ranges, int32_t *ranges, void *workspace,
+                                size_t workspace_bytes, fd_stream_t stream_) {
+    FD_REQUIRE(nbr && ranges && workspace, "fd_spconv_ranges: null argument");
+    FD_REQUIRE(n_ranges >= 1 && n_out >= 0 && n_out <= nbr_stride && n_out < (1ll << 31), "fd_spconv_ranges: bad sizes");
+    FD_REQUIRE(workspace_bytes >= fd_spconv_ranges_workspace_bytes(n_out), "fd_spconv_ranges: workspace too small");
+    hipStream_t stream = fd::as_stream(stream_);
+    const int n_blocks = (int)((n_out + kWorkRows - 1) / kWorkRows);
+    unsigned *work = (unsigned *)workspace;
+    if (n_blocks > 0)
+        hipLaunchKernelGGL(block_work_kernel, dim3((unsigned)((n_blocks + 31) / 32)), dim3(256), 0, stream, nbr, nbr_stride, K, (int)n_out, n_blocks, work);
+    hipLaunchKernelGGL(range_split_kernel, dim3(1), dim3(1024), 0, stream, work, n_blocks, (int)n_out, n_ranges, ranges);
+    return fd::check_launch("fd_spconv_ranges");
 }
 
 namespace fd {
 // returns 1 when launched, 0 when this shape is not covered (caller falls back to the register kernel)
 int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
-                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, const int *tile_order, hipStream_t stream) {
+                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, const int *ranges,
+                                int n_ranges, hipStream_t stream) {
     // (input row << 8 | local row) must fit an int32 and the feature matrix a 31-bit buffer range
     if (n_in_bound >= (1ll << 23) || n_in_bound * cin * 4 >= (1ll << 31)) return 0;
     const unsigned in_bytes = (unsigned)(n_in_bound * cin * 4);
     const int dsel = fd::tuning(fd::kTuneV2Depth), tsel = fd::tuning(fd::kTuneV2TM);  // tuning overrides
 #define FD_LAUNCH(CI, CO, T, D) \
-    launch_compact<CI, CO, T, D>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, (T == 128 ? tile_order : nullptr), stream)
+    launch_compact<CI, CO, T, D>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, ranges, n_ranges, stream)
 #define FD_CASE(CI, CO, DDEF, TDEF)                                  \
     if (cin == CI && cout == CO) {                                   \
         const int dd = dsel ? dsel : DDEF, tt = tsel ? tsel : TDEF;  \

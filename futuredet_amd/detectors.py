@@ -129,18 +129,21 @@ class VoxelNet(SingleStageDetector):
         if cache.get("version") != ver:
             cache.clear()
             cache["version"] = ver
-        key = (B, dt, bb.dense_channels_last, idx4.D, idx4.H, idx4.W, dev)
+        # one graph (with its own static input / output buffers) per stream: sweeps in flight on different streams replay
+        # different graphs
+        key = (B, dt, bb.dense_channels_last, idx4.D, idx4.H, idx4.W, dev, torch.cuda.current_stream(dev).cuda_stream)
         if key in cache:
             return cache[key]
         try:
             static_bev = torch.empty((B, 128 * idx4.D, idx4.H, idx4.W), dtype=dt, device=dev,
                                      memory_format=torch.channels_last if bb.dense_channels_last else torch.contiguous_format).zero_()
+            cur = torch.cuda.current_stream(dev)
             side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
+            side.wait_stream(cur)
             with torch.cuda.stream(side):
                 for _ in range(2):
                     self.bbox_head(self.neck(static_bev), None)
-            torch.cuda.current_stream(dev).wait_stream(side)
+            cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 preds = self.bbox_head(self.neck(static_bev), None)

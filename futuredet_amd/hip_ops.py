@@ -1,7 +1,6 @@
 """Torch-tensor front end of the C ABI (include/futuredet_hip.h).  Tensors are device memory plumbing only:
 every function passes raw pointers + the current HIP stream to libfuturedet_hip.so.  No CPU fallbacks."""
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -11,7 +10,6 @@ from .lib import DecodeCfg, FutureDetHipError, check
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_NO_TILE_ORDER = bool(os.environ.get("FD_NO_TILE_ORDER"))
 
 
 def _stream():
@@ -38,13 +36,14 @@ def _p(t):
 
 
 class _Workspace(object):
-    """Grow-only per-(device, tag) scratch buffers so steady-state steps do no allocation."""
+    """Grow-only per-(tag, device, stream) scratch buffers so steady-state steps do no allocation.  The stream is part
+    of the key: sweeps in flight on different streams (bench.py --inflight, serving) must not share scratch memory."""
 
     def __init__(self):
         self._bufs = {}
 
     def get(self, tag, nbytes, device):
-        key = (tag, device.index)
+        key = (tag, device.index, _stream().value)
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -233,24 +232,25 @@ def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device):
     return idx
 
 
-def tile_order_for(nbr):
-    """Work-sorted 128-row tile order of a rulebook (fp32 kernel only); computed once, shared by every convolution
-    that reuses the rulebook."""
-    order = getattr(nbr, "tile_order", None)
-    if order is None:
-        L = _lib.load()
-        n_out = getattr(nbr, "n_out", None)
-        if n_out is None or n_out == 0:
-            return None
-        K, nstride = nbr.shape
-        n_tiles = (n_out + 127) // 128
-        if n_tiles >= (1 << 20):
-            return None
-        order = torch.empty((n_tiles,), dtype=torch.int32, device=nbr.device)
-        ws = workspace.get("tile_order", 8 * n_tiles, nbr.device)
-        check(L.fd_spconv_tile_order(_p(nbr), nstride, K, n_out, _p(order), _p(ws), ws.numel(), _stream()), "fd_spconv_tile_order")
-        nbr.tile_order = order
-    return order
+def ranges_for(nbr, cin, cout):
+    """Work-balanced row ranges of a rulebook for the fp32 kernel (fd_spconv_ranges); computed once per rulebook and
+    shared by every convolution that reuses it.  Returns (ranges int32[n+1], n) or (None, n) for an equal-rows split."""
+    cached = getattr(nbr, "ranges", None)
+    if cached is not None:
+        return cached
+    L = _lib.load()
+    n_out = getattr(nbr, "n_out", None)
+    if not n_out:
+        return None, 0
+    K, nstride = nbr.shape
+    n = int(L.fd_spconv_num_ranges(n_out, cin, cout, 0))
+    if n <= 0:
+        return None, 0
+    ranges = torch.empty((n + 1,), dtype=torch.int32, device=nbr.device)
+    ws = workspace.get("spconv_ranges", L.fd_spconv_ranges_workspace_bytes(n_out), nbr.device)
+    check(L.fd_spconv_ranges(_p(nbr), nstride, K, n_out, n, _p(ranges), _p(ws), ws.numel(), _stream()), "fd_spconv_ranges")
+    nbr.ranges = (ranges, n)
+    return nbr.ranges
 
 
 def rows_permute(src, row_of, c_dst, dtype=torch.float32, n_rows=None, n_dev=None):
@@ -279,7 +279,7 @@ def pack_spconv_weight(w_kio, dtype=torch.float32):
     return host.to(dev)
 
 
-def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=False, out=None):
+def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=False, out=None, balanced=None):
     L = _lib.load()
     feats = _dev(feats, "feats")
     dt = _DT[feats.dtype]
@@ -289,13 +289,21 @@ def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=Fal
         out = torch.empty((max(n_out, 1), cout), dtype=feats.dtype, device=feats.device)[:n_out]
     if residual is not None:
         _dev(residual, "residual", feats.dtype)
-    # Work-sorted tile order only where it pays (measured): the MFMA-bound 64- and 128-channel residual layers gain
-    # 7-12 % from balanced CUs; the narrow / strided layers are gather-bound and lose 5-25 % of their spatial locality
-    # when tiles leave index order (and skip the two ordering kernels).
-    order = tile_order_for(nbr) if (dt == 0 and K == 27 and cin == cout and cin >= 64
-                                    and not _NO_TILE_ORDER) else None
+    # fp32: the kernel walks row ranges.  The MFMA-bound SubM layers (Cout >= 64; their rulebook is shared by the 4-5
+    # convolutions of a level) get equal-WORK ranges from fd_spconv_ranges; narrow layers and strided convolutions (rulebook
+    # used once) take equal row counts -- see fd_spconv_num_ranges for the measurements.
+    ranges, n_ranges = None, 0
+    if dt == 0 and n_out > 0:
+        if balanced is None:
+            balanced = K == 27 and cin == cout and bool(L.fd_spconv_wants_balanced_ranges(cin, cout, dt))
+        if balanced == "tiles":      # one 128-row tile per workgroup (tuning comparisons)
+            n_ranges = 0
+        elif balanced:
+            ranges, n_ranges = ranges_for(nbr, cin, cout)
+        else:
+            n_ranges = int(L.fd_spconv_num_ranges(n_out, cin, cout, 0))
     check(L.fd_spconv_apply(_p(feats), feats.shape[0], _p(_dev(wpacked, "wpacked")), _p(bias), _p(residual), int(bool(relu)),
-                            _p(_dev(nbr, "nbr", torch.int32)), nstride, _p(order), K, n_out, cin, cout, dt, _p(out), _stream()),
+                            _p(_dev(nbr, "nbr", torch.int32)), nstride, _p(ranges), n_ranges, K, n_out, cin, cout, dt, _p(out), _stream()),
           "fd_spconv_apply")
     return out
 

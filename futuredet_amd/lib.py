@@ -49,9 +49,12 @@ SIGNATURES = {
                             c_void_p, c_void_p, c_void_p]),
     "fd_spconv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "fd_spconv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "fd_spconv_apply": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p, c_int, c_i64,
+    "fd_spconv_apply": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p, c_int, c_int, c_i64,
                                 c_int, c_int, c_int, c_void_p, c_void_p]),
-    "fd_spconv_tile_order": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fd_spconv_num_ranges": (c_int, [c_i64, c_int, c_int, c_int]),
+    "fd_spconv_wants_balanced_ranges": (c_int, [c_int, c_int, c_int]),
+    "fd_spconv_ranges_workspace_bytes": (c_size_t, [c_i64]),
+    "fd_spconv_ranges": (c_int, [c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fd_densify": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_i64,
                            c_i64, c_i64, c_i64, c_void_p]),
     "fd_conv2d_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -32,7 +32,7 @@ int fd_abi_version(void);
 const char *fd_last_error(void);
 /* Tuning / test knobs (no reference counterpart).  0 = built-in heuristic.  Names: "spconv_rg" (rows per wave of the
  * register sparse-conv kernel: 1|2|4), "spconv_v1" (1: fp32 on the register kernel instead of the compacting one),
- * "spconv_bf16_v1", "v2_depth", "v2_tm", "v2_ldspad", "conv_nt".  Initial values come from the FD_SPCONV_RG,
+ * "spconv_bf16_v1", "v2_depth", "v2_tm", "v2_ldspad", "conv_nt", "v2_ranges_per_cu", "v2_uniform".  Initial values come from the FD_SPCONV_RG,
  * FD_SPCONV_V1, ... environment variables, read once when the library is loaded; nothing on the launch path calls
  * getenv(). */
 int fd_tuning_set(const char *name, int value);
@@ -112,13 +112,22 @@ int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int D
 size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype);
 int fd_spconv_pack_weight(const float *w_kio_host, int K, int cin, int cout, int dtype, void *wpacked_host);
 int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *wpacked, const float *bias, const void *residual,
-                    int relu, const int32_t *nbr, int64_t nbr_stride, const int32_t *tile_order /* or NULL */, int K,
-                    int64_t n_out, int cin, int cout, int dtype, void *out_feats, fd_stream_t stream);
-/* Optional load balancing for fd_spconv_apply (fp32): order[b] = 128-row output tile processed by workgroup b,
- * heaviest tiles (most rulebook pairs) first and paired with light ones per CU.  One call per rulebook; the order is
- * reused by every convolution sharing the rulebook.  workspace >= 8 * ceil(n_out/128) bytes. */
-int fd_spconv_tile_order(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int32_t *order, void *workspace,
-                         size_t workspace_bytes, fd_stream_t stream);
+                    int relu, const int32_t *nbr, int64_t nbr_stride, const int32_t *ranges /* [n_ranges+1] or NULL */,
+                    int n_ranges, int K, int64_t n_out, int cin, int cout, int dtype, void *out_feats, fd_stream_t stream);
+/* Work distribution of fd_spconv_apply (fp32; no reference counterpart -- spconv launches one GEMM per tap).  Workgroup b
+ * computes output rows ranges[b] .. ranges[b+1]-1 (consecutive rows = neighbouring voxels), in chunks of <= 128 rows.
+ *   ranges == NULL, n_ranges == 0 : one 128-row tile per workgroup
+ *   ranges == NULL, n_ranges  > 0 : n_ranges equal row counts
+ *   ranges != NULL                : device table from fd_spconv_ranges: equal WORK (16-pair MFMA groups, counted per
+ *                                   8-row block of the rulebook) per range; boundaries are multiples of 8 rows.
+ * fd_spconv_num_ranges returns the count the kernel prefers for a layer shape on the current device (a whole number of
+ * ranges per compute unit).  The table depends only on the rulebook, so the 4-5 convolutions that share an indice_key
+ * share it.  Results never depend on the distribution (fixed summation order per output row). */
+int fd_spconv_num_ranges(int64_t n_out, int cin, int cout, int dtype);
+int fd_spconv_wants_balanced_ranges(int cin, int cout, int dtype); /* 1: use fd_spconv_ranges; 0: equal rows (ranges = NULL) */
+size_t fd_spconv_ranges_workspace_bytes(int64_t n_out);
+int fd_spconv_ranges(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int n_ranges, int32_t *ranges /*[n_ranges+1]*/,
+                     void *workspace, size_t workspace_bytes, fd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Densify.  Replaces SparseConvTensor.dense() + view (scn.py:165-168): out[b, c*D + d, y, x] = feats[row, c].

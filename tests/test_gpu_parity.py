@@ -730,28 +730,50 @@ def test_pointpillars_end_to_end_vs_oracle(hip):
             assert bad <= max(2, 0.02 * (len(gu) + len(wu))), (b, bad, len(gu), len(wu))
 
 
-def test_spconv_tile_order_is_a_work_sorted_permutation(hip):
-    """fd_spconv_tile_order only steers scheduling; it must be a permutation of the 128-row tiles that starts with the
-    heaviest one (work = sum over taps of ceil(valid rows / 16))."""
+def test_spconv_ranges_partition_rows_and_balance_work(hip):
+    """fd_spconv_ranges only steers scheduling: the table must be a monotone partition of the output rows (multiples of 32)
+    whose ranges carry near-equal work on a rulebook with a strong density gradient, and the convolution must give the
+    same bits with balanced ranges, equal-row ranges and one tile per workgroup."""
     rng = np.random.default_rng(5)
-    K, n_out = 27, 128 * 37 + 50
+    K, n_out, cin, cout = 27, 128 * 61 + 50, 32, 32
     stride = (n_out + 63) // 64 * 64
     nbr = np.full((K, stride), -1, np.int32)
-    dens = rng.uniform(0.05, 0.9, (n_out + 127) // 128)
-    for t, d in enumerate(dens):
-        lo, hi = t * 128, min(n_out, t * 128 + 128)
-        m = rng.uniform(size=(K, hi - lo)) < d
-        nbr[:, lo:hi] = np.where(m, rng.integers(0, 1000, (K, hi - lo)), -1)
+    dens = np.linspace(0.05, 0.9, n_out)  # sparse rows first, dense rows last
+    m = rng.uniform(size=(K, n_out)) < dens[None, :]
+    n_in = 5000
+    nbr[:, :n_out] = np.where(m, rng.integers(0, n_in, (K, n_out)), -1)
     t = _dev(nbr)
     t.n_out = n_out
-    order = hip.tile_order_for(t).cpu().numpy()
-    n_tiles = (n_out + 127) // 128
-    assert sorted(order.tolist()) == list(range(n_tiles))
-    pad = np.full((K, n_tiles * 128), -1, np.int32)
-    pad[:, :stride] = nbr
-    work = ((pad.reshape(K, n_tiles, 128) >= 0).sum(-1) + 15) // 16
-    work = work.sum(0)
-    assert work[order[0]] == work.max()
+    ranges, n = hip.ranges_for(t, cin, cout)
+    r = ranges.cpu().numpy()
+    assert len(r) == n + 1 and r[0] == 0 and r[-1] == n_out and np.all(np.diff(r) >= 0) and np.all(r[:-1] % 8 == 0)
+    pairs = (nbr[:, :n_out] >= 0).sum(0)
+    work = np.array([pairs[a:b].sum() for a, b in zip(r[:-1], r[1:])], np.float64)
+    rows = np.diff(r)
+    nz = work[rows > 0]
+    assert nz.max() <= 1.25 * nz.mean() + 8 * 27, (nz.max(), nz.mean())  # equal work up to one 8-row block
+    assert rows.max() > 2 * rows[rows > 0].min(), "sparse regions must get longer ranges than dense ones"
+    x = torch.randn((n_in, cin), device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    w = torch.randn((K, cin, cout), generator=torch.Generator().manual_seed(2)) * 0.05
+    wpk = hip.pack_spconv_weight(w).cuda()
+    ys = [hip.spconv_apply(x, wpk, None, t, n_out, cout, balanced=True)]
+    ys.append(hip.spconv_apply(x, wpk, None, t, n_out, cout, balanced=False))
+    try:
+        hip.set_tuning("v2_ranges_per_cu", 1)   # few long ranges: several chunks per workgroup (prefetch path)
+        ys.append(hip.spconv_apply(x, wpk, None, t, n_out, cout, balanced=False))
+        t2 = _dev(nbr)
+        t2.n_out = n_out
+        ys.append(hip.spconv_apply(x, wpk, None, t2, n_out, cout, balanced=True))
+    finally:
+        hip.set_tuning("v2_ranges_per_cu", 0)
+    for y in ys[1:]:
+        assert torch.equal(ys[0], y), "the work distribution must not change a single bit"
+    ref = torch.zeros((n_out, cout))
+    xc, nb = x.cpu(), torch.from_numpy(nbr[:, :n_out].astype(np.int64))
+    for k in range(K):
+        v = nb[k] >= 0
+        ref[v] += xc[nb[k][v]] @ w[k]
+    assert_close("spconv with work-balanced ranges vs dense torch reference", ys[0].cpu().numpy(), ref.numpy(), 1e-4)
 
 
 # ------------------------------------------------------------------------------------------------ forecast association (SURVEY 8f-3)
@@ -821,7 +843,7 @@ def test_c_abi_reports_errors_instead_of_exiting(hip):
     x = torch.zeros((64, 16), device="cuda")
     cases = [
         ("fd_voxelize", lambda: L.fd_voxelize(x.data_ptr(), 64, 99, None, None, 10, 100, 0, None, None, 0, None, 3, None, None, None, 0, None)),
-        ("fd_spconv_apply", lambda: L.fd_spconv_apply(x.data_ptr(), 64, x.data_ptr(), None, None, 0, x.data_ptr(), 64, None, 99, 64, 16, 16, 0,
+        ("fd_spconv_apply", lambda: L.fd_spconv_apply(x.data_ptr(), 64, x.data_ptr(), None, None, 0, x.data_ptr(), 64, None, 0, 99, 64, 16, 16, 0,
                                                      x.data_ptr(), None)),
         ("fd_rotated_nms", lambda: L.fd_rotated_nms(None, 10, ctypes.c_float(0.2), None, None, None, 0, None)),
         ("fd_conv2d_nhwc_bf16", lambda: L.fd_conv2d_nhwc_bf16(x.data_ptr(), 1, 8, 8, 7, x.data_ptr(), None, 16, 3, 1, 1, 1, x.data_ptr(), 16, 0, 1, 1,
