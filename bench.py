@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the second timed loop (host -> host)")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage GPU times to stderr")
+    ap.add_argument("--dump", default="", help="rank 0 saves the last step's gathered detections (npz: packed, counts) here (tests)")
     args = ap.parse_args()
     if args.config:
         for k, v in PRESETS[args.config].items():
@@ -82,7 +83,7 @@ def parse():
     return args
 
 
-PROF_EVERY = 4
+PROF_EVERY = 10
 
 
 class SpconvProfiler(object):
@@ -308,20 +309,24 @@ def main():
         window, last = [], None
         depth = max(1, len(streams) // max(1, len(schedule(first))))  # steps in flight (a step may hold several passes)
         for si in range(first, first + count):
-            if on_enqueue is not None:
-                on_enqueue(si)
+            alone = on_enqueue is not None and on_enqueue(si)
+            if alone:  # an instrumented step runs with nothing else in flight: its kernel durations are the kernels' own
+                while window:
+                    last = retire_step(window.pop(0))
             window.append(enqueue_step(si, from_host))
-            if len(window) > depth - 1:
+            if alone or len(window) > depth - 1:
                 last = retire_step(window.pop(0))
         while window:
             last = retire_step(window.pop(0))
         return last
 
     def set_prof(si):
-        # the per-launch HIP events of the roofline measurement are taken on every PROF_EVERY-th step of the timed region:
-        # an event pair costs ~5 us of queue time per launch (21 launches per step), which would otherwise be charged to
-        # every step of the headline number
+        # The per-launch HIP events of the roofline measurement are taken on every PROF_EVERY-th step of the timed region.
+        # Such a step runs ALONE (the passes in flight are retired first, the next one starts after it): with two sweeps
+        # sharing the GPU a launch's elapsed time contains the other sweep's kernels, which is not the kernel's duration.
+        # The drain and the event pairs (~5 us of queue time per launch) are charged to the headline number.
         prof.enabled = (si % PROF_EVERY == 0)
+        return prof.enabled and len(streams) > 1
 
     with torch.no_grad():
         for st in streams:  # set-up, not a warm-up step: every stream captures its neck+head graph and sizes its workspaces
@@ -364,6 +369,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt, dt_host = float(t[0]), (float(t[1]) if dt_host is not None else None)
 
+    if args.dump and rank == 0:
+        np.savez(args.dump, packed=host_p.numpy(), counts=host_c.numpy())
     per_step = (args.global_batch if strong else B * world)
     sweeps = args.steps * per_step
     out = {

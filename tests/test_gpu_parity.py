@@ -1051,6 +1051,40 @@ def test_full_size_config5_pedestrian_fine_grid_fp32_vs_oracle(hip):
     _attribute("full size config 5 forward_points", _rows(got), _rows(want), cfg.test_cfg)
 
 
+def test_two_ranks_on_one_gpu_equal_single_process(hip, tmp_path):
+    """The N > 1 path end to end on a 1-GPU box: bench.py under torch.distributed.run with 2 ranks that both use cuda:0
+    (FD_BENCH_ONE_DEVICE=1, collectives over gloo): rank-strided shards of a global batch of 4 clouds, per-step fixed-shape
+    all_gather, rank-0 JSON line.  The gathered, re-interleaved detections must equal a single-process run of the same 4
+    samples, and the line must carry the multi-rank fields."""
+    import json
+    import subprocess
+    import sys
+
+    from futuredet_amd import dist_infer
+    from futuredet_amd.synth import synthetic_cloud
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = os.path.join(str(tmp_path), "gathered.npz")
+    env = dict(os.environ, FD_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--variant", "forecast_n3", "--points", "30000", "--batch", "2", "--global-batch", "4", "--no-cpu-baseline", "--no-host-leg",
+           "--dump", dump]
+    out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2 and line["value"] > 0
+    g = np.load(dump)
+    got = dist_infer.unpack_results(torch.from_numpy(g["packed"]), torch.from_numpy(g["counts"]))
+    assert len(got) == 4
+    cfg, net, _ = _build_pair("forecast_n3")
+    with torch.no_grad():
+        for sid in range(4):  # global sample id = cloud seed (rank r computed samples r, r + 2)
+            want = net.forward_points([_dev(synthetic_cloud(seed=sid, target_points=30000))], cfg.voxel_generator, padded=False)[0]
+            _attribute("2 ranks on one GPU: gathered sample %d vs single process" % sid, _rows(got[sid]), _rows(want), cfg.test_cfg)
+
+
 def test_weights_reload_invalidates_captured_graph(hip):
     """The neck+head hipGraph and the folded / packed weight caches must not survive a weight change: run (graph
     captured), load other weights, run again -- the result must match the oracle with the NEW weights and differ from the
