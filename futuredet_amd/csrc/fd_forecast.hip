@@ -112,7 +112,144 @@ __global__ void __launch_bounds__(256) forecast_chains(FcArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- detections -> global boxes
+// _second_det_to_nusc_box (det3d/datasets/nuscenes/nusc_common.py:167-189) followed by _lidar_nusc_box_to_global (:192-216)
+// as arithmetic on arrays.  pyquaternion / nuScenes-devkit semantics restated (neither is in the reference tree):
+//   Quaternion(axis=[0,0,1], radians=a) = (cos(a/2), 0, 0, sin(a/2)) in float64;
+//   Quaternion.rotation_matrix = (Q(q) . Qbar(q)^T)[1:,1:] after normalising a non-unit q (|1 - |q|^2| >= 1e-14);
+//   Box.rotate(q): center = R.center, orientation = q*orientation (= Q(q).o), velocity = R.velocity; Box.translate(t): center += t.
+struct Rigid {  // one rotate + translate step; identity when !on
+    double q[4], t[3];
+    int on;
+};
+struct DetArgs {
+    const float *box3d;  // [n, 9] (x,y,z,w,l,h,vx,vy,yaw)
+    int n;
+    Rigid step[2];       // lidar -> ego (calibrated_sensor), ego -> global (ego_pose)
+    double *center, *quat, *velocity;  // [n,3], [n,4], [n,3]
+    float *size;                        // [n,3]
+};
+
+__device__ inline void quat_matrix(const double *q, double R[3][3]) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double Q[4][4] = {{w, -x, -y, -z}, {x, w, -z, y}, {y, z, w, -x}, {z, -y, x, w}};
+    const double P[4][4] = {{w, -x, -y, -z}, {x, w, z, -y}, {y, -z, w, x}, {z, y, -x, w}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc = fma(Q[i + 1][k], P[j + 1][k], acc);
+            R[i][j] = acc;
+        }
+}
+
+__global__ void __launch_bounds__(128) det_to_global_kernel(DetArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const float *b = a.box3d + (size_t)i * 9;
+    const float yaw = __fsub_rn(-b[8], 1.5707963267948966f);  // float32: -box3d[:, -1] - np.pi / 2
+    const double half = (double)yaw / 2.0;
+    double o[4] = {cos(half), 0.0, 0.0, sin(half)};
+    double c[3] = {(double)b[0], (double)b[1], (double)b[2]};
+    double v[3] = {(double)b[6], (double)b[7], 0.0};
+    for (int s = 0; s < 2; ++s) {
+        if (!a.step[s].on) continue;
+        double q[4] = {a.step[s].q[0], a.step[s].q[1], a.step[s].q[2], a.step[s].q[3]};
+        const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        if (fabs(1.0 - n2) >= 1e-14 && n2 > 0.0) {
+            const double nn = sqrt(n2);
+            for (int k = 0; k < 4; ++k) q[k] /= nn;
+        }
+        double R[3][3];
+        quat_matrix(q, R);
+        double c2[3], v2[3];
+        for (int r = 0; r < 3; ++r) {
+            c2[r] = fma(R[r][2], c[2], fma(R[r][1], c[1], R[r][0] * c[0]));
+            v2[r] = fma(R[r][2], v[2], fma(R[r][1], v[1], R[r][0] * v[0]));
+        }
+        const double w = q[0], x = q[1], y = q[2], z = q[3];
+        const double o2[4] = {w * o[0] - x * o[1] - y * o[2] - z * o[3], x * o[0] + w * o[1] - z * o[2] + y * o[3],
+                              y * o[0] + z * o[1] + w * o[2] - x * o[3], z * o[0] - y * o[1] + x * o[2] + w * o[3]};
+        for (int r = 0; r < 3; ++r) { c[r] = c2[r] + a.step[s].t[r]; v[r] = v2[r]; }
+        for (int k = 0; k < 4; ++k) o[k] = o2[k];
+    }
+    for (int r = 0; r < 3; ++r) {
+        a.center[(size_t)i * 3 + r] = c[r];
+        a.velocity[(size_t)i * 3 + r] = v[r];
+        a.size[(size_t)i * 3 + r] = b[3 + r];
+    }
+    for (int k = 0; k < 4; ++k) a.quat[(size_t)i * 4 + k] = o[k];
+}
+
+// ---------------------------------------------------------------------------------------------- multi_future groups
+// multi_future (nuscenes.py:299-339): boxes whose centres are closer than match_thresh are linked; network_split gives
+// every connected component an id; networkx enumerates components in the order of their smallest member, so the id of a
+// box is the rank of its component's smallest index.  One workgroup: min-label propagation over the adjacency
+// (distance_matrix on all three coordinates, float64, numpy's rounding order), then the rank.
+constexpr int kMaxGroupN = 1024;
+__device__ inline double dist3d(const double *a, const double *b) {
+    const double ad = __dadd_rn(__dadd_rn(__dmul_rn(a[0], a[0]), __dmul_rn(a[1], a[1])), __dmul_rn(a[2], a[2]));
+    const double bd = __dadd_rn(__dadd_rn(__dmul_rn(b[0], b[0]), __dmul_rn(b[1], b[1])), __dmul_rn(b[2], b[2]));
+    const double dot = fma(a[2], b[2], fma(a[1], b[1], __dmul_rn(a[0], b[0])));
+    double d = __dsub_rn(__dadd_rn(ad, bd), __dmul_rn(2.0, dot));
+    if (d < 0.0) d = 0.0;
+    return sqrt(d);
+}
+
+__global__ void __launch_bounds__(1024) forecast_groups_kernel(const double *__restrict__ centers, int n, double thresh, int *__restrict__ ids) {
+    __shared__ int s_label[kMaxGroupN];
+    __shared__ int s_changed;
+    const int i = threadIdx.x;
+    if (i < n) s_label[i] = i;
+    __syncthreads();
+    for (int it = 0; it < n; ++it) {  // a label travels at least one hop per sweep: at most n sweeps
+        if (i == 0) s_changed = 0;
+        __syncthreads();
+        int best = i < n ? s_label[i] : 0;
+        if (i < n)
+            for (int j = 0; j < n; ++j)
+                if (s_label[j] < best && dist3d(centers + (size_t)i * 3, centers + (size_t)j * 3) < thresh) best = s_label[j];
+        __syncthreads();
+        if (i < n && best != s_label[i]) { s_label[i] = best; s_changed = 1; }
+        __syncthreads();
+        if (!s_changed) break;
+    }
+    if (i < n) {
+        const int lab = s_label[i];
+        int rank = 0;
+        for (int r = 0; r < lab; ++r) rank += (s_label[r] == r);
+        ids[i] = rank;
+    }
+}
+
 }  // namespace
+
+extern "C" int fd_det_to_global_boxes(const float *box3d9, int n, const double *cs_rotation4, const double *cs_translation3,
+                                      const double *pose_rotation4, const double *pose_translation3, double *center, double *quat,
+                                      double *velocity, float *size, fd_stream_t stream) {
+    FD_REQUIRE(n >= 0, "fd_det_to_global_boxes: negative count");
+    if (n == 0) return FD_OK;
+    FD_REQUIRE(box3d9 && center && quat && velocity && size, "fd_det_to_global_boxes: null argument");
+    FD_REQUIRE((cs_rotation4 == nullptr) == (cs_translation3 == nullptr) && (pose_rotation4 == nullptr) == (pose_translation3 == nullptr),
+               "fd_det_to_global_boxes: a rotation needs its translation");
+    DetArgs a;
+    a.box3d = box3d9; a.n = n; a.center = center; a.quat = quat; a.velocity = velocity; a.size = size;
+    const double *rq[2] = {cs_rotation4, pose_rotation4}, *rt[2] = {cs_translation3, pose_translation3};
+    for (int s = 0; s < 2; ++s) {
+        a.step[s].on = rq[s] != nullptr;
+        for (int k = 0; k < 4; ++k) a.step[s].q[k] = rq[s] ? rq[s][k] : (k == 0 ? 1.0 : 0.0);
+        for (int k = 0; k < 3; ++k) a.step[s].t[k] = rt[s] ? rt[s][k] : 0.0;
+    }
+    hipLaunchKernelGGL(det_to_global_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, fd::as_stream(stream), a);
+    return fd::check_launch("fd_det_to_global_boxes");
+}
+
+extern "C" int fd_forecast_groups(const double *centers3, int n, double match_thresh, int32_t *ids, fd_stream_t stream) {
+    FD_REQUIRE(n >= 0 && n <= kMaxGroupN, "fd_forecast_groups: n must be in [0,%d]", kMaxGroupN);
+    if (n == 0) return FD_OK;
+    FD_REQUIRE(centers3 && ids, "fd_forecast_groups: null argument");
+    hipLaunchKernelGGL(forecast_groups_kernel, dim3(1), dim3(1024), 0, fd::as_stream(stream), centers3, n, match_thresh, ids);
+    return fd::check_launch("fd_forecast_groups");
+}
 
 extern "C" int fd_forecast_chains(const double *centers, const double *velocity, const int32_t *counts, const double *time_dev, int T,
                                   int n_max, double reject_thresh, int32_t *fwd_idx, int32_t *fwd_ok, int32_t *bwd_idx, int32_t *bwd_ok,

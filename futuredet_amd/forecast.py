@@ -1,7 +1,13 @@
-"""Forecast association consuming the head output, mirroring det3d/datasets/nuscenes/nuscenes.py:
+"""Forecast association consuming the head output, mirroring det3d/datasets/nuscenes/nuscenes.py and nusc_common.py:
 
 match_boxes(ret_boxes)              : nuscenes.py:112-123
 tracker(classname, time, ret_boxes) : nuscenes.py:125-257 (forward chains, constant-velocity forward, back-cast chains)
+_second_det_to_nusc_box(detection)  : nusc_common.py:167-189   (head rows -> boxes: yaw flip, quaternion, velocity triple)
+_lidar_nusc_box_to_global(...)      : nusc_common.py:192-216   (the two rigid transforms, records passed as arrays)
+forecast_boxes(...)                 : nuscenes.py:384-494      (per-step split, matching / tracking, constant-velocity roll-out,
+                                      jitter); the devkit token / time look-ups of :385-398 are the caller's: ``time`` and the
+                                      calibrated_sensor / ego_pose records come in as arrays
+multi_future(forecast_boxes, name)  : nuscenes.py:299-339      (forecast_id = connected component of the < 0.25 m graph)
 
 ``ret_boxes`` is what the reference builds at :398-409: one list per forecast step of box objects with ``.center`` and
 ``.velocity`` (nuScenes-devkit ``Box`` in the reference; any object with those two array attributes works).  The
@@ -74,3 +80,130 @@ def tracker(classname, time, ret_boxes):
             chain = [ret_boxes[T - 1 - s][int(res["bwd_idx"][i, s])] for s in range(T)]
             trajectory.append(chain[::-1])
     return trajectory
+
+
+# ------------------------------------------------------------------------------------------------ boxes from head rows
+class Quat(object):
+    """The little of pyquaternion.Quaternion the reference's forecasting code touches: .elements / indexing (w,x,y,z)."""
+
+    def __init__(self, q):
+        self.q = np.asarray(q, np.float64)
+
+    @property
+    def elements(self):
+        return self.q
+
+    def __getitem__(self, i):
+        return self.q[i]
+
+
+class Box(object):
+    """Array-backed stand-in for nuscenes.utils.data_classes.Box with the attributes forecast_boxes / box_serialize read."""
+
+    def __init__(self, center, size, orientation, label=np.nan, score=np.nan, velocity=(np.nan, np.nan, np.nan), name=None, token=None):
+        self.center, self.wlh, self.orientation = np.array(center), np.array(size), orientation
+        self.label, self.score, self.velocity, self.name, self.token = label, score, np.array(velocity), name, token
+
+
+def _boxes_from_arrays(center, quat, vel, size, scores, labels):
+    return [Box(center[i], size[i], Quat(quat[i]), label=labels[i], score=scores[i], velocity=vel[i]) for i in range(len(center))]
+
+
+def det_arrays(detection, cs_record=None, pose_record=None, device="cuda"):
+    """Array core of _second_det_to_nusc_box (+ _lidar_nusc_box_to_global when the records are given): one HIP launch
+    (fd_det_to_global_boxes).  Returns host arrays (center f64 [n,3], quat f64 [n,4], velocity f64 [n,3], size f32 [n,3])."""
+    box3d = detection["box3d_lidar"]
+    box3d = box3d if isinstance(box3d, torch.Tensor) else torch.as_tensor(np.asarray(box3d))
+    box3d = box3d.detach().to(device, torch.float32).contiguous()
+    c, q, v, s = hip_ops.det_to_global_boxes(box3d, cs_record, pose_record)
+    return c.cpu().numpy(), q.cpu().numpy(), v.cpu().numpy(), s.cpu().numpy()
+
+
+def _second_det_to_nusc_box(detection, cs_record=None, pose_record=None):
+    """nusc_common.py:167-189; with the two records also :192-216 (rotation = (w,x,y,z), translation = (x,y,z) each)."""
+    c, q, v, s = det_arrays(detection, cs_record, pose_record)
+    scores = detection["scores"].detach().cpu().numpy() if isinstance(detection["scores"], torch.Tensor) else np.asarray(detection["scores"])
+    labels = detection["label_preds"].detach().cpu().numpy() if isinstance(detection["label_preds"], torch.Tensor) else np.asarray(detection["label_preds"])
+    if cs_record is None and pose_record is None:
+        c = c.astype(np.float32)  # the reference's Box keeps the float32 slice until its first rotation
+    return _boxes_from_arrays(c, q, v, s, scores, labels)
+
+
+def forecast_boxes(det_forecast, time, cs_record, pose_record, forecast, forecast_mode, classname, jitter=False, K=1, C=0.0, stale=None):
+    """nuscenes.py:384-494 with the devkit look-ups factored out: ``time`` = seconds between consecutive forecast steps
+    (get_time, :399-406), ``cs_record`` / ``pose_record`` = (rotation, translation) of the sample's LIDAR_TOP calibrated
+    sensor and ego pose.  Returns ret_boxes: a list of trajectories, each a list of ``forecast`` boxes."""
+    time = list(time)
+    if stale is None:
+        stale = any(t == 0 for t in time)
+    labels = det_forecast["label_preds"]
+    labels_np = labels.detach().cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
+    ret_boxes = []
+    for t in range(forecast):  # :408-417
+        mask = labels_np == t
+        det = {k: det_forecast[k][torch.as_tensor(mask)] if isinstance(det_forecast[k], torch.Tensor) else np.asarray(det_forecast[k])[mask]
+               for k in ("box3d_lidar", "scores", "label_preds")}
+        ret_boxes.append(_second_det_to_nusc_box(det, cs_record, pose_record))
+    if stale or len(ret_boxes[0]) == 0:
+        return []
+    if forecast_mode in ["velocity_constant", "velocity_forward", "velocity_reverse"]:
+        ret_boxes = match_boxes(ret_boxes)
+    elif forecast_mode != "velocity_dense":
+        raise NotImplementedError("forecast_mode %r: only the velocity_* modes of the shipped evaluate.py settings are covered" % forecast_mode)
+    if "dense" not in forecast_mode:  # :433-441
+        trajectory_boxes = [[ret_boxes[i][j] for i in range(forecast)] for j in range(len(ret_boxes[0]))]
+        if forecast_mode == "velocity_reverse":
+            time = time[::-1]
+        out = []
+        for trajectory_box in trajectory_boxes:  # :445-463
+            fboxes = [trajectory_box[0]]
+            for i in range(forecast - 1):
+                new_box = deepcopy(fboxes[-1])
+                step = time[i] * trajectory_box[i].velocity
+                new_box.center = new_box.center - step if forecast_mode == "velocity_reverse" else new_box.center + step
+                fboxes.append(new_box)
+            out.append(fboxes[::-1] if forecast_mode == "velocity_reverse" else fboxes)
+        ret_boxes = out
+    else:
+        ret_boxes = tracker(classname, time, ret_boxes)  # :443,465-466
+    if jitter:  # :476-492 (draws from numpy's global generator like the reference)
+        jitter_boxes = []
+        for trajectory_box in ret_boxes:
+            for _ in range(K - 1):
+                start_box = trajectory_box[0]
+                vel_norm = C * np.linalg.norm(start_box.velocity)
+                jittered_vel = np.random.normal(start_box.velocity, np.array([vel_norm, vel_norm, vel_norm]))
+                fboxes = [start_box]
+                for i in range(forecast - 1):
+                    new_box = deepcopy(fboxes[-1])
+                    new_box.center = new_box.center + time[i] * jittered_vel
+                    fboxes.append(new_box)
+                jitter_boxes.append(fboxes)
+        ret_boxes = ret_boxes + jitter_boxes
+    return ret_boxes
+
+
+def forecast_ids(centers, match_thresh=0.25, device="cuda"):
+    """Array core of multi_future: component id per box (fd_forecast_groups)."""
+    centers = np.ascontiguousarray(np.asarray(centers, np.float64).reshape(-1, 3))
+    if len(centers) == 0:
+        return np.zeros((0,), np.int32)
+    return hip_ops.forecast_groups(torch.from_numpy(centers).to(device), match_thresh).cpu().numpy()
+
+
+def multi_future(forecast_boxes, classname):
+    """nuscenes.py:299-339 on the serialised box dicts (keys translation / detection_name / detection_score /
+    forecast_score / forecast_id / forecast_boxes), in place like the reference."""
+    for sample_token in forecast_boxes.keys():
+        boxes = [box for box in forecast_boxes[sample_token] if classname in box["detection_name"]]
+        if len(boxes) == 0:
+            continue
+        ids = forecast_ids(np.array([box["translation"] for box in boxes]))
+        for box, fid in zip(boxes, ids):
+            box["forecast_id"] = int(fid)
+            for sub in box["forecast_boxes"]:
+                sub["detection_score"] = box["detection_score"]
+                sub["forecast_score"] = box["forecast_score"]
+                sub["forecast_id"] = int(fid)
+        forecast_boxes[sample_token] = boxes
+    return forecast_boxes

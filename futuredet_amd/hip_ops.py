@@ -536,3 +536,38 @@ def forecast_chains(centers, velocity, counts, time, reject_thresh):
                                _p(out["fwd_ok"]), _p(out["bwd_idx"]), _p(out["bwd_ok"]), _p(out["match_idx"]), _p(out["cv_centers"]),
                                _p(out["status"]), _stream()), "fd_forecast_chains")
     return out
+
+
+def det_to_global_boxes(box3d, cs_record=None, pose_record=None):
+    """fd_det_to_global_boxes: box3d [n,9] float32 device tensor; cs_record / pose_record = (rotation wxyz, translation xyz)
+    or None.  Returns device tensors (center [n,3] f64, quat [n,4] f64, velocity [n,3] f64, size [n,3] f32)."""
+    L = _lib.load()
+    box3d = _dev(box3d, "box3d", torch.float32)
+    n = box3d.shape[0]
+    assert box3d.shape[1] == 9, "box3d_lidar rows are (x,y,z,w,l,h,vx,vy,yaw)"
+    dev = box3d.device
+    center = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    quat = torch.empty((n, 4), dtype=torch.float64, device=dev)
+    vel = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    size = torch.empty((n, 3), dtype=torch.float32, device=dev)
+
+    def rec(r):
+        if r is None:
+            return None, None
+        q, t = (ctypes.c_double * 4)(*[float(v) for v in r[0]]), (ctypes.c_double * 3)(*[float(v) for v in r[1]])
+        return q, t
+
+    cq, ct = rec(cs_record)
+    pq, pt = rec(pose_record)
+    check(L.fd_det_to_global_boxes(_p(box3d), n, cq, ct, pq, pt, _p(center), _p(quat), _p(vel), _p(size), _stream()), "fd_det_to_global_boxes")
+    return center, quat, vel, size
+
+
+def forecast_groups(centers, match_thresh):
+    """fd_forecast_groups: centers [n,3] float64 device tensor -> int32 [n] component ids (multi_future's forecast_id)."""
+    L = _lib.load()
+    centers = _dev(centers, "centers", torch.float64)
+    n = centers.shape[0]
+    ids = torch.zeros((max(n, 1),), dtype=torch.int32, device=centers.device)[:n]
+    check(L.fd_forecast_groups(_p(centers), n, float(match_thresh), _p(ids), _stream()), "fd_forecast_groups")
+    return ids

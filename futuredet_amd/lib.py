@@ -76,6 +76,8 @@ SIGNATURES = {
     "fd_bias_act_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_i64, c_int, c_void_p, c_i64, c_void_p]),
     "fd_forecast_chains": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_det_to_global_boxes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fd_forecast_groups": (c_int, [c_void_p, c_int, ctypes.c_double, c_void_p, c_void_p]),
     "fd_index_pyramid": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, ctypes.POINTER(IndexLevel), c_void_p, c_void_p, c_size_t,
                                  c_void_p]),
     "fd_index_pyramid_coords": (c_int, [c_int, c_int, ctypes.POINTER(IndexLevel), c_void_p]),

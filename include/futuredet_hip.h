@@ -264,6 +264,22 @@ int fd_forecast_chains(const double *centers, const double *velocity, const int3
                        int n_max, double reject_thresh, int32_t *fwd_idx, int32_t *fwd_ok, int32_t *bwd_idx, int32_t *bwd_ok,
                        int32_t *match_idx, double *cv_centers, int32_t *status, fd_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Head output -> global-frame boxes: _second_det_to_nusc_box (det3d/datasets/nuscenes/nusc_common.py:167-189: yaw ->
+ * -yaw - pi/2 in float32, Quaternion(axis z, that angle), velocity (vx, vy, 0)) followed by _lidar_nusc_box_to_global
+ * (:192-216: rotate + translate by the calibrated_sensor record, then by the ego_pose record).  The two records are host
+ * arrays (rotation w,x,y,z / translation x,y,z, float64) instead of devkit table look-ups; pass NULL pairs to stay in
+ * the lidar frame.  Outputs: center [n,3], quat [n,4] (w,x,y,z), velocity [n,3] float64 (Box.center / .orientation /
+ * .velocity), size [n,3] float32 (Box.wlh).
+ * ------------------------------------------------------------------------------------------------- */
+int fd_det_to_global_boxes(const float *box3d9, int n, const double *cs_rotation4_host, const double *cs_translation3_host,
+                           const double *pose_rotation4_host, const double *pose_translation3_host, double *center,
+                           double *quat, double *velocity, float *size, fd_stream_t stream);
+/* multi_future's grouping (det3d/datasets/nuscenes/nuscenes.py:299-339 with network_split :283-297): boxes whose centres
+ * (all three coordinates, distance_matrix :100-110) are closer than match_thresh are linked; ids[i] = index of box i's
+ * connected component, components numbered by their smallest member (networkx's enumeration order).  n <= 1024. */
+int fd_forecast_groups(const double *centers3, int n, double match_thresh, int32_t *ids, fd_stream_t stream);
+
 /* The whole index pyramid of the backbone in one call (the same launches as fd_index_mark / _downsample / _scan /
  * _coords above, issued back to back): level 0 is marked from the voxelizer's coords of every sample
  * (coords [B * n_max_per_sample, 4], n_dev[b] = voxel count of sample b or NULL), level l > 0 is derived from

@@ -494,10 +494,190 @@ def gen_forecast():
     save("forecast.npz", **out)
 
 
+class _Quaternion(object):
+    """Restatement of the part of pyquaternion 0.9.x (requirements.txt:24 pins >=0.9.5; the package is absent from the image)
+    that the reference's forecasting path uses: construction from 4 elements / array= / axis+radians, .elements,
+    indexing, Hamilton product, .rotation_matrix.  Follows pyquaternion/quaternion.py: _from_axis_angle
+    (theta = angle / 2; (cos theta, axis * sin theta), math.cos / math.sin), _q_matrix / _q_bar_matrix, rotation_matrix =
+    (Q . Qbar^H)[1:, 1:] after _normalise() (tolerance 1e-14), __mul__ = Q(self) . other.q."""
+
+    def __init__(self, *args, **kwargs):
+        from math import cos, sin, sqrt
+        if "array" in kwargs:
+            self.q = np.array(kwargs["array"], dtype=float)
+        elif "axis" in kwargs:
+            axis = np.array(kwargs["axis"], dtype=float)
+            angle = kwargs.get("radians", kwargs.get("angle", 0.0)) or 0.0
+            mag_sq = np.dot(axis, axis)
+            if abs(1.0 - mag_sq) > 1e-12:
+                axis = axis / sqrt(mag_sq)
+            theta = angle / 2.0
+            r, i = cos(theta), axis * sin(theta)
+            self.q = np.array([r, i[0], i[1], i[2]], dtype=float)
+        elif len(args) == 1:
+            self.q = np.array(args[0].q if isinstance(args[0], _Quaternion) else args[0], dtype=float)
+        else:
+            self.q = np.array(args, dtype=float)
+        assert self.q.shape == (4,)
+
+    elements = property(lambda self: self.q)
+
+    def __getitem__(self, i):
+        return self.q[int(i)]
+
+    def _q_matrix(self):
+        w, x, y, z = self.q
+        return np.array([[w, -x, -y, -z], [x, w, -z, y], [y, z, w, -x], [z, -y, x, w]])
+
+    def _q_bar_matrix(self):
+        w, x, y, z = self.q
+        return np.array([[w, -x, -y, -z], [x, w, z, -y], [y, -z, w, x], [z, y, -x, w]])
+
+    def _normalise(self):
+        if not abs(1.0 - np.dot(self.q, self.q)) < 1e-14:
+            n = np.sqrt(np.dot(self.q, self.q))
+            if n > 0:
+                self.q = self.q / n
+
+    @property
+    def rotation_matrix(self):
+        self._normalise()
+        product_matrix = np.dot(self._q_matrix(), self._q_bar_matrix().conj().transpose())
+        return product_matrix[1:][:, 1:]
+
+    def __mul__(self, other):
+        return _Quaternion(array=np.dot(self._q_matrix(), other.q))
+
+
+class _Box(object):
+    """Restatement of nuscenes.utils.data_classes.Box (nuScenes devkit, absent from the image): constructor attributes,
+    translate (center += x), rotate (center = R.center, orientation = q * orientation, velocity = R.velocity)."""
+
+    def __init__(self, center, size, orientation, label=np.nan, score=np.nan, velocity=(np.nan, np.nan, np.nan), name=None, token=None):
+        assert not np.any(np.isnan(center)) and not np.any(np.isnan(size)) and len(center) == 3 and len(size) == 3
+        self.center, self.wlh, self.orientation = np.array(center), np.array(size), orientation
+        self.label = int(label) if not np.isnan(label) else label
+        self.score = float(score) if not np.isnan(score) else score
+        self.velocity, self.name, self.token = np.array(velocity), name, token
+
+    def translate(self, x):
+        self.center += x
+
+    def rotate(self, quaternion):
+        self.center = np.dot(quaternion.rotation_matrix, self.center)
+        self.orientation = quaternion * self.orientation
+        self.velocity = np.dot(quaternion.rotation_matrix, self.velocity)
+
+
+class _Nusc(object):
+    def __init__(self, tables):
+        self.tables = tables
+
+    def get(self, table, token):
+        return self.tables[table][token]
+
+
+def gen_forecast2():
+    """The reference's own forecast_boxes (nuscenes.py:384-494), multi_future (:299-339), _second_det_to_nusc_box and
+    _lidar_nusc_box_to_global (nusc_common.py:167-216), run UNMODIFIED on seeded head outputs.  Their third-party
+    dependencies are absent from the image: pyquaternion.Quaternion and the devkit Box are the restatements above (so
+    those two libraries' arithmetic is parity-unpinned), the devkit tables are a dict-backed stand-in, networkx is the
+    real package."""
+    import importlib
+    import networkx  # noqa: F401  (the real one, before any inert shim can take its name)
+    mod = lambda name, **a: sys.modules.setdefault(name, type(sys)(name)).__dict__.update(a)  # noqa: E731
+    mod("nuscenes"), mod("nuscenes.utils"), mod("nuscenes.utils.geometry_utils", view_points=None)
+    mod("shapely"), mod("shapely.geometry", Polygon=object), mod("pyquaternion", Quaternion=_Quaternion)
+    mod("tqdm", tqdm=lambda x, **k: x)
+    if "det3d.datasets" not in sys.modules:
+        m = types.ModuleType("det3d.datasets")
+        m.__path__ = [os.path.join(REF, "det3d", "datasets")]
+        sys.modules["det3d.datasets"] = m
+    nm = importlib.import_module("det3d.datasets.nuscenes.nuscenes")
+    nc = importlib.import_module("det3d.datasets.nuscenes.nusc_common")
+    for m in (nm, nc):
+        m.Quaternion, m.Box = _Quaternion, _Box
+    rng = np.random.default_rng(77)
+    T = 7
+    tokens = ["tok%02d" % i for i in range(10)]
+    stamps = np.cumsum(rng.integers(480000, 520000, len(tokens))) + 1_600_000_000_000_000
+    cs = {"rotation": [0.7077955119163518, -0.006492242056004365, 0.010646214713995808, -0.7063073142877817],
+          "translation": [0.943713, 0.0, 1.84023]}
+    pose = {"rotation": [0.5720320396729045, -0.0016977771610471074, 0.011798001930183783, -0.8201446642457809],
+            "translation": [411.3039349319818, 1180.8903791765097, 0.0]}
+    tables = {"sample": {t: {"timestamp": int(ts), "data": {"LIDAR_TOP": "sd_" + t}, "token": t} for t, ts in zip(tokens, stamps)},
+              "sample_data": {"sd_" + t: {"calibrated_sensor_token": "cs", "ego_pose_token": "pose"} for t in tokens},
+              "calibrated_sensor": {"cs": cs}, "ego_pose": {"pose": pose}}
+    nusc = _Nusc(tables)
+    sample_data = [{"token": t, "scene_token": "scene"} for t in tokens]
+    scene_data = {"scene": list(tokens)}
+    out = {"cs_rotation": np.array(cs["rotation"]), "cs_translation": np.array(cs["translation"]),
+           "pose_rotation": np.array(pose["rotation"]), "pose_translation": np.array(pose["translation"])}
+    # a 7-step detection set shaped like CenterHead.predict's output: per step up to 83 rows (x,y,z,w,l,h,vx,vy,yaw)
+    n0 = 30
+    base = rng.uniform(-40, 40, (n0, 2))
+    vel = rng.normal(0, 3.0, (n0, 2))
+    rows, labels, scores = [], [], []
+    for t in range(T):
+        keep = rng.permutation(n0)[: n0 - int(rng.integers(0, 4))]
+        c = base[keep] + vel[keep] * 0.5 * t + rng.normal(0, 0.3, (len(keep), 2))
+        b = np.concatenate([c, rng.normal(-1, 0.3, (len(keep), 1)), rng.uniform(1.5, 2.2, (len(keep), 1)), rng.uniform(3.8, 5.0, (len(keep), 1)),
+                            rng.uniform(1.4, 1.9, (len(keep), 1)), vel[keep] + rng.normal(0, 0.2, (len(keep), 2)),
+                            rng.uniform(-3.1, 3.1, (len(keep), 1))], axis=1)
+        rows.append(b)
+        labels.append(np.full(len(keep), t))
+        scores.append(rng.uniform(0.1, 0.95, len(keep)))
+    det = {"box3d_lidar": torch.from_numpy(np.concatenate(rows).astype(np.float32)), "scores": torch.from_numpy(np.concatenate(scores).astype(np.float32)),
+           "label_preds": torch.from_numpy(np.concatenate(labels).astype(np.int64)), "metadata": {"token": tokens[1]}}
+    out["box3d"], out["scores"], out["labels"] = det["box3d_lidar"].numpy(), det["scores"].numpy(), det["label_preds"].numpy()
+    # ---- _second_det_to_nusc_box and _lidar_nusc_box_to_global on the whole set
+    lidar_boxes = nc._second_det_to_nusc_box({k: (v.clone() if torch.is_tensor(v) else v) for k, v in det.items()})
+    out["lidar_center"] = np.stack([b.center for b in lidar_boxes]).astype(np.float64)
+    out["lidar_quat"] = np.stack([b.orientation.elements for b in lidar_boxes])
+    out["lidar_velocity"] = np.stack([b.velocity for b in lidar_boxes])
+    out["lidar_size"] = np.stack([b.wlh for b in lidar_boxes])
+    glob = nc._lidar_nusc_box_to_global(nusc, lidar_boxes, tokens[1])
+    out["global_center"] = np.stack([b.center for b in glob])
+    out["global_quat"] = np.stack([b.orientation.elements for b in glob])
+    out["global_velocity"] = np.stack([b.velocity for b in glob])
+    # ---- forecast_boxes in every deterministic mode
+    for mode in ("velocity_constant", "velocity_forward", "velocity_reverse", "velocity_dense"):
+        d = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in det.items()}
+        ret, ret_tokens = nm.forecast_boxes(nusc, sample_data, scene_data, tokens, d, T, mode, "car", False, 1, 0.0, None, False)
+        assert ret_tokens == tokens[1:1 + T]
+        out[mode + "_center"] = np.array([[b.center for b in tr] for tr in ret], np.float64).reshape(-1, T, 3)
+        out[mode + "_quat"] = np.array([[b.orientation.elements for b in tr] for tr in ret], np.float64).reshape(-1, T, 4)
+        out[mode + "_velocity"] = np.array([[b.velocity for b in tr] for tr in ret], np.float64).reshape(-1, T, 3)
+        out[mode + "_score"] = np.array([[b.score for b in tr] for tr in ret], np.float64).reshape(-1, T)
+        out[mode + "_label"] = np.array([[b.label for b in tr] for tr in ret], np.int64).reshape(-1, T)
+        print("forecast_boxes", mode, "trajectories", len(ret))
+    out["time"] = np.array([nm.get_time(nusc, a, b) for a, b in zip(tokens[1:T], tokens[2:T + 1])])
+    # ---- multi_future on serialised boxes: clusters of near-identical first boxes plus chains that link transitively
+    cents = np.concatenate([rng.uniform(-30, 30, (12, 3)) * [1, 1, 0.02]] * 3) + rng.normal(0, 0.06, (36, 3))
+    cents = np.concatenate([cents, np.array([[50.0 + 0.2 * i, 5.0, 0.0] for i in range(6)])])  # a 0.2 m chain: one component
+    cents = cents[rng.permutation(len(cents))]
+    fb = {"tokA": [{"sample_token": "tokA", "translation": c.tolist(), "detection_name": "car" if i % 7 else "pedestrian",
+                    "detection_score": float(rng.uniform(0.1, 0.9)), "forecast_score": float(rng.uniform(0.1, 0.9)), "forecast_id": -1,
+                    "forecast_boxes": [{"detection_score": 0.0, "forecast_score": 0.0, "forecast_id": -1} for _ in range(3)]}
+                   for i, c in enumerate(cents)],
+          "tokB": []}
+    out["mf_translation"] = cents
+    out["mf_is_car"] = np.array([b["detection_name"] == "car" for b in fb["tokA"]])
+    out["mf_det_score"] = np.array([b["detection_score"] for b in fb["tokA"]])
+    out["mf_fc_score"] = np.array([b["forecast_score"] for b in fb["tokA"]])
+    res = nm.multi_future(fb, "car")
+    out["mf_ids"] = np.array([b["forecast_id"] for b in res["tokA"]], np.int64)
+    out["mf_sub_ids"] = np.array([[s["forecast_id"] for s in b["forecast_boxes"]] for b in res["tokA"]], np.int64)
+    out["mf_sub_det"] = np.array([[s["detection_score"] for s in b["forecast_boxes"]] for b in res["tokA"]])
+    print("multi_future groups", len(set(out["mf_ids"].tolist())), "of", len(out["mf_ids"]))
+    save("forecast2.npz", **out)
+
+
 if __name__ == "__main__":
     install_shims()
     sys.path.insert(0, REF)
     which = sys.argv[1:] or ["voxelizer", "configs", "dense", "predict", "iou", "backbone", "sweeps", "pillars", "forecast"]
     for w in which:
         {"voxelizer": gen_voxelizer, "configs": gen_configs, "dense": gen_dense_nets, "predict": gen_predict,
-         "iou": gen_iou, "backbone": gen_backbone, "sweeps": gen_sweeps, "pillars": gen_pillars, "forecast": gen_forecast}[w]()
+         "iou": gen_iou, "backbone": gen_backbone, "sweeps": gen_sweeps, "pillars": gen_pillars, "forecast": gen_forecast,
+         "forecast2": gen_forecast2}[w]()

@@ -803,6 +803,66 @@ def test_forecast_tracker_matches_reference_golden(hip, golden, case, cls):
     assert forecast.tracker("truck", list(g[case + "_time"]), ret_boxes) == []
 
 
+def test_det_to_global_boxes_match_reference_golden(hip, golden):
+    """fd_det_to_global_boxes vs the reference's _second_det_to_nusc_box + _lidar_nusc_box_to_global (forecast2.npz).  float64
+    on the device (fma chains, device sin/cos) vs numpy on the host: |d| <= 1e-9 * max(1, |ref|); the float32 yaw flip and
+    the velocity triple are exact."""
+    from futuredet_amd import forecast
+
+    g = golden("forecast2.npz")
+    det = {"box3d_lidar": torch.from_numpy(g["box3d"]), "scores": torch.from_numpy(g["scores"]), "label_preds": torch.from_numpy(g["labels"])}
+    c, q, v, s = forecast.det_arrays(det)
+    assert np.array_equal(c, g["lidar_center"]) and np.array_equal(v, g["lidar_velocity"]) and np.array_equal(s, g["lidar_size"])
+    assert_close("det -> lidar boxes: quaternion", q, g["lidar_quat"], 1e-12)
+    cs, pose = (g["cs_rotation"], g["cs_translation"]), (g["pose_rotation"], g["pose_translation"])
+    c, q, v, s = forecast.det_arrays(det, cs, pose)
+    assert_close("det -> global boxes: center", c, g["global_center"], 1e-9)
+    assert_close("det -> global boxes: quaternion", q, g["global_quat"], 1e-9)
+    assert_close("det -> global boxes: velocity", v, g["global_velocity"], 1e-9)
+    boxes = forecast._second_det_to_nusc_box(det)
+    assert len(boxes) == len(g["box3d"]) and boxes[3].center.dtype == np.float32 and float(boxes[3].score) == float(g["scores"][3])
+    assert forecast._second_det_to_nusc_box({k: t[:0] for k, t in det.items()}) == []
+
+
+@pytest.mark.parametrize("mode", ["velocity_constant", "velocity_forward", "velocity_reverse", "velocity_dense"])
+def test_forecast_boxes_match_reference_golden(hip, golden, mode):
+    """futuredet_amd.forecast.forecast_boxes (per-step split, global transform, match_boxes / tracker, constant-velocity
+    roll-out) vs the reference's forecast_boxes run on the same detections: same trajectories in the same order, labels and
+    scores identical, float64 centres / orientations / velocities within 1e-9."""
+    from futuredet_amd import forecast
+
+    g = golden("forecast2.npz")
+    det = {"box3d_lidar": torch.from_numpy(g["box3d"]).cuda(), "scores": torch.from_numpy(g["scores"]).cuda(),
+           "label_preds": torch.from_numpy(g["labels"]).cuda()}
+    cs, pose = (g["cs_rotation"], g["cs_translation"]), (g["pose_rotation"], g["pose_translation"])
+    ret = forecast.forecast_boxes(det, list(g["time"]), cs, pose, 7, mode, "car")
+    want_c = g[mode + "_center"]
+    assert len(ret) == len(want_c) and all(len(tr) == 7 for tr in ret)
+    assert np.array_equal(np.array([[b.label for b in tr] for tr in ret], np.int64), g[mode + "_label"])
+    assert np.array_equal(np.array([[float(b.score) for b in tr] for tr in ret]), g[mode + "_score"])
+    assert_close("forecast_boxes %s centres" % mode, np.array([[b.center for b in tr] for tr in ret], np.float64), want_c, 1e-9)
+    assert_close("forecast_boxes %s orientations" % mode, np.array([[b.orientation.elements for b in tr] for tr in ret]), g[mode + "_quat"], 1e-9)
+    assert_close("forecast_boxes %s velocities" % mode, np.array([[b.velocity for b in tr] for tr in ret]), g[mode + "_velocity"], 1e-9)
+    assert forecast.forecast_boxes(det, [0.5, 0.0, 0.5, 0.5, 0.5, 0.5], cs, pose, 7, mode, "car") == []  # a stale step (:402-403,419-420)
+
+
+def test_multi_future_matches_reference_golden(hip, golden):
+    """forecast ids (connected components of the < 0.25 m graph, numbered like networkx enumerates them) and the copied
+    scores vs the reference's multi_future; a 0.2 m chain must end up in one component, other classes are dropped."""
+    from futuredet_amd import forecast
+
+    g = golden("forecast2.npz")
+    fb = {"tokA": [{"sample_token": "tokA", "translation": c.tolist(), "detection_name": "car" if car else "pedestrian",
+                    "detection_score": float(ds), "forecast_score": float(fs), "forecast_id": -1,
+                    "forecast_boxes": [{"detection_score": 0.0, "forecast_score": 0.0, "forecast_id": -1} for _ in range(3)]}
+                   for c, car, ds, fs in zip(g["mf_translation"], g["mf_is_car"], g["mf_det_score"], g["mf_fc_score"])], "tokB": []}
+    res = forecast.multi_future(fb, "car")
+    assert np.array_equal(np.array([b["forecast_id"] for b in res["tokA"]], np.int64), g["mf_ids"])
+    assert np.array_equal(np.array([[s["forecast_id"] for s in b["forecast_boxes"]] for b in res["tokA"]], np.int64), g["mf_sub_ids"])
+    assert np.array_equal(np.array([[s["detection_score"] for s in b["forecast_boxes"]] for b in res["tokA"]]), g["mf_sub_det"])
+    assert res["tokB"] == [] and len(forecast.forecast_ids(np.zeros((0, 3)))) == 0
+
+
 # ------------------------------------------------------------------------------------------------ edge cases
 def test_forward_points_empty_and_ragged_batch(hip):
     """An empty cloud, a cloud entirely outside the range and a normal cloud in one batch: no crash, finite output for
@@ -853,6 +913,9 @@ def test_c_abi_reports_errors_instead_of_exiting(hip):
         ("fd_pillar_encode", lambda: L.fd_pillar_encode(x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 4, 99, 5, 0, ctypes.c_float(1), ctypes.c_float(1),
                                                        ctypes.c_float(0), ctypes.c_float(0), x.data_ptr(), x.data_ptr(), x.data_ptr(), 64, None, None,
                                                        None, 0, 0, x.data_ptr(), 64, None)),
+        ("fd_forecast_groups", lambda: L.fd_forecast_groups(x.data_ptr(), 5000, ctypes.c_double(0.25), x.data_ptr(), None)),
+        ("fd_det_to_global_boxes", lambda: L.fd_det_to_global_boxes(x.data_ptr(), 4, (ctypes.c_double * 4)(1, 0, 0, 0), None, None, None, x.data_ptr(),
+                                                                   x.data_ptr(), x.data_ptr(), x.data_ptr(), None)),
         ("fd_forecast_chains", lambda: L.fd_forecast_chains(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 99, 8, ctypes.c_double(1.0),
                                                            x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
                                                            x.data_ptr(), None)),

@@ -263,3 +263,19 @@ def test_oracle_forecast_tracker_matches_reference_golden(golden, case, cls):
     assert np.array_equal(np.asarray(got_centers, np.float64).reshape(-1, 7, 3), want_centers)
     if case + "_match_tags" in g:
         assert np.array_equal(np.asarray(ofc.match_indices(centers)), g[case + "_match_tags"])
+
+
+def test_oracle_det_to_global_and_forecast_ids_match_reference_golden(golden):
+    """oracle/forecast.py's array restatements of _second_det_to_nusc_box / _lidar_nusc_box_to_global / multi_future's
+    grouping vs the reference's own functions (forecast2.npz; float64, 1e-12 relative -- BLAS vs plain summation order)."""
+    from oracle import forecast as of
+
+    g = golden("forecast2.npz")
+    c, q, v, s = of.det_to_boxes(g["box3d"])
+    assert np.array_equal(c, g["lidar_center"]) and np.array_equal(q, g["lidar_quat"]) and np.array_equal(v, g["lidar_velocity"])
+    assert np.array_equal(s, g["lidar_size"])
+    c2, q2, v2 = of.boxes_to_global(c, q, v, [(g["cs_rotation"], g["cs_translation"]), (g["pose_rotation"], g["pose_translation"])])
+    for got, key in ((c2, "global_center"), (q2, "global_quat"), (v2, "global_velocity")):
+        assert (np.abs(got - g[key]) / np.maximum(1.0, np.abs(g[key]))).max() <= 1e-12, key
+    assert np.array_equal(of.forecast_ids(g["mf_translation"][g["mf_is_car"]]), g["mf_ids"])
+    assert len(of.forecast_ids(np.zeros((0, 3)))) == 0
