@@ -5,7 +5,8 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if "vox_hash" in r["Kernel_Name"]]
-a, b = starts[-2], starts[-1]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else None  # k-th forward pass of a serial run, else the last full one
+a, b = (starts[k], starts[k + 1]) if k is not None else (starts[-2], starts[-1])
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b]:
     n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")[:60]

@@ -4,13 +4,18 @@ import sys
 from collections import OrderedDict
 
 
-def main(path, steps_back=1):
+def main(path, steps_back=1, step_index=None):
+    """step_index = k: the k-th forward pass of the trace (0-based, counted by its vox_hash launch; use with a serial
+    --inflight 1 run: passes in flight on two streams interleave in time).  Otherwise the steps_back passes before the last."""
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if "vox_hash" in r["Kernel_Name"]]
     # full steps only: from the (steps_back+1)-th last step start up to the start of the last step (the trailing
     # part of the trace also holds bench.py's post-loop pair counting, which is not part of a step)
-    first, last = starts[-1 - steps_back], starts[-1]
+    if step_index is not None:
+        first, last, steps_back = starts[step_index], starts[step_index + 1], 1
+    else:
+        first, last = starts[-1 - steps_back], starts[-1]
     sel = rows[first:last]
     agg = OrderedDict()
     for r in sel:
@@ -28,4 +33,4 @@ def main(path, steps_back=1):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1, int(sys.argv[3]) if len(sys.argv) > 3 else None)
