@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the second timed loop (host -> host)")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage GPU times to stderr")
+    ap.add_argument("--torch-dense", action="store_true", help="A/B: run RPN + head through PyTorch-ROCm (MIOpen) instead of the hand-written MFMA convolutions")
     ap.add_argument("--dump", default="", help="rank 0 saves the last step's gathered detections (npz: packed, counts) here (tests)")
     args = ap.parse_args()
     if args.config:
@@ -213,6 +214,8 @@ def main():
     net.load_state_dict(sd, strict=False)
     net = net.to(dev).eval()
     dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
+    if args.torch_dense:
+        net.neck.use_hip_conv = net.bbox_head.use_hip_conv = False
     net.set_precision(dtype, None if args.channels_last < 0 else bool(args.channels_last))
     prof = SpconvProfiler()
     net.backbone.profile_hook = prof

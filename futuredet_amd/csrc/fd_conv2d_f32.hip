@@ -1,0 +1,314 @@
+// Dense 2-D convolution for gfx950 in fp32 (fp32 in, fp32 MFMA, fp32 out), NHWC, fused bias (+folded BN) + ReLU.
+//
+// Serves the RPN neck and CenterHead convolutions (det3d/models/necks/rpn.py:81-159,
+// det3d/models/bbox_heads/center_head.py:104-143,344-349) of the fp32 configurations (BASELINE configs[1], [4]).  MIOpen's
+// fp32 path for these shapes is an assembly Winograd kernel on the vector ALU (SQ_VALU_MFMA_BUSY_CYCLES = 0, see
+// profiles/) plus separate bias / ReLU / concat passes; this is a direct implicit GEMM on v_mfma_f32_16x16x4_f32:
+//
+//   * a workgroup computes a TH x TW patch of output pixels (flattened to MB = ceil(TH*TW/16) blocks of 16) times
+//     NT = 16 * NBW * WAVES_N output channels; a wave owns NBW blocks of 16 channels for MB / WAVES_M pixel blocks
+//     (wide layers: 4 waves side by side over the channels, each with all pixel blocks; the narrow final head
+//     convolutions: 4 waves over the pixel blocks), so the accumulators never leave the register file;
+//   * for every 16-channel slice of the input the (TH-1)*S+KS by (TW-1)*S+KS halo patch is staged in LDS once (64 bytes
+//     per pixel) and all KS*KS taps read their fragments from it with ds_read_b128 at a per-lane base plus an immediate
+//     tap offset -- the 9x im2col blow-up never touches HBM or L2.  (No swizzle: a b128 lane group covers 16 consecutive
+//     pixels x 2 chunks = a 2-way bank conflict, and with one 1 KiB fragment read per 4 * NBW MFMAs of 32 cycles the
+//     LDS is nowhere near busy; a swizzle would cost ~9 vector-ALU instructions per read next to the MFMAs.)
+//   * the product is issued transposed (A operand = weight fragment, B operand = pixel fragment): lane (pixel j, quad q)
+//     ends up with four consecutive output channels of pixel j, so the epilogue adds bias, applies ReLU and stores
+//     16 bytes per lane straight into the NHWC tensor -- no transpose through LDS;
+//   * weights are pre-packed in fragment order and streamed from L2 with one coalesced 1 KiB load per wave instruction,
+//     one (slice, tap) step ahead of their MFMAs; the next slice's patch is fetched into registers while the current
+//     slice's MFMAs run (double-buffered LDS);
+//   * output placement (y*osy+ooy, x*osx+oox, co_off + co) in a tensor with cout_total channels expresses the RPN's
+//     concat and the 2x2 stride-2 transposed convolution (four 1x1 convolutions writing interleaved pixels) in place.
+// The tile shape is chosen per layer (fd_conv2d_nhwc_f32 below): 180 x 180 maps take 12 x 12 tiles (225 workgroups for
+// 256 compute units, no padded pixel rows), 90 x 90 maps 5 x 15 tiles.
+#include "fd_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvParamsF {
+    int B, H, W, Cin, Ho, Wo, Cout_pad, Cout_real, cout_total, co_off, pad, relu;
+    int osy, osx, ooy, oox;  // output pixel mapping
+    int tiles_x, tiles_y;
+};
+
+// CS = 16-channel sub-slices staged per barrier (3x3: 2 -> 32 channels, 1x1: 4 -> 64 channels: a 1x1 step has no taps to
+// amortise the patch hand-over over)
+template <int KS, int S, int TH, int TW, int NBW, int WAVES_N, int CS>
+__global__ void __launch_bounds__(256) conv2d_nhwc_f32(const float *__restrict__ x, const float4 *__restrict__ wp, const float *__restrict__ bias,
+                                                       float *__restrict__ y, ConvParamsF p) {
+    constexpr int MPIX = TH * TW, MB_ALL = (MPIX + 15) / 16;
+    constexpr int WAVES_M = 4 / WAVES_N, MB = MB_ALL / WAVES_M;  // pixel blocks per wave
+    static_assert(WAVES_N * WAVES_M == 4 && MB * WAVES_M == MB_ALL, "pixel blocks must split evenly over the waves");
+    constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PP = PH * PW;
+    constexpr int PIXB = 64 * CS;                       // bytes per pixel of a staged slice
+    constexpr int NCHUNK = PP * 4 * CS;                 // 16-byte chunks per staged slice
+    constexpr int NLOAD = (NCHUNK + 255) / 256;
+    constexpr int NT = 16 * NBW * WAVES_N;              // output channels per workgroup
+    constexpr int TAPS = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x PP x PIXB bytes
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 15, lq = lane >> 4;
+    int t = blockIdx.x;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int n0 = blockIdx.y * NT + wn * NBW * 16;     // first output channel of this wave
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+    const int nslices = (p.Cin / 16 + CS - 1) / CS;  // staged slices; the last one may be partly past Cin (zero-filled)
+
+    float4 stage[NLOAD];
+    auto load_slice = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int id = tid + i * 256;
+            stage[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id < NCHUNK) {
+                const int pix = id / (4 * CS), q = id % (4 * CS);
+                const int iy = iy0 + pix / PW, ix = ix0 + pix % PW;
+                const int ch = s * 16 * CS + q * 4;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ch < p.Cin)
+                    stage[i] = *reinterpret_cast<const float4 *>(x + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + ch);
+            }
+        }
+    };
+    auto store_slice = [&](int buf) {
+        unsigned char *dst = smem + buf * (PP * PIXB);
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) {
+            const int id = tid + i * 256;
+            if (id < NCHUNK) *reinterpret_cast<float4 *>(dst + id * 16) = stage[i];  // pixel-major, chunk-minor = id order
+        }
+    };
+
+    f32x4 acc[MB][NBW];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // LDS byte offset of this lane's pixel (tap 0) and chunk in every pixel block of the wave (row-major inside the tile;
+    // lanes past the tile re-read its last pixel)
+    int abase[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        int m = (wm * MB + i) * 16 + lm;
+        m = m < MPIX ? m : MPIX - 1;
+        abase[i] = ((m / TW) * S * PW + (m % TW) * S) * PIXB + lq * 16;
+    }
+    // packed weights: [Cout_pad/16][slice][tap][lane] x 16 bytes
+    const int64_t w_nb_stride = (int64_t)(p.Cin / 16) * TAPS * 64;
+    const float4 *wb[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int nb = (n0 >> 4) + j;  // blocks past the packed width (a tile wider than the layer) re-read the last one
+        wb[j] = wp + (int64_t)(nb < (p.Cout_pad >> 4) ? nb : (p.Cout_pad >> 4) - 1) * w_nb_stride + lane;
+    }
+    const int total_steps = (p.Cin / 16) * TAPS;
+
+    load_slice(0);
+    store_slice(0);
+    __syncthreads();
+    float4 bw[NBW], bw_next[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) bw[j] = wb[j][0];
+    if (nslices > 1) load_slice(1);  // registers hold slice s+1 while slice s is computed
+    for (int s = 0; s < nslices; ++s) {
+        const unsigned char *src = smem + (s & 1) * (PP * PIXB);
+        // pixel fragments are read one step ahead of their MFMAs (the LDS round trip of MB reads would otherwise sit in
+        // front of every step's MFMA block: one wave per SIMD has nobody else to fill it)
+        float4 a[2][MB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i) a[0][i] = *reinterpret_cast<const float4 *>(src + abase[i]);
+        constexpr int STEPS = CS * TAPS;  // steps of a staged slice: sub-slice major, tap minor (= the packed weight order)
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int step = s * STEPS + st;
+            if (step >= total_steps) break;  // (only a trailing partial slice ends early)
+            {   // weights of the next step travel under this step's MFMAs
+                const int ns = step + 1 < total_steps ? step + 1 : 0;
+#pragma unroll
+                for (int j = 0; j < NBW; ++j) bw_next[j] = wb[j][(int64_t)ns * 64];
+            }
+            if (st + 1 < STEPS) {
+                constexpr int kZero = 0;
+                const int sub = (st + 1) / TAPS + kZero, tap = (st + 1) % TAPS;
+                const int toff = ((tap / KS) * PW + (tap % KS)) * PIXB + sub * 64;  // compile-time: the ds_read offset field
+#pragma unroll
+                for (int i = 0; i < MB; ++i) a[(st + 1) & 1][i] = *reinterpret_cast<const float4 *>(src + abase[i] + toff);
+            }
+            // pin both prefetches HERE: left alone, hipcc sinks the weight loads below the last MFMA that reads the old
+            // registers (to coalesce the copy at the end of the step) and the fragment reads next to them, which puts an
+            // L2 round trip and an LDS round trip in front of every step
+            __builtin_amdgcn_sched_barrier(0);
+            // k-step outermost: MB * NBW independent accumulators lie between two MFMAs on the same one (the dependent-
+            // accumulator latency of v_mfma_f32_16x16x4_f32 is 40 cycles against 32 of issue)
+#define FD_KSTEP(C)                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int j = 0; j < NBW; ++j)                    \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[j].C, a[st & 1][i].C, acc[i][j], 0, 0, 0);
+            FD_KSTEP(x) FD_KSTEP(y) FD_KSTEP(z) FD_KSTEP(w)
+#undef FD_KSTEP
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) bw[j] = bw_next[j];
+        }
+        // patch hand-over at the END of a slice (vector-memory loads return in order: issued here the next patch has a full
+        // slice of MFMAs to land and only the weight loads of the next slice's first steps queue behind it)
+        if (s + 1 < nslices) store_slice((s + 1) & 1);
+        if (s + 2 < nslices) load_slice(s + 2);
+        __syncthreads();
+    }
+    // epilogue: lane (pixel lm of block i, quad lq) holds channels n0 + 16 j + 4 lq .. + 3 of its pixel
+    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
+    const bool wide = ((p.cout_total | p.co_off) & 3) == 0;  // 16-byte aligned channel quads
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int co = n0 + j * 16 + lq * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && co < p.Cout_real) {
+            bv.x = bias[co];
+            if (co + 1 < p.Cout_real) bv.y = bias[co + 1];
+            if (co + 2 < p.Cout_real) bv.z = bias[co + 2];
+            if (co + 3 < p.Cout_real) bv.w = bias[co + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int m = (wm * MB + i) * 16 + lm;
+            const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+            if (m >= MPIX || oy >= p.Ho || ox >= p.Wo || co >= p.Cout_real) continue;
+            float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
+            float *dst = y + (((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co;
+            if (wide && co + 3 < p.Cout_real) {
+                *reinterpret_cast<float4 *>(dst) = v;
+            } else {
+                dst[0] = v.x;
+                if (co + 1 < p.Cout_real) dst[1] = v.y;
+                if (co + 2 < p.Cout_real) dst[2] = v.z;
+                if (co + 3 < p.Cout_real) dst[3] = v.w;
+            }
+        }
+    }
+}
+
+template <int KS, int S, int TH, int TW, int NBW, int WAVES_N>
+void launch_f32(const float *x, const void *wp, const float *bias, float *y, ConvParamsF p, hipStream_t stream) {
+    constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
+    constexpr int NT = 16 * NBW * WAVES_N;
+    // channels staged per barrier: 64 for 1x1, 32 for 3x3 stride 1, 16 for the large stride-2 patches
+    constexpr int CS = KS == 1 ? 4 : (S == 1 ? 2 : 1);
+    const size_t lds = 2 * (size_t)PH * PW * 64 * CS;
+    p.tiles_x = (p.Wo + TW - 1) / TW;
+    p.tiles_y = (p.Ho + TH - 1) / TH;
+    auto kern = conv2d_nhwc_f32<KS, S, TH, TW, NBW, WAVES_N, CS>;
+    static std::atomic<uint64_t> lds_set{0};
+    if (lds > 65536) (void)fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_set);
+    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)((p.Cout_real + NT - 1) / NT));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, x, (const float4 *)wp, bias, y, p);
+}
+
+struct TileChoice { int th, tw, nbw, wn; };
+constexpr TileChoice kTiles[] = {{12, 12, 2, 4}, {8, 16, 2, 4}, {5, 15, 2, 4}, {8, 8, 2, 4},   // 128 channels per workgroup
+                                 {12, 12, 1, 4}, {8, 16, 1, 4}, {5, 15, 1, 4}, {8, 8, 1, 4},   // 64
+                                 {8, 16, 2, 1}, {8, 16, 1, 1}, {8, 8, 2, 1}, {8, 8, 1, 1}};    // 32 / 16: the final head convolutions
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+// makespan estimate in MFMA-block units (16 pixels x 16 channels x one 16-channel slice-tap) per SIMD: workgroups are dealt
+// to the compute units in rounds; a workgroup costs (pixel blocks per wave) x NBW, plus a prologue / epilogue term
+inline double tile_cost(int Ho, int Wo, int B, int cout, const TileChoice &c, int n_cu) {
+    const int nt = 16 * c.nbw * c.wn;
+    const int64_t wgs = (int64_t)((Ho + c.th - 1) / c.th) * ((Wo + c.tw - 1) / c.tw) * B * ((cout + nt - 1) / nt);
+    const int mb = ((c.th * c.tw + 15) / 16) / (4 / c.wn);
+    const int64_t rounds = (wgs + n_cu - 1) / n_cu;
+    return (double)rounds * (mb * c.nbw + 0.35);
+}
+
+template <int KS, int S>
+int dispatch_tile(const float *x, const void *wp, const float *bias, float *y, const ConvParamsF &p, hipStream_t stream) {
+    const int n_cu = fd::device_cu_count();
+    int best = -1;
+    double bc = 1e30;
+    const int force = fd::tuning(fd::kTuneConvNT);  // tuning override: 1-based candidate index
+    for (int i = 0; i < kNumTiles; ++i) {
+        const double c = tile_cost(p.Ho, p.Wo, p.B, p.Cout_real, kTiles[i], n_cu);
+        if (force == i + 1) { best = i; break; }
+        if (c < bc) { bc = c; best = i; }
+    }
+    switch (best) {
+        case 0: launch_f32<KS, S, 12, 12, 2, 4>(x, wp, bias, y, p, stream); break;
+        case 1: launch_f32<KS, S, 8, 16, 2, 4>(x, wp, bias, y, p, stream); break;
+        case 2: launch_f32<KS, S, 5, 15, 2, 4>(x, wp, bias, y, p, stream); break;
+        case 3: launch_f32<KS, S, 8, 8, 2, 4>(x, wp, bias, y, p, stream); break;
+        case 4: launch_f32<KS, S, 12, 12, 1, 4>(x, wp, bias, y, p, stream); break;
+        case 5: launch_f32<KS, S, 8, 16, 1, 4>(x, wp, bias, y, p, stream); break;
+        case 6: launch_f32<KS, S, 5, 15, 1, 4>(x, wp, bias, y, p, stream); break;
+        case 7: launch_f32<KS, S, 8, 8, 1, 4>(x, wp, bias, y, p, stream); break;
+        case 8: launch_f32<KS, S, 8, 16, 2, 1>(x, wp, bias, y, p, stream); break;
+        case 9: launch_f32<KS, S, 8, 16, 1, 1>(x, wp, bias, y, p, stream); break;
+        case 10: launch_f32<KS, S, 8, 8, 2, 1>(x, wp, bias, y, p, stream); break;
+        case 11: launch_f32<KS, S, 8, 8, 1, 1>(x, wp, bias, y, p, stream); break;
+        default: return 0;
+    }
+    return 1;
+}
+
+}  // namespace
+
+extern "C" size_t fd_conv2d_f32_packed_weight_bytes(int cout, int cin, int ks) {
+    if (cout <= 0 || cin <= 0 || cin % 16 || (ks != 1 && ks != 3)) return 0;
+    const size_t cout_pad = ((size_t)cout + 63) / 64 * 64;
+    return cout_pad * cin * ks * ks * 4;
+}
+
+// w: [cout][cin][ks][ks] float32 (torch Conv2d layout) -> [cout_pad/16][cin/16][tap][lane][4] float32:
+// lane = (co & 15) + 16 * q holds w[co][16 s + 4 q + 0..3][tap]
+extern "C" int fd_conv2d_f32_pack_weight(const float *w, int cout, int cin, int ks, void *dst) {
+    FD_REQUIRE(w && dst, "fd_conv2d_f32_pack_weight: null argument");
+    FD_REQUIRE(cin % 16 == 0 && (ks == 1 || ks == 3) && cout > 0, "fd_conv2d_f32_pack_weight: need cin %% 16 == 0 and ks in {1,3}");
+    const int cout_pad = (cout + 63) / 64 * 64, nsl = cin / 16, taps = ks * ks;
+    float *d = (float *)dst;
+    for (int nb = 0; nb < cout_pad / 16; ++nb)
+        for (int s = 0; s < nsl; ++s)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = nb * 16 + (lane & 15);
+                        const int ci = s * 16 + 4 * (lane >> 4) + j;
+                        d[((((int64_t)nb * nsl + s) * taps + tap) * 64 + lane) * 4 + j] =
+                            co < cout ? w[(((int64_t)co * cin + ci) * ks + tap / ks) * ks + tap % ks] : 0.0f;
+                    }
+    return FD_OK;
+}
+
+extern "C" int fd_conv2d_nhwc_f32(const float *x, int B, int H, int W, int cin, const void *wpacked, const float *bias, int cout, int ks,
+                                  int stride, int pad, int relu, float *y, int cout_total, int co_off, int osy, int osx, int ooy, int oox,
+                                  fd_stream_t stream) {
+    FD_REQUIRE(x && wpacked && y, "fd_conv2d_nhwc_f32: null argument");
+    FD_REQUIRE(cin % 16 == 0 && cin >= 16, "fd_conv2d_nhwc_f32: cin must be a multiple of 16 (got %d)", cin);
+    FD_REQUIRE((ks == 3 && (stride == 1 || stride == 2) && pad == 1) || (ks == 1 && stride == 1 && pad == 0),
+               "fd_conv2d_nhwc_f32: supported: 3x3 stride 1|2 pad 1, 1x1 stride 1 pad 0");
+    FD_REQUIRE(B > 0 && H > 0 && W > 0 && cout > 0 && osy >= 1 && osx >= 1, "fd_conv2d_nhwc_f32: bad shape");
+    ConvParamsF p;
+    p.B = B; p.H = H; p.W = W; p.Cin = cin;
+    p.Ho = (H + 2 * pad - ks) / stride + 1;
+    p.Wo = (W + 2 * pad - ks) / stride + 1;
+    p.Cout_real = cout;
+    p.Cout_pad = (cout + 63) / 64 * 64;
+    p.cout_total = cout_total; p.co_off = co_off; p.pad = pad; p.relu = relu;
+    p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox;
+    p.tiles_x = p.tiles_y = 0;
+    hipStream_t s = fd::as_stream(stream);
+    int ok;
+    if (ks == 3 && stride == 1) ok = dispatch_tile<3, 1>(x, wpacked, bias, y, p, s);
+    else if (ks == 3) ok = dispatch_tile<3, 2>(x, wpacked, bias, y, p, s);
+    else ok = dispatch_tile<1, 1>(x, wpacked, bias, y, p, s);
+    FD_REQUIRE(ok, "fd_conv2d_nhwc_f32: no tile shape for cout %d", cout);
+    return fd::check_launch("fd_conv2d_nhwc_f32");
+}

@@ -1,6 +1,7 @@
-"""bf16 execution plan of the RPN neck + CenterHead on the hand-written MFMA convolution (fd_conv2d_nhwc_bf16).
+"""Execution plan of the RPN neck + CenterHead on the hand-written MFMA convolutions: bf16 (fd_conv2d_nhwc_bf16,
+v_mfma_f32_32x32x16_bf16) and fp32 (fd_conv2d_nhwc_f32, v_mfma_f32_16x16x4_f32).
 
-Activations are NHWC bf16 tensors; BatchNorm is folded; the RPN concat is written in place (channel offsets), the
+Activations are NHWC tensors of the plan's dtype; BatchNorm is folded; the RPN concat is written in place (channel offsets), the
 2x2 stride-2 transposed convolution runs as four 1x1 convolutions writing interleaved pixels, and the six branches
 of a SepHead run as one 64->384 convolution followed by one block-diagonal 384->(9+2T) convolution.
 Built lazily from the torch modules (so state_dict loading is unchanged) and cached until the next load.
@@ -12,31 +13,39 @@ from . import hip_ops
 from .nn_utils import fold_stack
 
 
+def granule(dtype):
+    """input-channel granule of the convolution kernel of ``dtype`` (one LDS slice)"""
+    return 32 if dtype == torch.bfloat16 else 16
+
+
 class _Conv(object):
-    def __init__(self, w_oihw, bias, stride, relu):
+    def __init__(self, w_oihw, bias, stride, relu, dtype):
         self.cout, self.cin, self.ks, _ = w_oihw.shape
-        self.stride, self.relu = stride, relu
-        self.wpk = hip_ops.pack_conv2d_weight(w_oihw)
+        self.stride, self.relu, self.dtype = stride, relu, dtype
+        if self.cin % granule(dtype):
+            raise ValueError("conv plan: %d input channels are not a multiple of %d" % (self.cin, granule(dtype)))
+        self.wpk = hip_ops.pack_conv2d_weight(w_oihw) if dtype == torch.bfloat16 else hip_ops.pack_conv2d_weight_f32(w_oihw)
         self.bias = bias.float().contiguous() if bias is not None else None
+        self.fn = hip_ops.conv2d_nhwc_bf16 if dtype == torch.bfloat16 else hip_ops.conv2d_nhwc_f32
 
     def __call__(self, x, out=None, co_off=0, **kw):
-        return hip_ops.conv2d_nhwc_bf16(x, self.wpk, self.bias, self.cout, self.ks, self.stride, self.relu, out=out,
-                                        co_off=co_off, **kw)
+        return self.fn(x, self.wpk, self.bias, self.cout, self.ks, self.stride, self.relu, out=out, co_off=co_off, **kw)
 
 
-def _convs_from_stack(modules):
+def _convs_from_stack(modules, dtype):
     out = []
     for f in fold_stack(modules, torch.float32, False):
         assert not f.transposed
         assert (f.weight.shape[-1] == 3 and f.padding == 1) or (f.weight.shape[-1] == 1 and f.padding == 0), \
             "only 3x3 pad 1 / 1x1 pad 0 convolutions appear in the RPN / head"
-        out.append(_Conv(f.weight, f.bias, f.stride, f.relu))
+        out.append(_Conv(f.weight, f.bias, f.stride, f.relu, dtype))
     return out
 
 
 class RPNPlan(object):
-    def __init__(self, rpn):
-        self.blocks = [_convs_from_stack(b._modules.values()) for b in rpn.blocks]
+    def __init__(self, rpn, dtype=torch.bfloat16):
+        self.dtype = dtype
+        self.blocks = [_convs_from_stack(b._modules.values(), dtype) for b in rpn.blocks]
         self.start = rpn._upsample_start_idx
         self.deblocks = []
         for d in rpn.deblocks:
@@ -45,21 +54,21 @@ class RPNPlan(object):
             if f.transposed:  # ConvTranspose2d(k = s): weight [Cin, Cout, k, k] -> k*k 1x1 convs on interleaved pixels
                 k = f.weight.shape[-1]
                 assert f.stride == k and f.padding == 0
-                subs = [(_Conv(f.weight[:, :, dy, dx].t().contiguous()[:, :, None, None], f.bias, 1, f.relu), dy, dx)
+                subs = [(_Conv(f.weight[:, :, dy, dx].t().contiguous()[:, :, None, None], f.bias, 1, f.relu, dtype), dy, dx)
                         for dy in range(k) for dx in range(k)]
                 self.deblocks.append(("up", k, subs, f.weight.shape[1]))
             elif f.weight.shape[-1] == 1:
                 assert f.stride == 1 and f.padding == 0
-                self.deblocks.append(("conv", 1, _Conv(f.weight, f.bias, 1, f.relu), f.weight.shape[0]))
+                self.deblocks.append(("conv", 1, _Conv(f.weight, f.bias, 1, f.relu, dtype), f.weight.shape[0]))
             else:
                 # Conv2d(k = s, stride s) of an `us stride` 1/s (rpn.py:95-110, the pp configs): space-to-depth + 1x1 conv
                 k = f.weight.shape[-1]
                 assert f.stride == k and f.padding == 0
                 w = f.weight.permute(0, 2, 3, 1).reshape(f.weight.shape[0], -1)[:, :, None, None].contiguous()
-                self.deblocks.append(("down", k, _Conv(w, f.bias, 1, f.relu), f.weight.shape[0]))
+                self.deblocks.append(("down", k, _Conv(w, f.bias, 1, f.relu, dtype), f.weight.shape[0]))
         self.cout_total = sum(d[3] for d in self.deblocks)
 
-    def __call__(self, x):  # x [B,H,W,C] bf16
+    def __call__(self, x):  # x [B,H,W,C] of the plan's dtype
         ups = None
         co = 0
         for i, stack in enumerate(self.blocks):
@@ -71,7 +80,7 @@ class RPNPlan(object):
                 B, H, W, C = x.shape
                 Ho, Wo = (H // k, W // k) if kind == "down" else (H * k, W * k)
                 if ups is None:
-                    ups = torch.empty((B, Ho, Wo, self.cout_total), dtype=torch.bfloat16, device=x.device)
+                    ups = torch.empty((B, Ho, Wo, self.cout_total), dtype=self.dtype, device=x.device)
                 assert ups.shape[1] == Ho and ups.shape[2] == Wo
                 if kind == "conv":
                     op(x, out=ups, co_off=co)
@@ -91,9 +100,10 @@ class HeadPlan(object):
     i > 0 reads cat[x, feats_{i-1}], which is laid out in place: two ping-pong [B,H,W,2c] buffers hold x in channels
     [0,c) and receive the previous task's feats in [c,2c) (task 0 reads the same buffer through zero weights)."""
 
-    def __init__(self, head):
+    def __init__(self, head, dtype=torch.bfloat16):
         assert not head.bev_map
-        self.shared = _convs_from_stack(head.shared_conv)
+        self.dtype = dtype
+        self.shared = _convs_from_stack(head.shared_conv, dtype)
         self.ff = bool(head.forecast_feature)
         self.tasks = []
         self.pre = []
@@ -105,7 +115,7 @@ class HeadPlan(object):
                 w0 = st[0].weight
                 if ti == 0:  # reads [x | stale feats]: zero weights on the second half
                     w0 = torch.cat([w0, torch.zeros_like(w0)], dim=1)
-                self.pre.append((_Conv(w0, st[0].bias, 1, True), _Conv(st[1].weight, st[1].bias, 1, True)))
+                self.pre.append((_Conv(w0, st[0].bias, 1, True, dtype), _Conv(st[1].weight, st[1].bias, 1, True, dtype)))
             names = list(task.heads)
             firsts, finals = [], []
             for h in names:
@@ -123,9 +133,9 @@ class HeadPlan(object):
                 w2[o:o + couts[i], i * hc:(i + 1) * hc] = f.weight
                 o += couts[i]
             b2 = torch.cat([f.bias for f in finals], 0)
-            self.tasks.append((_Conv(w1, b1, 1, True), _Conv(w2, b2, 1, False), names, couts))
+            self.tasks.append((_Conv(w1, b1, 1, True, dtype), _Conv(w2, b2, 1, False, dtype), names, couts))
 
-    def __call__(self, x):  # x [B,H,W,C] bf16 -> list of dicts of NCHW float32 tensors
+    def __call__(self, x):  # x [B,H,W,C] of the plan's dtype -> list of dicts of NCHW float32 tensors
         for conv in self.shared[:-1]:
             x = conv(x)
         last = self.shared[-1]
@@ -133,7 +143,7 @@ class HeadPlan(object):
         if self.ff:
             B, H, W, _ = x.shape
             if self._cat is None or self._cat[0].shape[:3] != (B, H, W) or self._cat[0].device != x.device:
-                self._cat = [torch.zeros((B, H, W, 2 * hc), dtype=torch.bfloat16, device=x.device) for _ in range(2)]
+                self._cat = [torch.zeros((B, H, W, 2 * hc), dtype=self.dtype, device=x.device) for _ in range(2)]
             # task 0 reads [x | feats of the previous frame] through zero weights: clear that half so a non-finite value
             # of an earlier frame (0 * Inf = NaN) cannot leak into this one
             self._cat[0][..., hc:].zero_()

@@ -65,6 +65,7 @@ class VoxelNet(SingleStageDetector):
         super().__init__(reader, backbone, neck, bbox_head, train_cfg, test_cfg, pretrained)
         # a captured neck+head graph replays kernels that read the folded / packed weights of the moment of capture
         self.register_load_state_dict_post_hook(lambda m, keys: m.invalidate_caches())
+        self.set_precision(torch.float32)
 
     def invalidate_caches(self):
         """Drops the captured hipGraphs (and, through the sub-modules' own hooks / version keys, every derived weight).
@@ -85,8 +86,8 @@ class VoxelNet(SingleStageDetector):
         if channels_last is None:
             channels_last = False  # measured on MI355X: MIOpen is as fast or faster on NCHW for these shapes
         self.backbone.compute_dtype = dtype
-        # bf16: the neck/head run on the hand-written NHWC MFMA convolution, so the BEV map is written channels-last
-        self.backbone.dense_channels_last = channels_last or dtype == torch.bfloat16
+        # the neck/head run on the hand-written NHWC MFMA convolutions (bf16 and fp32), so the BEV map is written channels-last
+        self.backbone.dense_channels_last = channels_last or dtype == torch.bfloat16 or getattr(self.neck, "use_hip_conv", False)
         self.neck.compute_dtype = dtype
         self.neck.channels_last = channels_last
         self.bbox_head.compute_dtype = dtype
@@ -232,7 +233,7 @@ class PointPillars(SingleStageDetector):
     def set_precision(self, dtype=torch.float32, channels_last=None):
         channels_last = bool(channels_last)
         self.reader.compute_dtype = dtype
-        self.backbone.dense_channels_last = channels_last or dtype == torch.bfloat16
+        self.backbone.dense_channels_last = channels_last or dtype == torch.bfloat16 or getattr(self.neck, "use_hip_conv", False)
         self.neck.compute_dtype = dtype
         self.neck.channels_last = channels_last
         self.bbox_head.compute_dtype = dtype

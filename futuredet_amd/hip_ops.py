@@ -358,6 +358,36 @@ def conv2d_nhwc_bf16(x, wpk, bias, cout, ks, stride=1, relu=True, out=None, co_o
     return out
 
 
+def pack_conv2d_weight_f32(w_oihw):
+    """[Cout, Cin, k, k] float32 -> MFMA-fragment-ordered fp32 weights on the same device (fd_conv2d_f32_pack_weight)."""
+    L = _lib.load()
+    dev = w_oihw.device
+    w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+    cout, cin, ks, _ = w.shape
+    nbytes = L.fd_conv2d_f32_packed_weight_bytes(cout, cin, ks)
+    if nbytes == 0:
+        raise FutureDetHipError("fd_conv2d_f32: unsupported weight shape %s" % (tuple(w.shape),))
+    host = torch.empty((nbytes,), dtype=torch.uint8)
+    check(L.fd_conv2d_f32_pack_weight(ctypes.c_void_p(w.data_ptr()), cout, cin, ks, ctypes.c_void_p(host.data_ptr())),
+          "fd_conv2d_f32_pack_weight")
+    return host.to(dev)
+
+
+def conv2d_nhwc_f32(x, wpk, bias, cout, ks, stride=1, relu=True, out=None, co_off=0, osy=1, osx=1, ooy=0, oox=0):
+    """x [B,H,W,Cin] float32 contiguous -> y [B,Ho*osy,Wo*osx,Ctot] float32 (allocated when ``out`` is None)."""
+    L = _lib.load()
+    x = _dev(x, "x", torch.float32)
+    B, H, W, cin = x.shape
+    pad = 1 if ks == 3 else 0
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho * osy, Wo * osx, cout), dtype=torch.float32, device=x.device)
+    _dev(out, "out", torch.float32)
+    check(L.fd_conv2d_nhwc_f32(_p(x), B, H, W, cin, _p(wpk), _p(bias), cout, ks, stride, pad, int(bool(relu)), _p(out),
+                               out.shape[3], co_off, osy, osx, ooy, oox, _stream()), "fd_conv2d_nhwc_f32")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ decode / NMS
 def make_decode_cfg(H, W, test_cfg):
     c = DecodeCfg()

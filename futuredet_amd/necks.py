@@ -1,7 +1,8 @@
 """RPN neck (det3d/models/necks/rpn.py:22-159).  Same constructor, same state_dict keys
 (blocks.{i}.{1,4,...}.weight, deblocks.{i}.0.weight, ...).  In eval mode the stack runs with BatchNorm folded
-into the convolutions (ZeroPad2d merged into the conv padding), optionally channels-last / bf16, through
-PyTorch-ROCm's MIOpen convolutions (MFMA); training mode keeps the plain module stack."""
+into the convolutions (ZeroPad2d merged into the conv padding) on the hand-written MFMA convolutions (dense_bf16.py:
+NHWC, bf16 or fp32, concat and transposed convolution written in place); ``use_hip_conv = False`` selects the
+PyTorch-ROCm (MIOpen) path kept for comparison; training mode keeps the plain module stack."""
 import logging
 
 import numpy as np
@@ -113,15 +114,21 @@ class RPN(nn.Module):
     def forward(self, x):
         if self.training:
             return self.forward_modules(x)
-        if self.compute_dtype == torch.bfloat16 and x.is_cuda and self.use_hip_conv:
-            # hand-written MFMA convolutions on NHWC bf16; returned as an NCHW-shaped view of the NHWC buffer
-            ver = weights_version(self)
+        if x.is_cuda and self.use_hip_conv and self.compute_dtype in (torch.bfloat16, torch.float32):
+            # hand-written MFMA convolutions on NHWC activations (bf16 or fp32); returned as an NCHW-shaped view of the
+            # NHWC buffer.  A stack with a channel count the kernels do not take (not a multiple of 32 / 16) stays on the
+            # PyTorch path below.
+            ver = (weights_version(self), self.compute_dtype)
             if self._plan is None or self._plan[0] != ver:
                 from .dense_bf16 import RPNPlan
 
-                self._plan = (ver, RPNPlan(self))
-            y = self._plan[1](x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous())
-            return y.permute(0, 3, 1, 2)
+                try:
+                    self._plan = (ver, RPNPlan(self, self.compute_dtype))
+                except ValueError:
+                    self._plan = (ver, None)
+            if self._plan[1] is not None:
+                xin = x.to(self.compute_dtype).permute(0, 2, 3, 1).contiguous()  # no copy for a channels-last BEV map
+                return self._plan[1](xin).permute(0, 3, 1, 2)
         blocks, deblocks = self._fold()
         x = x.to(self.compute_dtype)
         if self.channels_last:

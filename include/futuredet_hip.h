@@ -153,6 +153,14 @@ int fd_conv2d_pack_weight(const float *w_oihw_host, int cout, int cin, int ks, v
 int fd_conv2d_nhwc_bf16(const void *x, int B, int H, int W, int cin, const void *wpacked, const float *bias, int cout,
                         int ks, int stride, int pad, int relu, void *y, int cout_total, int co_off, int osy, int osx,
                         int ooy, int oox, fd_stream_t stream);
+/* The same convolution in fp32 (fp32 activations / weights / output, v_mfma_f32_16x16x4_f32): the RPN / CenterHead layers of
+ * the fp32 configurations, where the reference runs cuDNN (det3d/models/necks/rpn.py:124-159,
+ * det3d/models/bbox_heads/center_head.py:129-143,344-349).  cin must be a multiple of 16; same placement arguments. */
+size_t fd_conv2d_f32_packed_weight_bytes(int cout, int cin, int ks);
+int fd_conv2d_f32_pack_weight(const float *w_oihw_host, int cout, int cin, int ks, void *wpacked_host);
+int fd_conv2d_nhwc_f32(const float *x, int B, int H, int W, int cin, const void *wpacked, const float *bias, int cout, int ks,
+                       int stride, int pad, int relu, float *y, int cout_total, int co_off, int osy, int osx, int ooy, int oox,
+                       fd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * CenterPoint decode + rotated NMS.  Replaces CenterHead.predict's per-step decode

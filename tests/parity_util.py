@@ -9,7 +9,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = os.path.join(REPO, "gpurun_out", "parity_report.txt")
 
 SCORE_EPS = 1e-5   # a detection may appear / disappear when its score is this close to score_threshold
-IOU_EPS = 1e-4     # an NMS decision may flip when the pair's IoU is this close to nms_iou_threshold
+IOU_EPS = 1e-4     # an NMS decision on IDENTICAL input boxes may flip when the pair's IoU is this close to the threshold
+# End to end the two pipelines' boxes themselves agree only to the 1e-3 (relative, per component) of north_star, and an IoU
+# moves by about the same relative amount as its boxes: a pair within 3e-3 of the threshold can legitimately flip.
+IOU_EPS_E2E = 3e-3
 
 
 def report(name, err, tol, note=""):
@@ -84,9 +87,9 @@ def match_rows(got, want, tol=1e-3):
     return [int(i) for i in np.nonzero(d.min(1) > tol)[0]], [int(i) for i in np.nonzero(d.min(0) > tol)[0]]
 
 
-def attribute_detection_diffs(name, got, want, iou_fn, score_thr, iou_thr, n_box=9, max_frac=0.02):
+def attribute_detection_diffs(name, got, want, iou_fn, score_thr, iou_thr, n_box=9, max_frac=0.02, iou_eps=IOU_EPS_E2E):
     """got / want: [K, n_box + 2] rows (box, score, label).  Every row without a counterpart within 1e-3 must be
-    explained by (a) a score within SCORE_EPS of the threshold, (b) an IoU within IOU_EPS of the NMS threshold with a
+    explained by (a) a score within SCORE_EPS of the threshold, (b) an IoU within ``iou_eps`` of the NMS threshold with a
     box of the same label, or (c) an IoU above the threshold with another *unexplained-by-itself* unmatched row
     (the cascade of (a)/(b): its suppressor appeared or vanished).  Returns the number of unmatched rows."""
     ug, uw = match_rows(got, want)
@@ -104,10 +107,10 @@ def attribute_detection_diffs(name, got, want, iou_fn, score_thr, iou_thr, n_box
             continue
         same = allrows[lab == row[n_box + 1]]
         iou = iou_fn(nms_layout(row[None, :n_box]), nms_layout(same[:, :n_box]))[0]
-        if np.any(np.abs(iou - iou_thr) <= IOU_EPS):
+        if np.any(np.abs(iou - iou_thr) <= iou_eps):
             continue
         others = un_boxes[(un_boxes[:, n_box + 1] == row[n_box + 1]) & (np.abs(un_boxes - row).max(1) > 0)]
-        if len(others) and np.any(iou_fn(nms_layout(row[None, :n_box]), nms_layout(others[:, :n_box]))[0] > iou_thr - IOU_EPS):
+        if len(others) and np.any(iou_fn(nms_layout(row[None, :n_box]), nms_layout(others[:, :n_box]))[0] > iou_thr - iou_eps):
             continue
         unexplained.append((side, row[:3].tolist(), float(row[n_box])))
     assert not unexplained, "%s: detections differ without a near-threshold score / IoU pair: %s" % (name, unexplained[:5])

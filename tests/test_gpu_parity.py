@@ -489,6 +489,66 @@ def test_conv2d_nhwc_bf16_vs_torch(hip, cfg):
     assert bool((out[..., :3] == 7).all()) and bool((out[..., 3 + cout:] == 7).all()), "writes outside the channel window"
 
 
+F32_CONV_CASES = [(3, 1, 64, 128, 37, 45, 0), (3, 2, 32, 128, 40, 33, 0), (3, 1, 128, 64, 20, 20, 0), (3, 1, 96, 11, 19, 35, 0),
+                  (1, 1, 128, 256, 23, 18, 0), (3, 1, 256, 256, 16, 16, 0), (3, 1, 384, 23, 30, 26, 0)] + \
+                 [(3, 1, 48, 70, 29, 31, k) for k in range(1, 13)] + [(3, 2, 16, 130, 33, 27, k) for k in (1, 3, 9, 12)]
+
+
+@pytest.mark.parametrize("cfg", F32_CONV_CASES, ids=lambda c: "k%ds%d_%d-%d_%dx%d_t%d" % c)
+def test_conv2d_nhwc_f32_vs_torch(hip, cfg):
+    """Hand-written fp32 MFMA conv vs torch conv2d in float64 on the host: partial tiles, stride 2, 1x1, Cout that is not
+    a multiple of 16 / 64, channel-offset (concat) writes, every tile shape of the dispatcher (conv_nt = 1..12 forces one;
+    0 = the heuristic).  fp32 FMA chains of <= 9 * 384 terms: |d| <= 1e-4 * max(1, |ref|)."""
+    ks, stride, cin, cout, H, W, tile = cfg
+    rng = np.random.default_rng(cin + cout + H + tile)
+    x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((cout, cin, ks, ks)) * (2.0 / (cin * ks * ks)) ** 0.5).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1 if ks == 3 else 0)).float()
+    wpk = hip.pack_conv2d_weight_f32(w).cuda()
+    xn = x.cuda().permute(0, 2, 3, 1).contiguous()
+    out = torch.full((2, ref.shape[2], ref.shape[3], cout + 5), 7.0, dtype=torch.float32, device="cuda")
+    try:
+        hip.set_tuning("conv_nt", tile)
+        hip.conv2d_nhwc_f32(xn, wpk, b.cuda(), cout, ks, stride, True, out=out, co_off=3)
+    finally:
+        hip.set_tuning("conv_nt", 0)
+    got = out[..., 3:3 + cout].permute(0, 3, 1, 2).cpu()
+    assert_close("conv2d_nhwc_f32 k%d s%d %d->%d %dx%d tile %d" % cfg, got.numpy(), ref.numpy(), 1e-4)
+    assert bool((out[..., :3] == 7).all()) and bool((out[..., 3 + cout:] == 7).all()), "writes outside the channel window"
+
+
+def test_dense_f32_plan_vs_torch_modules(hip):
+    """RPN + CenterHead (n3: 7-timestep head) on the fp32 MFMA plan (concat in place, transposed conv as 4 interleaved
+    1x1, fused heads) vs the plain fp32 torch modules (MIOpen): |d| <= 1e-3 * max(1, |ref|) per element."""
+    import logging
+
+    from futuredet_amd import build_head, build_neck
+    from futuredet_amd.synth import seeded_state_dict
+
+    rpn = build_neck(dict(type="RPN", layer_nums=[2, 2], ds_layer_strides=[1, 2], ds_num_filters=[64, 128], us_layer_strides=[1, 2],
+                          us_num_filters=[128, 128], num_input_features=64, logger=logging.getLogger("RPN")))
+    rpn.load_state_dict(seeded_state_dict(rpn, 3), strict=False)
+    head = build_head(dict(type="CenterHead", in_channels=256, tasks=[dict(num_class=1, class_names=["car"])], dataset="nuscenes",
+                           weight=0.25, code_weights=[1.0] * 10,
+                           common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
+                           share_conv_channel=64, dcn_head=False, timesteps=7, two_stage=False, reverse=False, sparse=False, dense=False,
+                           bev_map=False, forecast_feature=False, classify=False, wide_head=False))
+    head.load_state_dict(seeded_state_dict(head, 4), strict=False)
+    rpn, head = rpn.cuda().eval(), head.cuda().eval()
+    x = torch.randn((2, 64, 44, 36), device="cuda")
+    with torch.no_grad():
+        y_ref = rpn.forward_modules(x)
+        p_ref = head.forward_modules(y_ref)
+        y = rpn(x)
+        p = head(y)
+        assert rpn._plan[1] is not None and head._plan[1] is not None, "the fp32 plan must be the path that ran"
+    assert_close("fp32 plan RPN vs torch modules", y.cpu().numpy(), y_ref.cpu().numpy(), 1e-3)
+    for k in p_ref[0]:
+        assert p[0][k].shape == p_ref[0][k].shape
+        assert_close("fp32 plan head %s vs torch modules" % k, p[0][k].float().cpu().numpy(), p_ref[0][k].cpu().numpy(), 1e-3)
+
+
 def test_dense_bf16_plan_vs_torch_modules(hip):
     """RPN + CenterHead on the HIP bf16 plan (concat in place, transposed conv as 4 interleaved 1x1, fused heads) vs
     the plain fp32 torch modules; bf16 tolerance 3e-2 of each tensor's scale."""

@@ -1,16 +1,53 @@
-import sys, time, torch
-sys.path.insert(0, ".")
+"""Per-layer timing of the RPN / CenterHead convolutions in fp32: hand-written MFMA conv (fd_conv2d_nhwc_f32, every tile
+candidate) vs torch / MIOpen.  usage: python tools/dense_fp32_bench.py [--tiles 0,1,2,...]"""
+import argparse
+import os
+import sys
+
+import torch
 import torch.nn.functional as F
-torch.backends.cudnn.benchmark = ("bench" in sys.argv)
-x = torch.randn(1, 128, 180, 180, device="cuda")
-w = torch.randn(128, 128, 3, 3, device="cuda")
-x2 = torch.randn(1, 256, 90, 90, device="cuda"); w2 = torch.randn(256, 256, 3, 3, device="cuda")
-x3 = torch.randn(1, 512, 180, 180, device="cuda"); w3 = torch.randn(64, 512, 3, 3, device="cuda")
-x4 = torch.randn(1, 64, 180, 180, device="cuda"); w4 = torch.randn(384, 64, 3, 3, device="cuda")
-for name, a, b in (("128x128@180", x, w), ("256x256@90", x2, w2), ("512->64@180", x3, w3), ("64->384@180", x4, w4)):
-    for _ in range(3): F.conv2d(a, b, padding=1)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(20): F.conv2d(a, b, padding=1)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 20
-    fl = 2 * a.shape[2] * a.shape[3] * b.shape[0] * b.shape[1] * 9
-    print(name, "%.1f us  %.1f TFLOP/s" % (dt * 1e6, fl / dt / 1e12))
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from futuredet_amd import hip_ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--tiles", default="0")
+ap.add_argument("--iters", type=int, default=20)
+args = ap.parse_args()
+LAYERS = [("256->128 @180 3x3", 256, 128, 180, 3, 1), ("128->128 @180 3x3", 128, 128, 180, 3, 1), ("128->256 @180 3x3 s2", 128, 256, 180, 3, 2),
+          ("256->256 @90 3x3", 256, 256, 90, 3, 1), ("128->256 @180 1x1", 128, 256, 180, 1, 1), ("256->256 @90 1x1", 256, 256, 90, 1, 1),
+          ("512->64 @180 3x3", 512, 64, 180, 3, 1), ("64->384 @180 3x3", 64, 384, 180, 3, 1), ("384->11 @180 3x3", 384, 11, 180, 3, 1),
+          ("384->23 @180 3x3", 384, 23, 180, 3, 1)]
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / iters
+
+
+for name, cin, cout, hw, ks, st in LAYERS:
+    x = torch.randn(1, cin, hw, hw, device="cuda")
+    w = torch.randn(cout, cin, ks, ks, device="cuda") * 0.02
+    b = torch.randn(cout, device="cuda")
+    pad = 1 if ks == 3 else 0
+    ho = (hw + 2 * pad - ks) // st + 1
+    fl = 2.0 * ho * ho * cout * cin * ks * ks
+    us = timeit(lambda: F.conv2d(x, w, None, stride=st, padding=pad), args.iters)
+    line = "%-22s %6.2f GF | MIOpen %7.1f us %6.1f TF" % (name, fl / 1e9, us, fl / us / 1e6)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wpk = hip_ops.pack_conv2d_weight_f32(w.cpu()).cuda()
+    out = torch.empty((1, ho, ho, cout), device="cuda")
+    for t in [int(v) for v in args.tiles.split(",")]:
+        hip_ops.set_tuning("conv_nt", t)
+        us = timeit(lambda: hip_ops.conv2d_nhwc_f32(xn, wpk, b, cout, ks, st, True, out=out), args.iters)
+        line += " | t%d %7.1f us %6.1f TF" % (t, us, fl / us / 1e6)
+    hip_ops.set_tuning("conv_nt", 0)
+    print(line, flush=True)
