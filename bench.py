@@ -185,7 +185,7 @@ def main():
     from futuredet_amd import build as fbuild
     from futuredet_amd import build_detector, dist_infer, lib
     from futuredet_amd.configs import centerpoint_config
-    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims
 
     # FD_BENCH_ONE_DEVICE=1 (test hook for 1-GPU boxes): every rank uses cuda:0 and the collectives run over gloo, so the
     # world > 1 logic (sharded seeds, barriers, MAX over ranks, result gather, rank-0 print) can be exercised anywhere
@@ -210,7 +210,7 @@ def main():
         cfg = centerpoint_config(args.variant, args.class_name, voxel_size=(args.voxel_xy, args.voxel_xy, 0.2),
                                  max_voxel_num=(min(120000, args.max_voxels), args.max_voxels))
     net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
-    sd = seeded_state_dict(net, 7)
+    sd = tame_box_dims(seeded_state_dict(net, 7))  # random-init weights, box sizes kept in metres (synth.tame_box_dims)
     net.load_state_dict(sd, strict=False)
     net = net.to(dev).eval()
     dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16

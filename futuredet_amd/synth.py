@@ -89,3 +89,14 @@ def load_seeded(module, seed=0):
     missing = [m for m in missing if not m.endswith("num_batches_tracked")]
     assert not missing and not unexpected, (missing, unexpected)
     return module
+
+
+def tame_box_dims(sd, factor=0.01):
+    """Scales the last convolution of every ``dim`` head in a seeded state dict.  With plain random weights the size logits
+    reach +-150, i.e. boxes of exp(150) metres: the reference's float32 rotated-IoU arithmetic has no correct digits left for
+    such boxes (its result changes by O(1) with the last ulp of sin / cos), so NMS decisions between them are noise in ANY
+    implementation.  Scaled, the synthetic network emits boxes of 0.2 .. 5 m like a trained one.  Returns ``sd``."""
+    for k in list(sd.keys()):
+        if k.endswith(".dim.3.weight") or k.endswith(".dim.3.bias"):
+            sd[k] = sd[k] * factor
+    return sd

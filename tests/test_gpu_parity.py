@@ -353,12 +353,12 @@ def _match_detections(got, want, tol=1e-3):
     return int((d.min(1) > tol).sum() + (d.min(0) > tol).sum())
 
 
-def _attribute(name, got, want, cfg=None):
+def _attribute(name, got, want, cfg=None, topk_cut=None):
     """Every detection without a counterpart must be explained by a near-threshold score or NMS pair (parity_util)."""
     from oracle import ops as oops
 
     cfg = cfg or TEST_CFG
-    return attribute_detection_diffs(name, got, want, oops.boxes_iou_bev, cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"])
+    return attribute_detection_diffs(name, got, want, oops.boxes_iou_bev, cfg["score_threshold"], cfg["nms"]["nms_iou_threshold"], topk_cut=topk_cut)
 
 
 def _rows(res):
@@ -404,7 +404,7 @@ def test_voxelnet_end_to_end_vs_oracle(hip, variant):
     from futuredet_amd import build_detector
     from futuredet_amd.collate import collate_kitti_multi, example_to_device
     from futuredet_amd.configs import centerpoint_config
-    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims
     from futuredet_amd.voxelize import Voxelization
     from oracle import model as omodel
     from oracle import ops as oops
@@ -414,7 +414,7 @@ def test_voxelnet_end_to_end_vs_oracle(hip, variant):
     else:
         cfg = centerpoint_config(variant)
     net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
-    sd = seeded_state_dict(net, 7)
+    sd = tame_box_dims(seeded_state_dict(net, 7))
     net.load_state_dict(sd, strict=False)
     net = net.cuda().eval()
     onet = omodel.VoxelNet(cfg.model["reader"], cfg.model["backbone"], cfg.model["neck"], cfg.model["bbox_head"],
@@ -748,13 +748,13 @@ def test_pointpillars_end_to_end_vs_oracle(hip):
     from futuredet_amd import build_detector
     from futuredet_amd.collate import collate_kitti_multi, example_to_device
     from futuredet_amd.configs import pointpillars_config
-    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims
     from futuredet_amd.voxelize import Voxelization
     from oracle import model as omodel
 
     cfg = pointpillars_config()
     net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
-    sd = seeded_state_dict(net, 9)
+    sd = tame_box_dims(seeded_state_dict(net, 9))
     # raw coordinates (tens of metres) and intensities (0..255) enter the first Linear directly: scale it so the random
     # network stays in a sane range (otherwise every heat-map logit saturates and the scores are all exactly 1.0)
     sd["reader.pfn_layers.0.linear.weight"] = sd["reader.pfn_layers.0.linear.weight"] * 0.02
@@ -929,11 +929,11 @@ def test_forward_points_empty_and_ragged_batch(hip):
     the empty samples, and the normal sample's detections match its single-sample run (samples are independent)."""
     from futuredet_amd import build_detector
     from futuredet_amd.configs import centerpoint_config
-    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims
 
     cfg = centerpoint_config("forecast_n0")
     net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
-    net.load_state_dict(seeded_state_dict(net, 7), strict=False)
+    net.load_state_dict(tame_box_dims(seeded_state_dict(net, 7)), strict=False)
     net = net.cuda().eval()
     good = _dev(synthetic_cloud(seed=4, target_points=20000))
     empty = torch.zeros((0, 5), device="cuda")
@@ -997,12 +997,12 @@ def _build_pair(variant, class_name="car", seed=7, **cfg_kw):
     """(cfg, HIP detector on the GPU, CPU oracle detector) with the same seeded weights."""
     from futuredet_amd import build_detector
     from futuredet_amd.configs import centerpoint_config
-    from futuredet_amd.synth import seeded_state_dict
+    from futuredet_amd.synth import seeded_state_dict, tame_box_dims
     from oracle import model as omodel
 
     cfg = centerpoint_config(variant, class_name, **cfg_kw)
     net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
-    sd = seeded_state_dict(net, seed)
+    sd = tame_box_dims(seeded_state_dict(net, seed))  # box sizes of metres, not exp(150) m (see synth.tame_box_dims)
     net.load_state_dict(sd, strict=False)
     net = net.cuda().eval()
     onet = omodel.VoxelNet(cfg.model["reader"], cfg.model["backbone"], cfg.model["neck"], cfg.model["bbox_head"],
@@ -1028,7 +1028,12 @@ def _oracle_run(cfg, onet, cloud):
         feats = onet.reader(ex["voxels"], ex["num_points"])
         bb, _ = onet.backbone(feats, ex["coordinates"], 1, ex["shape"][0])
         bev = onet.neck(bb)
-        det = onet.bbox_head.predict(ex, onet.bbox_head(bev, None), cfg.test_cfg)[0]
+        preds = onet.bbox_head(bev, None)
+        det = onet.bbox_head.predict(ex, preds, cfg.test_cfg)[0]
+    # the nms_pre_max-th best candidate score (standard head: one heat-map shared by the steps), None when fewer cells qualify
+    sc = torch.sigmoid(preds[0]["hm"].float()).flatten()
+    k = int(cfg.test_cfg["nms"]["nms_pre_max_size"])
+    det["topk_cut"] = float(torch.topk(sc, k).values[-1]) if int((sc > cfg.test_cfg["score_threshold"]).sum()) > k else None
     return v, c, n, bb, bev, det
 
 
@@ -1093,7 +1098,7 @@ def test_full_size_config2_fp32_vs_oracle(hip):
     with torch.no_grad():
         for i in range(2):  # eager + graph replay
             got = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
-            _attribute("full size config 2 forward_points run %d" % i, _rows(got), _rows(want), cfg.test_cfg)
+            _attribute("full size config 2 forward_points run %d" % i, _rows(got), _rows(want), cfg.test_cfg, topk_cut=want["topk_cut"])
 
 
 def test_full_size_config3_bf16_vs_oracle(hip):
@@ -1171,7 +1176,7 @@ def test_full_size_config5_pedestrian_fine_grid_fp32_vs_oracle(hip):
         got = net.forward_points([_dev(cloud)], vg, padded=False)[0]
     for a, b in zip(*outs):
         assert torch.equal(a, b), "forward_points must be deterministic"
-    _attribute("full size config 5 forward_points", _rows(got), _rows(want), cfg.test_cfg)
+    _attribute("full size config 5 forward_points", _rows(got), _rows(want), cfg.test_cfg, topk_cut=want["topk_cut"])
 
 
 def test_two_ranks_on_one_gpu_equal_single_process(hip, tmp_path):
@@ -1212,7 +1217,7 @@ def test_weights_reload_invalidates_captured_graph(hip):
     """The neck+head hipGraph and the folded / packed weight caches must not survive a weight change: run (graph
     captured), load other weights, run again -- the result must match the oracle with the NEW weights and differ from the
     old result; then the same after an in-place update without load_state_dict (caches are keyed on parameter versions)."""
-    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims
 
     cfg, net, onet = _build_pair("forecast_n0", seed=7)
     cloud = synthetic_cloud(seed=1, target_points=20000)
@@ -1220,7 +1225,7 @@ def test_weights_reload_invalidates_captured_graph(hip):
         for _ in range(2):
             first = _rows(net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0])
     # other weights in every stage (a different seed saturates every score to 1.0, which leaves the NMS order undefined)
-    sd = seeded_state_dict(net, 7)
+    sd = tame_box_dims(seeded_state_dict(net, 7))
     for key, f in (("backbone.conv_input.0.weight", 0.8), ("neck.blocks.0.1.weight", 0.7), ("bbox_head.shared_conv.0.weight", 0.6),
                    ("bbox_head.tasks.0.hm.0.weight", 0.9)):
         sd[key] = sd[key] * f
