@@ -22,8 +22,9 @@
 //     slice's MFMAs run (double-buffered LDS);
 //   * output placement (y*osy+ooy, x*osx+oox, co_off + co) in a tensor with cout_total channels expresses the RPN's
 //     concat and the 2x2 stride-2 transposed convolution (four 1x1 convolutions writing interleaved pixels) in place.
-// The tile shape is chosen per layer (fd_conv2d_nhwc_f32 below): 180 x 180 maps take 12 x 12 tiles (225 workgroups for
-// 256 compute units, no padded pixel rows), 90 x 90 maps 5 x 15 tiles.
+// The tile shape is chosen per layer: `tile` = 0 lets a makespan estimate pick among the instantiated shapes (180 x 180
+// maps with 128 channels: 12 x 12 tiles = 225 workgroups for 256 compute units, no padded pixel rows); the host plan
+// (futuredet_amd/dense_bf16.py) instead times every shape once per layer and passes the winner.
 #include "fd_common.h"
 
 namespace {
@@ -217,7 +218,8 @@ void launch_f32(const float *x, const void *wp, const float *bias, float *y, Con
 struct TileChoice { int th, tw, nbw, wn; };
 constexpr TileChoice kTiles[] = {{12, 12, 2, 4}, {8, 16, 2, 4}, {5, 15, 2, 4}, {8, 8, 2, 4},   // 128 channels per workgroup
                                  {12, 12, 1, 4}, {8, 16, 1, 4}, {5, 15, 1, 4}, {8, 8, 1, 4},   // 64
-                                 {8, 16, 2, 1}, {8, 16, 1, 1}, {8, 8, 2, 1}, {8, 8, 1, 1}};    // 32 / 16: the final head convolutions
+                                 {8, 16, 2, 1}, {8, 16, 1, 1}, {8, 8, 2, 1}, {8, 8, 1, 1},     // 32 / 16: the final head convolutions
+                                 {8, 16, 2, 2}, {8, 16, 4, 2}, {8, 8, 2, 2}, {8, 8, 4, 2}};    // 2 x 2 wave grids: 64 / 128 channels
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 // makespan estimate in MFMA-block units (16 pixels x 16 channels x one 16-channel slice-tap) per SIMD: workgroups are dealt
@@ -231,15 +233,17 @@ inline double tile_cost(int Ho, int Wo, int B, int cout, const TileChoice &c, in
 }
 
 template <int KS, int S>
-int dispatch_tile(const float *x, const void *wp, const float *bias, float *y, const ConvParamsF &p, hipStream_t stream) {
+int dispatch_tile(const float *x, const void *wp, const float *bias, float *y, const ConvParamsF &p, int tile, hipStream_t stream) {
     const int n_cu = fd::device_cu_count();
     int best = -1;
     double bc = 1e30;
-    const int force = fd::tuning(fd::kTuneConvNT);  // tuning override: 1-based candidate index
-    for (int i = 0; i < kNumTiles; ++i) {
-        const double c = tile_cost(p.Ho, p.Wo, p.B, p.Cout_real, kTiles[i], n_cu);
-        if (force == i + 1) { best = i; break; }
-        if (c < bc) { bc = c; best = i; }
+    if (tile >= 1 && tile <= kNumTiles) {
+        best = tile - 1;  // the caller's choice (e.g. measured once per layer shape by the host plan)
+    } else {
+        for (int i = 0; i < kNumTiles; ++i) {
+            const double c = tile_cost(p.Ho, p.Wo, p.B, p.Cout_real, kTiles[i], n_cu);
+            if (c < bc) { bc = c; best = i; }
+        }
     }
     switch (best) {
         case 0: launch_f32<KS, S, 12, 12, 2, 4>(x, wp, bias, y, p, stream); break;
@@ -254,6 +258,10 @@ int dispatch_tile(const float *x, const void *wp, const float *bias, float *y, c
         case 9: launch_f32<KS, S, 8, 16, 1, 1>(x, wp, bias, y, p, stream); break;
         case 10: launch_f32<KS, S, 8, 8, 2, 1>(x, wp, bias, y, p, stream); break;
         case 11: launch_f32<KS, S, 8, 8, 1, 1>(x, wp, bias, y, p, stream); break;
+        case 12: launch_f32<KS, S, 8, 16, 2, 2>(x, wp, bias, y, p, stream); break;
+        case 13: launch_f32<KS, S, 8, 16, 4, 2>(x, wp, bias, y, p, stream); break;
+        case 14: launch_f32<KS, S, 8, 8, 2, 2>(x, wp, bias, y, p, stream); break;
+        case 15: launch_f32<KS, S, 8, 8, 4, 2>(x, wp, bias, y, p, stream); break;
         default: return 0;
     }
     return 1;
@@ -287,14 +295,17 @@ extern "C" int fd_conv2d_f32_pack_weight(const float *w, int cout, int cin, int 
     return FD_OK;
 }
 
+extern "C" int fd_conv2d_f32_num_tiles(void) { return kNumTiles; }
+
 extern "C" int fd_conv2d_nhwc_f32(const float *x, int B, int H, int W, int cin, const void *wpacked, const float *bias, int cout, int ks,
                                   int stride, int pad, int relu, float *y, int cout_total, int co_off, int osy, int osx, int ooy, int oox,
-                                  fd_stream_t stream) {
+                                  int tile, fd_stream_t stream) {
     FD_REQUIRE(x && wpacked && y, "fd_conv2d_nhwc_f32: null argument");
     FD_REQUIRE(cin % 16 == 0 && cin >= 16, "fd_conv2d_nhwc_f32: cin must be a multiple of 16 (got %d)", cin);
     FD_REQUIRE((ks == 3 && (stride == 1 || stride == 2) && pad == 1) || (ks == 1 && stride == 1 && pad == 0),
                "fd_conv2d_nhwc_f32: supported: 3x3 stride 1|2 pad 1, 1x1 stride 1 pad 0");
     FD_REQUIRE(B > 0 && H > 0 && W > 0 && cout > 0 && osy >= 1 && osx >= 1, "fd_conv2d_nhwc_f32: bad shape");
+    FD_REQUIRE(tile >= 0 && tile <= kNumTiles, "fd_conv2d_nhwc_f32: tile must be 0 (library heuristic) or 1..%d", kNumTiles);
     ConvParamsF p;
     p.B = B; p.H = H; p.W = W; p.Cin = cin;
     p.Ho = (H + 2 * pad - ks) / stride + 1;
@@ -306,9 +317,9 @@ extern "C" int fd_conv2d_nhwc_f32(const float *x, int B, int H, int W, int cin, 
     p.tiles_x = p.tiles_y = 0;
     hipStream_t s = fd::as_stream(stream);
     int ok;
-    if (ks == 3 && stride == 1) ok = dispatch_tile<3, 1>(x, wpacked, bias, y, p, s);
-    else if (ks == 3) ok = dispatch_tile<3, 2>(x, wpacked, bias, y, p, s);
-    else ok = dispatch_tile<1, 1>(x, wpacked, bias, y, p, s);
+    if (ks == 3 && stride == 1) ok = dispatch_tile<3, 1>(x, wpacked, bias, y, p, tile, s);
+    else if (ks == 3) ok = dispatch_tile<3, 2>(x, wpacked, bias, y, p, tile, s);
+    else ok = dispatch_tile<1, 1>(x, wpacked, bias, y, p, tile, s);
     FD_REQUIRE(ok, "fd_conv2d_nhwc_f32: no tile shape for cout %d", cout);
     return fd::check_launch("fd_conv2d_nhwc_f32");
 }

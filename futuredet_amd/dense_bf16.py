@@ -6,11 +6,16 @@ Activations are NHWC tensors of the plan's dtype; BatchNorm is folded; the RPN c
 of a SepHead run as one 64->384 convolution followed by one block-diagonal 384->(9+2T) convolution.
 Built lazily from the torch modules (so state_dict loading is unchanged) and cached until the next load.
 """
+import os
+
 import torch
 from torch import nn
 
 from . import hip_ops
 from .nn_utils import fold_stack
+
+
+USE_WINOGRAD = not os.environ.get("FD_NO_WINOGRAD")  # A/B switch: fp32 3x3 layers on the direct kernel only
 
 
 def granule(dtype):
@@ -27,8 +32,53 @@ class _Conv(object):
         self.wpk = hip_ops.pack_conv2d_weight(w_oihw) if dtype == torch.bfloat16 else hip_ops.pack_conv2d_weight_f32(w_oihw)
         self.bias = bias.float().contiguous() if bias is not None else None
         self.fn = hip_ops.conv2d_nhwc_bf16 if dtype == torch.bfloat16 else hip_ops.conv2d_nhwc_f32
+        # fp32 3x3 stride 1: the Winograd F(2x2,3x3) kernel is the second formulation; its transformed weights are packed too
+        self.wino = (dtype == torch.float32 and self.ks == 3 and stride == 1 and USE_WINOGRAD)
+        self.wpk_wino = hip_ops.pack_conv2d_weight_wino(w_oihw) if self.wino else None
+        self.choice = {}  # fp32: input shape -> measured-best (formulation, workgroup tile)
+
+    def _run(self, choice, x, out, co_off, kw):
+        kind, tile = choice
+        if kind == "wino":
+            return hip_ops.conv2d_wino_nhwc_f32(x, self.wpk_wino, self.bias, self.cout, self.relu, out=out, co_off=co_off, tile=tile)
+        return self.fn(x, self.wpk, self.bias, self.cout, self.ks, self.stride, self.relu, out=out, co_off=co_off, tile=tile, **kw)
+
+    def _pick(self, x, out, co_off, kw):
+        """fp32 only: times every formulation / tile shape once for this layer and input shape (eager calls only -- during a
+        graph capture the defaults are used) and remembers the fastest.  A few milliseconds per layer, once."""
+        key = tuple(x.shape)
+        c = self.choice.get(key)
+        if c is not None:
+            return c
+        default = ("wino", 0) if (self.wino and not kw) else ("direct", 0)
+        if torch.cuda.is_current_stream_capturing():
+            return default
+        if out is None:
+            out = self._run(default, x, None, co_off, kw)
+        cands = [("direct", t) for t in range(0, hip_ops.conv2d_f32_num_tiles() + 1)]
+        if self.wino and not kw:  # (the Winograd entry point has no pixel-stride placement; 3x3 layers never need it)
+            cands += [("wino", t) for t in range(1, hip_ops.conv2d_wino_f32_num_tiles() + 1)]
+        best, best_ms = default, float("inf")
+        for cand in cands:
+            try:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self._run(cand, x, out, co_off, kw)
+                e0.record()
+                for _ in range(3):
+                    self._run(cand, x, out, co_off, kw)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+            except hip_ops.FutureDetHipError:
+                continue
+            if ms < best_ms * 0.98:  # ties go to the earlier candidate
+                best, best_ms = cand, ms
+        self.choice[key] = best
+        return best
 
     def __call__(self, x, out=None, co_off=0, **kw):
+        if self.dtype == torch.float32:
+            return self._run(self._pick(x, out, co_off, kw), x, out, co_off, kw)
         return self.fn(x, self.wpk, self.bias, self.cout, self.ks, self.stride, self.relu, out=out, co_off=co_off, **kw)
 
 

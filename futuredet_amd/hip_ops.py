@@ -373,8 +373,9 @@ def pack_conv2d_weight_f32(w_oihw):
     return host.to(dev)
 
 
-def conv2d_nhwc_f32(x, wpk, bias, cout, ks, stride=1, relu=True, out=None, co_off=0, osy=1, osx=1, ooy=0, oox=0):
-    """x [B,H,W,Cin] float32 contiguous -> y [B,Ho*osy,Wo*osx,Ctot] float32 (allocated when ``out`` is None)."""
+def conv2d_nhwc_f32(x, wpk, bias, cout, ks, stride=1, relu=True, out=None, co_off=0, osy=1, osx=1, ooy=0, oox=0, tile=0):
+    """x [B,H,W,Cin] float32 contiguous -> y [B,Ho*osy,Wo*osx,Ctot] float32 (allocated when ``out`` is None).
+    ``tile``: 0 = the library's heuristic, 1..conv2d_f32_num_tiles() = that workgroup tile shape."""
     L = _lib.load()
     x = _dev(x, "x", torch.float32)
     B, H, W, cin = x.shape
@@ -384,8 +385,44 @@ def conv2d_nhwc_f32(x, wpk, bias, cout, ks, stride=1, relu=True, out=None, co_of
         out = torch.empty((B, Ho * osy, Wo * osx, cout), dtype=torch.float32, device=x.device)
     _dev(out, "out", torch.float32)
     check(L.fd_conv2d_nhwc_f32(_p(x), B, H, W, cin, _p(wpk), _p(bias), cout, ks, stride, pad, int(bool(relu)), _p(out),
-                               out.shape[3], co_off, osy, osx, ooy, oox, _stream()), "fd_conv2d_nhwc_f32")
+                               out.shape[3], co_off, osy, osx, ooy, oox, int(tile), _stream()), "fd_conv2d_nhwc_f32")
     return out
+
+
+def conv2d_f32_num_tiles():
+    return int(_lib.load().fd_conv2d_f32_num_tiles())
+
+
+def pack_conv2d_weight_wino(w_oihw):
+    """[Cout, Cin, 3, 3] float32 -> Winograd-transformed (G g G^T), fragment-ordered fp32 weights on the same device."""
+    L = _lib.load()
+    dev = w_oihw.device
+    w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+    cout, cin, ks, _ = w.shape
+    nbytes = L.fd_conv2d_wino_f32_packed_weight_bytes(cout, cin) if ks == 3 else 0
+    if nbytes == 0:
+        raise FutureDetHipError("fd_conv2d_wino_f32: unsupported weight shape %s" % (tuple(w.shape),))
+    host = torch.empty((nbytes,), dtype=torch.uint8)
+    check(L.fd_conv2d_wino_f32_pack_weight(ctypes.c_void_p(w.data_ptr()), cout, cin, ctypes.c_void_p(host.data_ptr())),
+          "fd_conv2d_wino_f32_pack_weight")
+    return host.to(dev)
+
+
+def conv2d_wino_nhwc_f32(x, wpk, bias, cout, relu=True, out=None, co_off=0, tile=0):
+    """3x3 stride-1 pad-1 convolution by Winograd F(2x2,3x3) on MFMA: x [B,H,W,Cin] float32 -> [B,H,W,Ctot] float32."""
+    L = _lib.load()
+    x = _dev(x, "x", torch.float32)
+    B, H, W, cin = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    _dev(out, "out", torch.float32)
+    check(L.fd_conv2d_wino_nhwc_f32(_p(x), B, H, W, cin, _p(wpk), _p(bias), cout, int(bool(relu)), _p(out), out.shape[3], co_off, int(tile),
+                                    _stream()), "fd_conv2d_wino_nhwc_f32")
+    return out
+
+
+def conv2d_wino_f32_num_tiles():
+    return int(_lib.load().fd_conv2d_wino_f32_num_tiles())
 
 
 # ------------------------------------------------------------------------------------------------ decode / NMS

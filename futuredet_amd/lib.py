@@ -63,8 +63,14 @@ SIGNATURES = {
                                     c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fd_conv2d_f32_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fd_conv2d_f32_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fd_conv2d_f32_num_tiles": (c_int, []),
     "fd_conv2d_nhwc_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                   c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                   c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fd_conv2d_wino_f32_num_tiles": (c_int, []),
+    "fd_conv2d_wino_f32_packed_weight_bytes": (c_size_t, [c_int, c_int]),
+    "fd_conv2d_wino_f32_pack_weight": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "fd_conv2d_wino_nhwc_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                        c_void_p]),
     "fd_decode_workspace_bytes": (c_size_t, [c_int, ctypes.POINTER(DecodeCfg)]),
     "fd_centerpoint_decode": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
                                       c_int, ctypes.POINTER(DecodeCfg), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

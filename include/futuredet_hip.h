@@ -158,9 +158,18 @@ int fd_conv2d_nhwc_bf16(const void *x, int B, int H, int W, int cin, const void 
  * det3d/models/bbox_heads/center_head.py:129-143,344-349).  cin must be a multiple of 16; same placement arguments. */
 size_t fd_conv2d_f32_packed_weight_bytes(int cout, int cin, int ks);
 int fd_conv2d_f32_pack_weight(const float *w_oihw_host, int cout, int cin, int ks, void *wpacked_host);
+int fd_conv2d_f32_num_tiles(void); /* number of workgroup tile shapes instantiated (valid `tile` values are 1..n) */
 int fd_conv2d_nhwc_f32(const float *x, int B, int H, int W, int cin, const void *wpacked, const float *bias, int cout, int ks,
                        int stride, int pad, int relu, float *y, int cout_total, int co_off, int osy, int osx, int ooy, int oox,
-                       fd_stream_t stream);
+                       int tile /* 0 = library heuristic, else 1..fd_conv2d_f32_num_tiles() */, fd_stream_t stream);
+/* 3x3 stride-1 pad-1 only: Winograd F(2x2,3x3) with the 16 element-wise products as MFMA GEMMs over the input channels
+ * (2.25x fewer multiplies than the direct form).  Weights are transformed (U = G g G^T) and packed by
+ * fd_conv2d_wino_f32_pack_weight; cin must be a multiple of 16; output placement: channel offset only. */
+int fd_conv2d_wino_f32_num_tiles(void);
+size_t fd_conv2d_wino_f32_packed_weight_bytes(int cout, int cin);
+int fd_conv2d_wino_f32_pack_weight(const float *w_oihw_host, int cout, int cin, void *wpacked_host);
+int fd_conv2d_wino_nhwc_f32(const float *x, int B, int H, int W, int cin, const void *wpacked, const float *bias, int cout, int relu,
+                            float *y, int cout_total, int co_off, int tile /* 0 = default, else 1..num_tiles */, fd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * CenterPoint decode + rotated NMS.  Replaces CenterHead.predict's per-step decode

@@ -491,14 +491,15 @@ def test_conv2d_nhwc_bf16_vs_torch(hip, cfg):
 
 F32_CONV_CASES = [(3, 1, 64, 128, 37, 45, 0), (3, 2, 32, 128, 40, 33, 0), (3, 1, 128, 64, 20, 20, 0), (3, 1, 96, 11, 19, 35, 0),
                   (1, 1, 128, 256, 23, 18, 0), (3, 1, 256, 256, 16, 16, 0), (3, 1, 384, 23, 30, 26, 0)] + \
-                 [(3, 1, 48, 70, 29, 31, k) for k in range(1, 13)] + [(3, 2, 16, 130, 33, 27, k) for k in (1, 3, 9, 12)]
+                 [(3, 1, 48, 70, 29, 31, k) for k in range(1, 17)] + [(3, 2, 16, 130, 33, 27, k) for k in (1, 3, 9, 12, 14)] + \
+                 [(1, 1, 80, 40, 21, 22, k) for k in (2, 10, 13)]
 
 
 @pytest.mark.parametrize("cfg", F32_CONV_CASES, ids=lambda c: "k%ds%d_%d-%d_%dx%d_t%d" % c)
 def test_conv2d_nhwc_f32_vs_torch(hip, cfg):
     """Hand-written fp32 MFMA conv vs torch conv2d in float64 on the host: partial tiles, stride 2, 1x1, Cout that is not
-    a multiple of 16 / 64, channel-offset (concat) writes, every tile shape of the dispatcher (conv_nt = 1..12 forces one;
-    0 = the heuristic).  fp32 FMA chains of <= 9 * 384 terms: |d| <= 1e-4 * max(1, |ref|)."""
+    a multiple of 16 / 64, channel-offset (concat) writes, every tile shape of the dispatcher (tile = 1..16 selects one;
+    0 = the library heuristic).  fp32 FMA chains of <= 9 * 384 terms: |d| <= 1e-4 * max(1, |ref|)."""
     ks, stride, cin, cout, H, W, tile = cfg
     rng = np.random.default_rng(cin + cout + H + tile)
     x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32))
@@ -508,13 +509,31 @@ def test_conv2d_nhwc_f32_vs_torch(hip, cfg):
     wpk = hip.pack_conv2d_weight_f32(w).cuda()
     xn = x.cuda().permute(0, 2, 3, 1).contiguous()
     out = torch.full((2, ref.shape[2], ref.shape[3], cout + 5), 7.0, dtype=torch.float32, device="cuda")
-    try:
-        hip.set_tuning("conv_nt", tile)
-        hip.conv2d_nhwc_f32(xn, wpk, b.cuda(), cout, ks, stride, True, out=out, co_off=3)
-    finally:
-        hip.set_tuning("conv_nt", 0)
+    assert hip.conv2d_f32_num_tiles() == 16
+    hip.conv2d_nhwc_f32(xn, wpk, b.cuda(), cout, ks, stride, True, out=out, co_off=3, tile=tile)
     got = out[..., 3:3 + cout].permute(0, 3, 1, 2).cpu()
     assert_close("conv2d_nhwc_f32 k%d s%d %d->%d %dx%d tile %d" % cfg, got.numpy(), ref.numpy(), 1e-4)
+    assert bool((out[..., :3] == 7).all()) and bool((out[..., 3 + cout:] == 7).all()), "writes outside the channel window"
+
+
+@pytest.mark.parametrize("cfg", [(64, 128, 37, 45, 1), (128, 128, 20, 20, 2), (96, 11, 19, 35, 3), (256, 256, 16, 16, 4), (48, 70, 29, 31, 0),
+                                 (16, 384, 8, 50, 1), (32, 64, 33, 6, 4), (128, 128, 21, 20, 5), (64, 70, 18, 23, 6)], ids=lambda c: "%d-%d_%dx%d_t%d" % c)
+def test_conv2d_wino_f32_vs_torch(hip, cfg):
+    """Winograd F(2x2,3x3) on MFMA vs torch conv2d in float64: odd sizes (partial 2x2 tiles and partial workgroup tiles), Cout
+    not a multiple of 16 / 64, channel-offset writes, every workgroup tile.  The transforms add a few roundings to an fp32
+    chain of <= 256 terms per product: |d| <= 2e-4 * max(1, |ref|)."""
+    cin, cout, H, W, tile = cfg
+    rng = np.random.default_rng(cin + cout + H + tile)
+    x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((cout, cin, 3, 3)) * (2.0 / (cin * 9)) ** 0.5).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
+    wpk = hip.pack_conv2d_weight_wino(w).cuda()
+    xn = x.cuda().permute(0, 2, 3, 1).contiguous()
+    out = torch.full((2, H, W, cout + 5), 7.0, dtype=torch.float32, device="cuda")
+    hip.conv2d_wino_nhwc_f32(xn, wpk, b.cuda(), cout, True, out=out, co_off=3, tile=tile)
+    got = out[..., 3:3 + cout].permute(0, 3, 1, 2).cpu()
+    assert_close("conv2d_wino_f32 %d->%d %dx%d tile %d" % cfg, got.numpy(), ref.numpy(), 2e-4)
     assert bool((out[..., :3] == 7).all()) and bool((out[..., 3 + cout:] == 7).all()), "writes outside the channel window"
 
 
@@ -968,6 +987,8 @@ def test_c_abi_reports_errors_instead_of_exiting(hip):
         ("fd_rotated_nms", lambda: L.fd_rotated_nms(None, 10, ctypes.c_float(0.2), None, None, None, 0, None)),
         ("fd_conv2d_nhwc_bf16", lambda: L.fd_conv2d_nhwc_bf16(x.data_ptr(), 1, 8, 8, 7, x.data_ptr(), None, 16, 3, 1, 1, 1, x.data_ptr(), 16, 0, 1, 1,
                                                              0, 0, None)),
+        ("fd_conv2d_nhwc_f32", lambda: L.fd_conv2d_nhwc_f32(x.data_ptr(), 1, 8, 8, 16, x.data_ptr(), None, 16, 3, 1, 1, 1, x.data_ptr(), 16, 0, 1, 1,
+                                                            0, 0, 99, None)),
         ("fd_sweep_assemble", lambda: L.fd_sweep_assemble(x.data_ptr(), 5, 9, 10, x.data_ptr(), 1, ctypes.c_float(1.0), x.data_ptr(), x.data_ptr(),
                                                          None, 0, None)),
         ("fd_pillar_encode", lambda: L.fd_pillar_encode(x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 4, 99, 5, 0, ctypes.c_float(1), ctypes.c_float(1),

@@ -46,8 +46,11 @@ for name, cin, cout, hw, ks, st in LAYERS:
     wpk = hip_ops.pack_conv2d_weight_f32(w.cpu()).cuda()
     out = torch.empty((1, ho, ho, cout), device="cuda")
     for t in [int(v) for v in args.tiles.split(",")]:
-        hip_ops.set_tuning("conv_nt", t)
-        us = timeit(lambda: hip_ops.conv2d_nhwc_f32(xn, wpk, b, cout, ks, st, True, out=out), args.iters)
+        us = timeit(lambda: hip_ops.conv2d_nhwc_f32(xn, wpk, b, cout, ks, st, True, out=out, tile=t), args.iters)
         line += " | t%d %7.1f us %6.1f TF" % (t, us, fl / us / 1e6)
-    hip_ops.set_tuning("conv_nt", 0)
+    if ks == 3 and st == 1:
+        wpw = hip_ops.pack_conv2d_weight_wino(w.cpu()).cuda()
+        for t in range(1, hip_ops.conv2d_wino_f32_num_tiles() + 1):
+            us = timeit(lambda: hip_ops.conv2d_wino_nhwc_f32(xn, wpw, b, cout, True, out=out, tile=t), args.iters)
+            line += " | w%d %7.1f us %6.1f TF" % (t, us, fl / us / 1e6)
     print(line, flush=True)
