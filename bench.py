@@ -51,7 +51,7 @@ PRESETS = {  # BASELINE.json configs[1..4]
     2: dict(variant="forecast_n0", dtype="fp32", points=300000, batch=1),
     3: dict(variant="forecast_n3", dtype="bf16", points=300000, batch=1),
     4: dict(variant="forecast_n3", dtype="bf16", points=300000, batch=8, global_batch=64),
-    5: dict(variant="forecast_n3", dtype="fp32", points=500000, batch=1, class_name="pedestrian", voxel_xy=0.05, max_voxels=400000),
+    5: dict(variant="forecast_n3", dtype="bf16", points=500000, batch=1, class_name="pedestrian", voxel_xy=0.05, max_voxels=400000),
 }
 
 

@@ -1198,6 +1198,13 @@ def test_full_size_config5_pedestrian_fine_grid_fp32_vs_oracle(hip):
     for a, b in zip(*outs):
         assert torch.equal(a, b), "forward_points must be deterministic"
     _attribute("full size config 5 forward_points", _rows(got), _rows(want), cfg.test_cfg, topk_cut=want["topk_cut"])
+    # BASELINE.md runs this config in bf16 (conv features / weights, fp32 accumulate): same cloud against the fp32 oracle
+    net.set_precision(torch.bfloat16)
+    with torch.no_grad():
+        for _ in range(2):
+            got16 = net.forward_points([_dev(cloud)], vg, padded=False)[0]
+    _, x16 = _hip_maps(net, cfg, v, c, n)
+    _check_bf16_vs_fp32_oracle("full size config 5 (ped n3 500k, 0.05 m)", got16, x16, want, obev)
 
 
 def test_two_ranks_on_one_gpu_equal_single_process(hip, tmp_path):
