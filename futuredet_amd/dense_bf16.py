@@ -82,6 +82,16 @@ class _Conv(object):
         return self.fn(x, self.wpk, self.bias, self.cout, self.ks, self.stride, self.relu, out=out, co_off=co_off, **kw)
 
 
+class _GroupedConv(object):
+    """fd_conv2d_grouped_nhwc_f32: the final 3x3 convolutions of a SepHead's branches in one launch (fp32)."""
+
+    def __init__(self, wpk, bias, counts, cin_g):
+        self.wpk, self.bias, self.counts, self.cin_g = wpk, bias, counts, cin_g
+
+    def __call__(self, x):
+        return hip_ops.conv2d_grouped_nhwc_f32(x, self.wpk, self.bias, self.counts, self.cin_g, relu=False)
+
+
 def _convs_from_stack(modules, dtype):
     out = []
     for f in fold_stack(modules, torch.float32, False):
@@ -104,6 +114,11 @@ class RPNPlan(object):
             if f.transposed:  # ConvTranspose2d(k = s): weight [Cin, Cout, k, k] -> k*k 1x1 convs on interleaved pixels
                 k = f.weight.shape[-1]
                 assert f.stride == k and f.padding == 0
+                if dtype == torch.float32 and f.weight.shape[1] % 4 == 0 and f.weight.shape[0] % 16 == 0:
+                    # one 1x1 convolution to (dy, dx, co) virtual channels + pixel-shuffle epilogue
+                    w = f.weight.permute(2, 3, 1, 0).reshape(-1, f.weight.shape[0])[:, :, None, None].contiguous()
+                    self.deblocks.append(("shuffle", k, (hip_ops.pack_conv2d_weight_f32(w), f.bias.float().contiguous(), f.relu), f.weight.shape[1]))
+                    continue
                 subs = [(_Conv(f.weight[:, :, dy, dx].t().contiguous()[:, :, None, None], f.bias, 1, f.relu, dtype), dy, dx)
                         for dy in range(k) for dx in range(k)]
                 self.deblocks.append(("up", k, subs, f.weight.shape[1]))
@@ -134,6 +149,8 @@ class RPNPlan(object):
                 assert ups.shape[1] == Ho and ups.shape[2] == Wo
                 if kind == "conv":
                     op(x, out=ups, co_off=co)
+                elif kind == "shuffle":
+                    hip_ops.conv2d_shuffle_nhwc_f32(x, op[0], op[1], cout, k, op[2], out=ups, co_off=co)
                 elif kind == "down":
                     xs = x.view(B, Ho, k, Wo, k, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Ho, Wo, k * k * C)
                     op(xs, out=ups, co_off=co)
@@ -183,7 +200,17 @@ class HeadPlan(object):
                 w2[o:o + couts[i], i * hc:(i + 1) * hc] = f.weight
                 o += couts[i]
             b2 = torch.cat([f.bias for f in finals], 0)
-            self.tasks.append((_Conv(w1, b1, 1, True, dtype), _Conv(w2, b2, 1, False, dtype), names, couts))
+            if dtype == torch.float32 and len(names) <= 8 and max(couts) <= 16 and hc % 16 == 0 and finals[0].weight.shape[-1] == 3:
+                # the branches' final 3x3 convs as ONE grouped launch (each branch reads only its own hc channels)
+                wg = torch.zeros((16 * len(names), hc, 3, 3), dtype=torch.float32, device=w1.device)
+                bg = torch.zeros((16 * len(names),), dtype=torch.float32, device=w1.device)
+                for i, f in enumerate(finals):
+                    wg[16 * i:16 * i + couts[i]] = f.weight
+                    bg[16 * i:16 * i + couts[i]] = f.bias
+                c2 = _GroupedConv(hip_ops.pack_conv2d_weight_f32(wg), bg.contiguous(), list(couts), hc)
+            else:
+                c2 = _Conv(w2, b2, 1, False, dtype)
+            self.tasks.append((_Conv(w1, b1, 1, True, dtype), c2, names, couts))
 
     def __call__(self, x):  # x [B,H,W,C] of the plan's dtype -> list of dicts of NCHW float32 tensors
         for conv in self.shared[:-1]:

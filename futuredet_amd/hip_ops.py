@@ -393,6 +393,34 @@ def conv2d_f32_num_tiles():
     return int(_lib.load().fd_conv2d_f32_num_tiles())
 
 
+def conv2d_shuffle_nhwc_f32(x, wpk, bias, cout_sub, k, relu=True, out=None, co_off=0, tile=0):
+    """ConvTranspose2d(k, stride k) as one 1x1 convolution + pixel shuffle: x [B,H,W,Cin] -> [B,H*k,W*k,Ctot] float32."""
+    L = _lib.load()
+    x = _dev(x, "x", torch.float32)
+    B, H, W, cin = x.shape
+    if out is None:
+        out = torch.empty((B, H * k, W * k, cout_sub), dtype=torch.float32, device=x.device)
+    _dev(out, "out", torch.float32)
+    check(L.fd_conv2d_shuffle_nhwc_f32(_p(x), B, H, W, cin, _p(wpk), _p(bias), int(cout_sub), int(k), int(bool(relu)), _p(out), out.shape[3],
+                                       co_off, int(tile), _stream()), "fd_conv2d_shuffle_nhwc_f32")
+    return out
+
+
+def conv2d_grouped_nhwc_f32(x, wpk, bias, counts, cin_g, relu=False, out=None, co_off=0, tile=0):
+    """Grouped 3x3 convolution (<= 16 outputs per group): x [B,H,W,groups*cin_g] -> [B,H,W,sum(counts)] float32."""
+    L = _lib.load()
+    x = _dev(x, "x", torch.float32)
+    B, H, W, cin = x.shape
+    groups = len(counts)
+    assert cin == groups * cin_g
+    if out is None:
+        out = torch.empty((B, H, W, int(sum(counts))), dtype=torch.float32, device=x.device)
+    _dev(out, "out", torch.float32)
+    check(L.fd_conv2d_grouped_nhwc_f32(_p(x), B, H, W, groups, int(cin_g), _p(wpk), _p(bias), (ctypes.c_int * groups)(*[int(c) for c in counts]),
+                                       int(bool(relu)), _p(out), out.shape[3], co_off, int(tile), _stream()), "fd_conv2d_grouped_nhwc_f32")
+    return out
+
+
 def pack_conv2d_weight_wino(w_oihw):
     """[Cout, Cin, 3, 3] float32 -> Winograd-transformed (G g G^T), fragment-ordered fp32 weights on the same device."""
     L = _lib.load()

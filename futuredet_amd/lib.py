@@ -66,6 +66,10 @@ SIGNATURES = {
     "fd_conv2d_f32_num_tiles": (c_int, []),
     "fd_conv2d_nhwc_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fd_conv2d_shuffle_nhwc_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                           c_void_p]),
+    "fd_conv2d_grouped_nhwc_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                           c_int, c_void_p]),
     "fd_conv2d_wino_f32_num_tiles": (c_int, []),
     "fd_conv2d_wino_f32_packed_weight_bytes": (c_size_t, [c_int, c_int]),
     "fd_conv2d_wino_f32_pack_weight": (c_int, [c_void_p, c_int, c_int, c_void_p]),

@@ -162,6 +162,17 @@ int fd_conv2d_f32_num_tiles(void); /* number of workgroup tile shapes instantiat
 int fd_conv2d_nhwc_f32(const float *x, int B, int H, int W, int cin, const void *wpacked, const float *bias, int cout, int ks,
                        int stride, int pad, int relu, float *y, int cout_total, int co_off, int osy, int osx, int ooy, int oox,
                        int tile /* 0 = library heuristic, else 1..fd_conv2d_f32_num_tiles() */, fd_stream_t stream);
+/* ConvTranspose2d(k, stride k) -- the RPN's upsampling deblock (det3d/models/necks/rpn.py:98-110) -- as ONE 1x1 convolution to
+ * k*k*cout_sub virtual channels with a pixel-shuffle epilogue.  Weights: fd_conv2d_f32_pack_weight of [(dy,dx,co), cin, 1, 1];
+ * bias [cout_sub]; y [B, H*k, W*k, cout_total]. */
+int fd_conv2d_shuffle_nhwc_f32(const float *x, int B, int H, int W, int cin, const void *wpacked, const float *bias, int cout_sub, int k,
+                               int relu, float *y, int cout_total, int co_off, int tile, fd_stream_t stream);
+/* Grouped 3x3 stride-1 pad-1 convolution, <= 16 outputs per group: the final convolutions of the six CenterHead branches
+ * (det3d/models/bbox_heads/center_head.py:129-143) in one launch.  x [B,H,W,groups*cin_g]; weights: fd_conv2d_f32_pack_weight of
+ * [groups*16, cin_g, 3, 3] (each group padded to 16 outputs); bias [groups*16]; counts_host[g] = real outputs of group g,
+ * written back to back from channel co_off of y. */
+int fd_conv2d_grouped_nhwc_f32(const float *x, int B, int H, int W, int groups, int cin_g, const void *wpacked, const float *bias,
+                               const int *counts_host, int relu, float *y, int cout_total, int co_off, int tile, fd_stream_t stream);
 /* 3x3 stride-1 pad-1 only: Winograd F(2x2,3x3) with the 16 element-wise products as MFMA GEMMs over the input channels
  * (2.25x fewer multiplies than the direct form).  Weights are transformed (U = G g G^T) and packed by
  * fd_conv2d_wino_f32_pack_weight; cin must be a multiple of 16; output placement: channel offset only. */

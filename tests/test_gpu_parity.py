@@ -537,6 +537,38 @@ def test_conv2d_wino_f32_vs_torch(hip, cfg):
     assert bool((out[..., :3] == 7).all()) and bool((out[..., 3 + cout:] == 7).all()), "writes outside the channel window"
 
 
+def test_conv2d_shuffle_and_grouped_f32_vs_torch(hip):
+    """fd_conv2d_shuffle_nhwc_f32 (ConvTranspose2d(k, stride k) as one 1x1 conv + pixel shuffle, into a channel slice) and
+    fd_conv2d_grouped_nhwc_f32 (the CenterHead branches' final convs in one launch) vs torch in float64, 1e-4 element-wise."""
+    rng = np.random.default_rng(11)
+    for (cin, cout, k, H, W) in ((64, 32, 2, 13, 21), (32, 20, 3, 9, 7)):
+        x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32))
+        w = torch.from_numpy((rng.standard_normal((cin, cout, k, k)) * 0.1).astype(np.float32))
+        b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+        ref = torch.relu(torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=k)).float()
+        wv = w.permute(2, 3, 1, 0).reshape(-1, cin)[:, :, None, None].contiguous()
+        out = torch.full((2, H * k, W * k, cout + 8), 7.0, device="cuda")
+        hip.conv2d_shuffle_nhwc_f32(x.cuda().permute(0, 2, 3, 1).contiguous(), hip.pack_conv2d_weight_f32(wv).cuda(), b.cuda(), cout, k, True,
+                                    out=out, co_off=4)
+        assert_close("conv2d_shuffle_f32 %d->%d k%d" % (cin, cout, k), out[..., 4:4 + cout].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), 1e-4)
+        assert bool((out[..., :4] == 7).all()) and bool((out[..., 4 + cout:] == 7).all())
+    counts, cin_g = [2, 1, 3, 2, 14, 1], 64
+    H, W = 19, 27
+    x = torch.from_numpy(rng.standard_normal((2, cin_g * len(counts), H, W)).astype(np.float32))
+    ws = [torch.from_numpy((rng.standard_normal((c, cin_g, 3, 3)) * 0.05).astype(np.float32)) for c in counts]
+    bs = [torch.from_numpy(rng.standard_normal(c).astype(np.float32)) for c in counts]
+    ref = torch.cat([torch.nn.functional.conv2d(x[:, g * cin_g:(g + 1) * cin_g].double(), ws[g].double(), bs[g].double(), padding=1)
+                     for g in range(len(counts))], 1).float()
+    wg = torch.zeros((16 * len(counts), cin_g, 3, 3))
+    bg = torch.zeros((16 * len(counts),))
+    for g, c in enumerate(counts):
+        wg[16 * g:16 * g + c], bg[16 * g:16 * g + c] = ws[g], bs[g]
+    for tile in (0, 12):
+        out = hip.conv2d_grouped_nhwc_f32(x.cuda().permute(0, 2, 3, 1).contiguous(), hip.pack_conv2d_weight_f32(wg).cuda(), bg.cuda(), counts, cin_g, tile=tile)
+        assert tuple(out.shape) == (2, H, W, sum(counts))
+        assert_close("conv2d_grouped_f32 6 x 64 -> %s tile %d" % (counts, tile), out.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), 1e-4)
+
+
 def test_dense_f32_plan_vs_torch_modules(hip):
     """RPN + CenterHead (n3: 7-timestep head) on the fp32 MFMA plan (concat in place, transposed conv as 4 interleaved
     1x1, fused heads) vs the plain fp32 torch modules (MIOpen): |d| <= 1e-3 * max(1, |ref|) per element."""

@@ -312,7 +312,7 @@ def test_hip_ops_exposes_every_wrapper():
     from futuredet_amd import hip_ops
 
     for name in ("voxelize", "SparseIndex", "build_pyramid", "ranges_for", "rows_permute", "pack_spconv_weight", "spconv_apply",
-                 "densify", "pack_conv2d_weight", "conv2d_nhwc_bf16", "pack_conv2d_weight_f32", "conv2d_nhwc_f32", "pack_conv2d_weight_wino", "conv2d_wino_nhwc_f32", "make_decode_cfg", "centerpoint_decode", "rotated_nms",
+                 "densify", "pack_conv2d_weight", "conv2d_nhwc_bf16", "pack_conv2d_weight_f32", "conv2d_nhwc_f32", "pack_conv2d_weight_wino", "conv2d_wino_nhwc_f32", "conv2d_shuffle_nhwc_f32", "conv2d_grouped_nhwc_f32", "make_decode_cfg", "centerpoint_decode", "rotated_nms",
                  "boxes_iou_bev", "sweep_descriptors", "assemble_sweeps", "pillar_encode", "pillar_scatter", "bias_act_nchw_",
                  "shuffle_bias_act", "forecast_chains", "det_to_global_boxes", "forecast_groups", "set_tuning"):
         assert hasattr(hip_ops, name), name

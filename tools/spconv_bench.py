@@ -19,6 +19,8 @@ ap.add_argument("--points", type=int, default=300000)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--modes", default="tiles,uniform,balanced")
 ap.add_argument("--rpc", default="0")
+ap.add_argument("--tm", type=int, default=0, help="chunk rows override (64 | 128)")
+ap.add_argument("--depth", type=int, default=0)
 args = ap.parse_args()
 dev = torch.device("cuda")
 dt = torch.float32 if args.dtype == "fp32" else torch.bfloat16
@@ -31,6 +33,8 @@ bb.load_state_dict(seeded_state_dict(bb, 7), strict=False)
 bb = bb.to(dev).eval()
 idx = bb.build_indexes(lambda i0: i0.mark(out["coors"][:m].contiguous()), 1, [1440, 1440, 40], dev)
 MODE = {"tiles": "tiles", "uniform": False, "balanced": True}
+hip_ops.set_tuning("v2_tm", args.tm)
+hip_ops.set_tuning("v2_depth", args.depth)
 for lvl in [int(v) for v in args.levels.split(",")]:
     C = [16, 32, 64, 128][lvl]
     ix = idx[lvl]
