@@ -146,7 +146,9 @@ class VoxelNet(SingleStageDetector):
                     self.bbox_head(self.neck(static_bev), None)
             cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread-local capture mode: another thread of the process (RCCL's watchdog in a multi-rank run) may call the
+            # HIP runtime while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 preds = self.bbox_head(self.neck(static_bev), None)
             cache[key] = (g, static_bev, preds)
         except Exception as e:  # capture is an optimisation; the eager launches are always available

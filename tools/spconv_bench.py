@@ -21,6 +21,7 @@ ap.add_argument("--modes", default="tiles,uniform,balanced")
 ap.add_argument("--rpc", default="0")
 ap.add_argument("--tm", type=int, default=0, help="chunk rows override (64 | 128)")
 ap.add_argument("--depth", type=int, default=0)
+ap.add_argument("--ldspad", type=int, default=0, help="extra LDS bytes per workgroup (occupancy experiments; 1 = drop the 64->64 floor)")
 args = ap.parse_args()
 dev = torch.device("cuda")
 dt = torch.float32 if args.dtype == "fp32" else torch.bfloat16
@@ -35,6 +36,7 @@ idx = bb.build_indexes(lambda i0: i0.mark(out["coors"][:m].contiguous()), 1, [14
 MODE = {"tiles": "tiles", "uniform": False, "balanced": True}
 hip_ops.set_tuning("v2_tm", args.tm)
 hip_ops.set_tuning("v2_depth", args.depth)
+hip_ops.set_tuning("v2_ldspad", args.ldspad)
 for lvl in [int(v) for v in args.levels.split(",")]:
     C = [16, 32, 64, 128][lvl]
     ix = idx[lvl]
