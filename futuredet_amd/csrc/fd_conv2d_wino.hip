@@ -29,6 +29,25 @@
 
 namespace {
 
+// phase timeline for tuning builds (tools/probes/build_trace.sh, -DFD_V2_TRACE): thread 0 of every workgroup accumulates the
+// s_memtime cycles of each phase over its slices
+#ifdef FD_V2_TRACE
+__device__ unsigned long long *g_wtrace;
+#define FD_WT(var) const unsigned long long var = __builtin_readcyclecounter()
+#define FD_WDECL unsigned long long wacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define FD_WADD(i, v) wacc[i] += (v)
+#define FD_WFLUSH                                                                                              \
+    do {                                                                                                       \
+        if (threadIdx.x == 0 && g_wtrace)                                                                      \
+            for (int i_ = 0; i_ < 8; ++i_) g_wtrace[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8 + i_] = wacc[i_]; \
+    } while (0)
+#else
+#define FD_WT(var)
+#define FD_WDECL
+#define FD_WADD(i, v)
+#define FD_WFLUSH
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct WinoParams {
@@ -54,6 +73,8 @@ __global__ void __launch_bounds__(256, (TY * TX * NBW <= 16) ? FD_WINO_OCC16 : (
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // raw patch | V
     unsigned char *s_raw = smem, *s_v = smem + RAW_BYTES;
 
+    FD_WDECL;
+    FD_WT(tstart);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 15, lq = lane >> 4;
     int t = blockIdx.x;
@@ -137,43 +158,58 @@ __global__ void __launch_bounds__(256, (TY * TX * NBW <= 16) ? FD_WINO_OCC16 : (
     const unsigned vbase = (unsigned)(lm * 64 + lq * 16);  // this lane's tile (inside a block of 16) and channel quad
 
     load_slice(0);
-    float4 bw[NBW], bw_next[NBW];
+    // Weight ring: a xi-step has only NTB * NBW * 4 MFMAs (128 cycles at NTB = NBW = 1) while an L2 round trip is ~1000
+    // cycles, so fragments are requested RW steps ahead (one step ahead the kernel waited ~800 cycles per step: 61 us for
+    // 128->128 at 180 x 180; the ring makes it MFMA / transform bound).  16 % RW == 0 keeps the slot index static.
+    constexpr int RW = (NTB * NBW >= 4) ? 2 : 4;
+    float4 bw[RW][NBW];
 #pragma unroll
-    for (int j = 0; j < NBW; ++j) bw[j] = wb[j][0];
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) bw[r][j] = wb[j][(int64_t)(r < total_steps ? r : 0) * 64];
+    FD_WT(tk0);
     for (int s = 0; s < nslices; ++s) {
+        FD_WT(t0);
         store_raw();
         __syncthreads();
+        FD_WT(t1);
         if (s + 1 < nslices) load_slice(s + 1);  // travels under this slice's transform + MFMAs
         transform();
+        FD_WT(t2);
         __syncthreads();
+        FD_WT(t3);
         float4 a[2][NTB];
 #pragma unroll
         for (int i = 0; i < NTB; ++i) a[0][i] = *reinterpret_cast<const float4 *>(s_v + vbase + i * 16 * 64);
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
             const int step = s * 16 + xi;
-            {
-                const int ns = step + 1 < total_steps ? step + 1 : 0;
-#pragma unroll
-                for (int j = 0; j < NBW; ++j) bw_next[j] = wb[j][(int64_t)ns * 64];
-            }
             if (xi + 1 < 16) {
 #pragma unroll
                 for (int i = 0; i < NTB; ++i)
                     a[(xi + 1) & 1][i] = *reinterpret_cast<const float4 *>(s_v + vbase + ((xi + 1) * NTILE + i * 16) * 64);
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep both prefetches in front of the MFMA block (see fd_conv2d_f32.hip)
+            __builtin_amdgcn_sched_barrier(0);  // keep the fragment prefetch in front of the MFMA block (see fd_conv2d_f32.hip)
 #define FD_KSTEP(C)                                                                                                   \
     _Pragma("unroll") for (int i = 0; i < NTB; ++i) _Pragma("unroll") for (int j = 0; j < NBW; ++j)                   \
-        acc[xi][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[j].C, a[xi & 1][i].C, acc[xi][i][j], 0, 0, 0);
+        acc[xi][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[xi % RW][j].C, a[xi & 1][i].C, acc[xi][i][j], 0, 0, 0);
             FD_KSTEP(x) FD_KSTEP(y) FD_KSTEP(z) FD_KSTEP(w)
 #undef FD_KSTEP
             __builtin_amdgcn_sched_barrier(0);
+            {   // refill the slot just consumed with the fragment of RW steps ahead
+                const int ns = step + RW < total_steps ? step + RW : 0;
 #pragma unroll
-            for (int j = 0; j < NBW; ++j) bw[j] = bw_next[j];
+                for (int j = 0; j < NBW; ++j) bw[xi % RW][j] = wb[j][(int64_t)ns * 64];
+            }
         }
+        FD_WT(t4);
         __syncthreads();  // V and the raw patch are rewritten by the next slice
+        FD_WT(t5);
+        FD_WADD(0, t1 - t0); FD_WADD(1, t2 - t1); FD_WADD(2, t3 - t2); FD_WADD(3, t4 - t3); FD_WADD(4, t5 - t4);
     }
+    FD_WT(tk1);
+    FD_WADD(5, ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)));
+    FD_WADD(6, tstart);
     // ---- output transform + epilogue: Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
     const bool wide = ((p.cout_total | p.co_off) & 3) == 0;
 #pragma unroll
@@ -221,6 +257,9 @@ __global__ void __launch_bounds__(256, (TY * TX * NBW <= 16) ? FD_WINO_OCC16 : (
                 }
         }
     }
+    FD_WT(tend);
+    FD_WADD(7, tend);
+    FD_WFLUSH;
 }
 
 template <int TY, int TX, int NBW>
@@ -239,6 +278,10 @@ void launch_wino(const float *x, const void *wp, const float *bias, float *y, Wi
 constexpr int kNumWinoTiles = 6;
 
 }  // namespace
+
+#ifdef FD_V2_TRACE
+extern "C" int fd_debug_set_wino_trace(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_wtrace), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#endif
 
 extern "C" int fd_conv2d_wino_f32_num_tiles(void) { return kNumWinoTiles; }
 
