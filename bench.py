@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="clouds per rank per forward pass")
     ap.add_argument("--global-batch", type=int, default=0, help=">0: a step = this many clouds in total, split over the ranks (strong scaling)")
     ap.add_argument("--pool", type=int, default=4, help="distinct clouds per rank to rotate through (weak-scaling mode)")
+    ap.add_argument("--graph", type=int, default=1, help="1: every pass is ONE hipGraph replay of the whole sweep (detectors.StaticStep: no host "
+                    "read-back between voxelizer and NMS); 0: eager launches with the one mid-sweep read of the level counts")
     ap.add_argument("--inflight", type=int, default=2, help="forward passes in flight per GPU, each on its own HIP stream (1 = strictly serial)")
     ap.add_argument("--channels-last", type=int, default=-1)
     ap.add_argument("--voxel-xy", type=float, default=0.075, help="x/y voxel size (0.05 = the finer grid of BASELINE configs[4])")
@@ -252,8 +254,18 @@ def main():
 
     net.stage_hook = stage_hook
 
+    # whole-sweep graphs: one StaticStep per stream (VoxelNet without a bev_map input).  Instrumented steps (per-launch HIP
+    # events around the sparse convs) cannot run inside a graph and take the eager path.
+    use_graph = bool(args.graph) and not is_pp and bev is None
+    static_steps = {}
+    capacity = (max(len(host[s]) for s in uniq) + 4095) // 4096 * 4096
+
     def forward(clouds):
-        boxes, scores, labels, counts = net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded=True)
+        step = static_steps.get(torch.cuda.current_stream(dev).cuda_stream) if (use_graph and not prof.enabled) else None
+        if step is not None:
+            boxes, scores, labels, counts = step(clouds)
+        else:
+            boxes, scores, labels, counts = net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded=True)
         return dist_infer.pack_results(boxes, scores, labels, counts)
 
     def sync_all():
@@ -332,9 +344,15 @@ def main():
         return prof.enabled and len(streams) > 1
 
     with torch.no_grad():
-        for st in streams:  # set-up, not a warm-up step: every stream captures its neck+head graph and sizes its workspaces
+        for st in streams:  # set-up, not a warm-up step: every stream captures its graph(s) and sizes its workspaces
             with torch.cuda.stream(st):
                 forward([resident[s] for s in seeds[0]])
+                if use_graph:
+                    from futuredet_amd.detectors import StaticStep
+                    step = StaticStep(net, cfg.voxel_generator, capacity, batch_size=B, ndim=host[uniq[0]].shape[1])
+                    step.warm_up([resident[s] for s in seeds[0]])
+                    step.capture()
+                    static_steps[st.cuda_stream] = step
         torch.cuda.synchronize()
         run_steps(0, args.warmup)
         sync_all()
@@ -386,7 +404,7 @@ def main():
                                "detections on the host (value_host_to_host: clouds start in pinned host memory)"
                                % (args.variant, args.class_name, n_pts,
                                   ("global batch %d over %d rank(s), micro-batch %d, %d passes in flight per GPU" % (args.global_batch, world, B, len(streams))) if strong
-                                  else ("%d per GPU per step, %d distinct clouds per GPU in rotation, %d passes in flight per GPU" % (B, len(seeds), len(streams))),
+                                  else ("%d per GPU per step, %d distinct clouds per GPU in rotation, %d passes in flight per GPU%s" % (B, len(seeds), len(streams), ", each pass one whole-sweep hipGraph replay" if use_graph else "")),
                                   "PointPillars(PillarFeatureNet+Scatter)" if is_pp else "VoxelNet+SpMiddleResNetFHD", args.dtype),
                    "parallelism": "sample-sharded x%d (no data-path collective; one fixed-shape all_gather of the detections per step)" % world,
                    "detections_last_step": int(host_c.sum())},

@@ -12,8 +12,18 @@ namespace fd {
 
 void set_error(const char *fmt, ...);
 int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
-                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, const int *ranges,
-                                int n_ranges, hipStream_t stream);
+                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, const int *n_out_dev, int cin, int cout, float *out,
+                                const int *ranges, int n_ranges, hipStream_t stream);
+
+// Element counts that only the device knows (voxels of a sweep, rows of a sparse level): entry points take the host-side
+// CAPACITY plus an optional device pointer to the actual count; kernels are launched for the capacity and work on
+// min(capacity, *count).  This is what lets a whole sweep be issued (or captured into one hipGraph) without reading a
+// count back to the host.
+__device__ __forceinline__ int device_count(int capacity, const int *count_dev) {
+    if (!count_dev) return capacity;
+    const int n = *count_dev;
+    return n < capacity ? (n > 0 ? n : 0) : capacity;
+}
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
@@ -33,6 +43,11 @@ inline int check_launch(const char *what) {
     } while (0)
 
 inline hipStream_t as_stream(fd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Fills n_words 32-bit words (p 4-byte aligned) with a kernel (fd_error.hip).  Used instead of hipMemsetAsync wherever the
+// call may be captured into a hipGraph: measured on ROCm 7.2 / MI355X, a captured graph whose memset nodes reset the
+// voxelizer's hash table hangs on its second replay (the table is not reset, the probe loop never finds a free slot).
+int fill_words(void *p, uint32_t value, size_t n_words, hipStream_t stream);
 
 // ---- per-process state (fd_error.hip).  The library keeps NO per-call mutable state; what it caches is
 //      keyed by device ordinal and published with atomics, so calls from several threads / for several

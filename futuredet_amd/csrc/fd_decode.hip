@@ -551,7 +551,7 @@ extern "C" int fd_rotated_nms(const float *boxes7, int n, float thresh, int64_t 
     FD_REQUIRE(n >= 0 && n <= kMaxPre, "fd_rotated_nms: n must be in [0,%d]", kMaxPre);
     hipStream_t stream = fd::as_stream(stream_);
     if (n == 0) {
-        (void)hipMemsetAsync(out_count, 0, sizeof(int32_t), stream);
+        fd::fill_words(out_count, 0u, 1, stream);
         return fd::check_launch("fd_rotated_nms");
     }
     if (!workspace || workspace_bytes < fd_nms_workspace_bytes(n)) {

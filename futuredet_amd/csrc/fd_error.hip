@@ -74,8 +74,23 @@ const char *const kTuneNames[kTuneCount] = {"spconv_rg", "spconv_v1", "spconv_bf
 int tuning(TuneKey key) { return tune_table().v[key].load(std::memory_order_relaxed); }
 }  // namespace fd
 
+namespace {
+__global__ void __launch_bounds__(256) fill_words_kernel(uint32_t *__restrict__ p, uint32_t v, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+}  // namespace
+
+int fd::fill_words(void *p, uint32_t value, size_t n_words, hipStream_t stream) {
+    if (!n_words) return 0;
+    size_t blocks = (n_words + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t *)p, value, n_words);
+    return 0;
+}
+
 extern "C" const char *fd_last_error(void) { return fd::g_err; }
-extern "C" int fd_abi_version(void) { return 2; }
+extern "C" int fd_abi_version(void) { return 3; }
 
 extern "C" int fd_tuning_set(const char *name, int value) {
     FD_REQUIRE(name, "fd_tuning_set: null name");

@@ -223,33 +223,37 @@ __global__ void __launch_bounds__(256) rows_place(const unsigned long long *__re
 // one thread per (output row, (ky,kx) column pair): fills the kz taps of that column from one word load
 __global__ void __launch_bounds__(256) rulebook_kernel(const unsigned long long *__restrict__ in_words, const int *__restrict__ in_prefix,
                                                        IndexGeom gi, const int *__restrict__ out_coords, const int *__restrict__ n_out_dev,
-                                                       int64_t nbr_stride, DownParams dp, int *__restrict__ nbr) {
+                                                       int64_t nbr_stride, int fill_tail, DownParams dp, int *__restrict__ nbr) {
     const int kyx = dp.k[1] * dp.k[2];
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t o = t % nbr_stride;  // rows fastest -> coalesced nbr writes
-    int q = (int)(t / nbr_stride);
-    if (q >= kyx) return;
-    const int ky = q / dp.k[2], kx = q % dp.k[2];
-    const int n_out = n_out_dev[0];
-    if (o >= n_out) {
-        for (int kz = 0; kz < dp.k[0]; ++kz) nbr[((int64_t)(kz * dp.k[1] + ky) * dp.k[2] + kx) * nbr_stride + o] = -1;
-        return;
-    }
-    const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];  // (b,z,y,x)
-    const int iy = c.z * dp.s[1] - dp.p[1] + ky;
-    const int ix = c.w * dp.s[2] - dp.p[2] + kx;
-    unsigned long long w = 0;
-    int base = 0;
-    if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) {
-        int64_t col = fd::col_of(gi, c.x, iy, ix);
-        w = in_words[col];
-        if (w) base = in_prefix[col];
-    }
-    for (int kz = 0; kz < dp.k[0]; ++kz) {
-        int iz = c.y * dp.s[0] - dp.p[0] + kz;
-        int r = -1;
-        if (iz >= 0 && iz < gi.D && ((w >> iz) & 1ull)) r = base + __popcll(w & ((1ull << iz) - 1ull));
-        nbr[((int64_t)(kz * dp.k[1] + ky) * dp.k[2] + kx) * nbr_stride + o] = r;
+    const int n_out = fd::device_count((int)(nbr_stride < 0x7fffffff ? nbr_stride : 0x7fffffff), n_out_dev);
+    // rows written: all of the table's row capacity (tail = -1), or only the device's count when the consumers clamp to it
+    // themselves (capacity-sized tables of the sync-free step: the launch must not cost what the capacity suggests)
+    const int64_t n_rows = fill_tail ? nbr_stride : (int64_t)n_out;
+    const int64_t total = n_rows * kyx;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = t % n_rows;  // rows fastest -> coalesced nbr writes
+        const int q = (int)(t / n_rows);
+        const int ky = q / dp.k[2], kx = q % dp.k[2];
+        if (o >= n_out) {
+            for (int kz = 0; kz < dp.k[0]; ++kz) nbr[((int64_t)(kz * dp.k[1] + ky) * dp.k[2] + kx) * nbr_stride + o] = -1;
+            continue;
+        }
+        const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];  // (b,z,y,x)
+        const int iy = c.z * dp.s[1] - dp.p[1] + ky;
+        const int ix = c.w * dp.s[2] - dp.p[2] + kx;
+        unsigned long long w = 0;
+        int base = 0;
+        if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) {
+            int64_t col = fd::col_of(gi, c.x, iy, ix);
+            w = in_words[col];
+            if (w) base = in_prefix[col];
+        }
+        for (int kz = 0; kz < dp.k[0]; ++kz) {
+            int iz = c.y * dp.s[0] - dp.p[0] + kz;
+            int r = -1;
+            if (iz >= 0 && iz < gi.D && ((w >> iz) & 1ull)) r = base + __popcll(w & ((1ull << iz) - 1ull));
+            nbr[((int64_t)(kz * dp.k[1] + ky) * dp.k[2] + kx) * nbr_stride + o] = r;
+        }
     }
 }
 
@@ -369,16 +373,19 @@ extern "C" int fd_rows_place(const uint64_t *words, const int32_t *prefix, int B
 }
 
 extern "C" int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int Din, int Hin, int Win,
-                           const int32_t *out_coords, const int32_t *n_out_dev, int64_t nbr_stride, const int *ksize3,
+                           const int32_t *out_coords, const int32_t *n_out_dev, int64_t nbr_stride, int fill_tail, const int *ksize3,
                            const int *stride3, const int *pad3, int32_t *nbr, fd_stream_t stream) {
     FD_REQUIRE(in_words && in_prefix && out_coords && n_out_dev && nbr && ksize3 && stride3 && pad3, "fd_rulebook: null argument");
     DownParams dp;
     FD_REQUIRE(fill_dp(dp, ksize3, stride3, pad3) == 0, "fd_rulebook: unsupported kernel/stride/pad");
     if (nbr_stride <= 0) return FD_OK;
     IndexGeom gi = fd::make_geom(B, Din, Hin, Win);
-    int64_t total = nbr_stride * dp.k[1] * dp.k[2];
-    hipLaunchKernelGGL(rulebook_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, fd::as_stream(stream),
-                       (const unsigned long long *)in_words, in_prefix, gi, out_coords, n_out_dev, nbr_stride, dp, nbr);
+    // grid-stride over (row, ky, kx): the launch is bounded, whatever the row capacity of the table
+    int64_t blocks = (nbr_stride * dp.k[1] * dp.k[2] + 255) / 256;
+    const int64_t cap = (int64_t)fd::device_cu_count() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(rulebook_kernel, dim3((unsigned)blocks), dim3(256), 0, fd::as_stream(stream),
+                       (const unsigned long long *)in_words, in_prefix, gi, out_coords, n_out_dev, nbr_stride, fill_tail, dp, nbr);
     return fd::check_launch("fd_rulebook");
 }
 

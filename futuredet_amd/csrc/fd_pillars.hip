@@ -226,7 +226,8 @@ extern "C" int fd_pillar_scatter(const void *feats, int c, int feat_stride, int 
     if (zero_first) {
         // the canvas is a dense (possibly permuted) tensor: B*C*H*W elements from `out`
         const size_t bytes = (size_t)B * c * H * W * (out_dtype ? 2 : 4);
-        if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return fd::check_launch("fd_pillar_scatter(memset)");
+        if (bytes % 4 == 0) fd::fill_words(out, 0u, bytes / 4, st);
+        else if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return fd::check_launch("fd_pillar_scatter(memset)");
     }
     if (m_max == 0) return FD_OK;
     FD_REQUIRE(feats && coors4 && feat_stride >= c, "fd_pillar_scatter: null argument");

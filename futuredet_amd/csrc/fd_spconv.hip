@@ -36,16 +36,18 @@ template <int CIN, int COUT, int RG>
 __global__ void __launch_bounds__(256) spconv_f32(const float *__restrict__ in, const float4 *__restrict__ wp,
                                                   const float *__restrict__ bias, const float *__restrict__ residual, int relu,
                                                   const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
-                                                  float *__restrict__ out) {
+                                                  const int *__restrict__ n_out_dev, float *__restrict__ out) {
     constexpr int ROWS_B = 64 * RG;  // rows per workgroup
     constexpr int NB = COUT / 16, NC = CIN / 16;
     __shared__ int s_nbr[kMaxTaps * ROWS_B];
     const int tile = blockIdx.x;  // index order: contiguous XCD chunks concentrate the dense regions on a few XCDs (measured -10%)
     const int row0 = tile * ROWS_B;
+    n_out = fd::device_count(n_out, n_out_dev);  // capacity launch (fd_common.h): workgroups past the device's count leave
+    if (row0 >= n_out) return;
     for (int t = threadIdx.x; t < K * ROWS_B; t += 256) {
         int k = t / ROWS_B, r = t - k * ROWS_B;
         int64_t o = (int64_t)row0 + r;
-        s_nbr[t] = (o < nbr_stride) ? nbr[(int64_t)k * nbr_stride + o] : -1;
+        s_nbr[t] = (o < n_out) ? nbr[(int64_t)k * nbr_stride + o] : -1;  // rows >= n_out of the table are never read
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -122,7 +124,7 @@ template <int CIN, int COUT, int RG>
 __global__ void __launch_bounds__(256) spconv_bf16(const unsigned short *__restrict__ in, const void *__restrict__ wp_,
                                                    const float *__restrict__ bias, const unsigned short *__restrict__ residual,
                                                    int relu, const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
-                                                   unsigned short *__restrict__ out) {
+                                                   const int *__restrict__ n_out_dev, unsigned short *__restrict__ out) {
     constexpr int ROWS_B = 64 * RG;
     constexpr int NB = COUT / 16;
     constexpr bool WIDE = CIN >= 32;
@@ -130,10 +132,12 @@ __global__ void __launch_bounds__(256) spconv_bf16(const unsigned short *__restr
     __shared__ int s_nbr[kMaxTaps * ROWS_B];
     const int tile = blockIdx.x;  // index order: contiguous XCD chunks concentrate the dense regions on a few XCDs (measured -10%)
     const int row0 = tile * ROWS_B;
+    n_out = fd::device_count(n_out, n_out_dev);  // capacity launch (fd_common.h): workgroups past the device's count leave
+    if (row0 >= n_out) return;
     for (int t = threadIdx.x; t < K * ROWS_B; t += 256) {
         int k = t / ROWS_B, r = t - k * ROWS_B;
         int64_t o = (int64_t)row0 + r;
-        s_nbr[t] = (o < nbr_stride) ? nbr[(int64_t)k * nbr_stride + o] : -1;
+        s_nbr[t] = (o < n_out) ? nbr[(int64_t)k * nbr_stride + o] : -1;  // rows >= n_out of the table are never read
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -226,7 +230,7 @@ template <int CIN, int COUT>
 __global__ void __launch_bounds__(256) spconv_bf16_cs(const unsigned short *__restrict__ in, const void *__restrict__ wp_,
                                                       const float *__restrict__ bias, const unsigned short *__restrict__ residual,
                                                       int relu, const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
-                                                      unsigned short *__restrict__ out, unsigned in_bytes) {
+                                                      const int *__restrict__ n_out_dev, unsigned short *__restrict__ out, unsigned in_bytes) {
     constexpr int RG = 4, ROWS = 64;
     constexpr int NC = CIN / 32, NB = COUT / 16, NBW = NB / 4;
     static_assert(CIN % 32 == 0 && COUT % 64 == 0, "column split needs CIN % 32 == 0 and COUT % 64 == 0");
@@ -234,10 +238,12 @@ __global__ void __launch_bounds__(256) spconv_bf16_cs(const unsigned short *__re
     __shared__ uint4 s_a[2][RG * NC * 64];
     __shared__ int s_any[2][RG];
     const int row0 = blockIdx.x * ROWS;
+    n_out = fd::device_count(n_out, n_out_dev);
+    if (row0 >= n_out) return;
     for (int t = threadIdx.x; t < K * ROWS; t += 256) {
         int k = t / ROWS, r = t - k * ROWS;
         int64_t o = (int64_t)row0 + r;
-        s_nbr[t] = (o < nbr_stride) ? nbr[(int64_t)k * nbr_stride + o] : -1;
+        s_nbr[t] = (o < n_out) ? nbr[(int64_t)k * nbr_stride + o] : -1;  // rows >= n_out of the table are never read
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -334,6 +340,7 @@ struct LaunchArgs {
     const int *nbr;
     int64_t nbr_stride;
     int K, n_out;
+    const int *n_out_dev;
     void *out;
     hipStream_t stream;
 };
@@ -344,10 +351,10 @@ void launch(const LaunchArgs &a, int dtype) {
     dim3 grid((unsigned)((a.n_out + rows_b - 1) / rows_b));
     if (dtype == 0)
         hipLaunchKernelGGL((spconv_f32<CIN, COUT, RG>), grid, dim3(256), 0, a.stream, (const float *)a.in, (const float4 *)a.wp, a.bias,
-                           (const float *)a.residual, a.relu, a.nbr, a.nbr_stride, a.K, a.n_out, (float *)a.out);
+                           (const float *)a.residual, a.relu, a.nbr, a.nbr_stride, a.K, a.n_out, a.n_out_dev, (float *)a.out);
     else
         hipLaunchKernelGGL((spconv_bf16<CIN, COUT, RG>), grid, dim3(256), 0, a.stream, (const unsigned short *)a.in, a.wp, a.bias,
-                           (const unsigned short *)a.residual, a.relu, a.nbr, a.nbr_stride, a.K, a.n_out, (unsigned short *)a.out);
+                           (const unsigned short *)a.residual, a.relu, a.nbr, a.nbr_stride, a.K, a.n_out, a.n_out_dev, (unsigned short *)a.out);
 }
 
 template <int CIN, int COUT>
@@ -424,18 +431,19 @@ extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, i
 }
 
 extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *wpacked, const float *bias, const void *residual, int relu,
-                               const int32_t *nbr, int64_t nbr_stride, const int32_t *ranges, int n_ranges, int K, int64_t n_out, int cin,
-                               int cout, int dtype, void *out_feats, fd_stream_t stream) {
+                               const int32_t *nbr, int64_t nbr_stride, const int32_t *ranges, int n_ranges, int K, int64_t n_out,
+                               const int32_t *n_out_dev, int64_t n_expected, int cin, int cout, int dtype, void *out_feats, fd_stream_t stream) {
     FD_REQUIRE(K >= 1 && K <= kMaxTaps, "fd_spconv_apply: K must be in [1,27]");
     FD_REQUIRE(dtype == 0 || dtype == 1, "fd_spconv_apply: dtype must be 0 (f32) or 1 (bf16)");
     FD_REQUIRE(n_out >= 0 && n_out <= nbr_stride && n_out < (1ll << 31), "fd_spconv_apply: n_out out of range");
     FD_REQUIRE(n_ranges >= 0 && (ranges == nullptr || n_ranges >= 1), "fd_spconv_apply: ranges needs n_ranges >= 1");
+    if (n_expected <= 0 || n_expected > n_out) n_expected = n_out;  // only steers launch heuristics
     if (n_out == 0) return FD_OK;  // an empty active set (empty cloud): nothing to compute, buffers may be null
     FD_REQUIRE(in_feats && wpacked && nbr && out_feats, "fd_spconv_apply: null argument");
     if (dtype == 0 && !fd::tuning(fd::kTuneSpconvV1)) {
         // fp32 is MFMA-bound: the pair-compacting kernel (fd_spconv_v2.hip) feeds the matrix core no zero rows
         if (fd::spconv_f32_compact_dispatch((const float *)in_feats, wpacked, bias, (const float *)residual, relu, nbr, nbr_stride, K, n_in,
-                                            (int)n_out, cin, cout, (float *)out_feats, ranges, n_ranges, fd::as_stream(stream)))
+                                            (int)n_out, n_out_dev, cin, cout, (float *)out_feats, ranges, n_ranges, fd::as_stream(stream)))
             return fd::check_launch("fd_spconv_apply(compact)");
     }
     if (dtype == 1 && cin >= 32 && cout >= 64 && !fd::tuning(fd::kTuneSpconvBf16V1) && n_in * cin * 2 < (1ll << 31)) {
@@ -446,7 +454,7 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
 #define FD_CS(CI, CO)                                                                                                                    \
     if (cin == CI && cout == CO) {                                                                                                       \
         hipLaunchKernelGGL((spconv_bf16_cs<CI, CO>), grid, dim3(256), 0, st, (const unsigned short *)in_feats, wpacked, bias,             \
-                           (const unsigned short *)residual, relu, nbr, nbr_stride, K, (int)n_out, (unsigned short *)out_feats, in_bytes); \
+                           (const unsigned short *)residual, relu, nbr, nbr_stride, K, (int)n_out, n_out_dev, (unsigned short *)out_feats, in_bytes); \
         return fd::check_launch("fd_spconv_apply(bf16 column split)");                                                                   \
     }
         FD_CS(32, 64)
@@ -455,8 +463,8 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
         FD_CS(128, 128)
 #undef FD_CS
     }
-    LaunchArgs a{in_feats, wpacked, bias, residual, relu, nbr, nbr_stride, K, (int)n_out, out_feats, fd::as_stream(stream)};
-    const int rg = pick_rg(n_out, cin, cout);
+    LaunchArgs a{in_feats, wpacked, bias, residual, relu, nbr, nbr_stride, K, (int)n_out, n_out_dev, out_feats, fd::as_stream(stream)};
+    const int rg = pick_rg(n_expected, cin, cout);
     const int key = cin * 1000 + cout;
     switch (key) {
         case 16016: launch_rg<16, 16>(a, dtype, rg); break;

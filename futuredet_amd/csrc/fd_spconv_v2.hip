@@ -60,8 +60,8 @@ template <int CIN, int COUT, int TM, int DEPTH>
 __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restrict__ in, const float4 *__restrict__ wp,
                                                           const float *__restrict__ bias, const float *__restrict__ residual, int relu,
                                                           const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
-                                                          float *__restrict__ out, unsigned in_bytes, const int *__restrict__ ranges,
-                                                          int rows_per_range) {
+                                                          const int *__restrict__ n_out_dev, float *__restrict__ out, unsigned in_bytes,
+                                                          const int *__restrict__ ranges, int rows_per_range) {
     constexpr int NB = COUT / 16, NC = CIN / 16;
     constexpr int WC = NB == 8 ? 4 : (NB >= 2 ? 2 : 1);  // column splits across the 4 waves (64 columns: 2 x 32)
     constexpr int NBW = NB / WC;          // 16-column blocks per wave
@@ -85,10 +85,13 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- this workgroup's row range, cut into equal chunks of at most TM rows (multiples of 16)
     int r_begin, r_end;
+    if (n_out_dev) n_out = fd::device_count(n_out, n_out_dev);  // capacity launch (see fd_common.h)
     if (ranges) {
         r_begin = ranges[blockIdx.x];
         r_end = ranges[blockIdx.x + 1];
     } else {
+        if (n_out_dev)  // the equal-rows split is made here, from the device's count
+            rows_per_range = (((n_out + (int)gridDim.x - 1) / (int)gridDim.x) + 15) & ~15;
         const int64_t b = (int64_t)blockIdx.x * rows_per_range;
         r_begin = (int)(b < n_out ? b : n_out);
         r_end = (int)(b + rows_per_range < n_out ? b + rows_per_range : n_out);
@@ -399,7 +402,8 @@ inline size_t lds_request(int cin, int cout, int tm) {
 
 template <int CIN, int COUT, int TM, int DEPTH>
 int launch_compact(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
-                   int64_t nbr_stride, int K, int n_out, float *out, unsigned in_bytes, const int *ranges, int n_ranges, hipStream_t stream) {
+                   int64_t nbr_stride, int K, int n_out, const int *n_out_dev, float *out, unsigned in_bytes, const int *ranges, int n_ranges,
+                   hipStream_t stream) {
     const size_t lds_req = lds_request(CIN, COUT, TM);
     static std::atomic<uint64_t> lds_set{0};  // devices on which this instantiation has its LDS limit raised
     auto kern = spconv_f32_compact<CIN, COUT, TM, DEPTH>;
@@ -415,10 +419,10 @@ int launch_compact(const float *in, const void *wp, const float *bias, const flo
     if (!ranges) {  // equal row counts (multiples of 16): n_ranges == 0 -> one TM-row tile per workgroup
         if (n_ranges <= 0) n_ranges = (n_out + TM - 1) / TM;
         rows_per = (((n_out + n_ranges - 1) / n_ranges) + 15) & ~15;
-        n_ranges = (n_out + rows_per - 1) / rows_per;
+        if (!n_out_dev) n_ranges = (n_out + rows_per - 1) / rows_per;  // (with a device count the kernel makes the split over n_ranges)
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_ranges), dim3(256), lds_req, stream, in, (const float4 *)wp, bias, residual, relu, nbr, nbr_stride, K,
-                       n_out, out, in_bytes, ranges, rows_per);
+                       n_out, n_out_dev, out, in_bytes, ranges, rows_per);
     return 1;
 }
 
@@ -427,8 +431,10 @@ int launch_compact(const float *in, const void *wp, const float *bias, const flo
 // the list padding: half a group per tap and 128-row chunk), + 4 for the per-row cost of prologue / epilogue.
 // One wave covers 64 rows = 8 blocks with one ballot per tap; lane i < 8 accumulates block i.
 constexpr int kWorkRows = 8;
-__global__ void __launch_bounds__(256) block_work_kernel(const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out, int n_blocks,
-                                                         unsigned *__restrict__ work) {
+__global__ void __launch_bounds__(256) block_work_kernel(const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
+                                                         const int *__restrict__ n_out_dev, unsigned *__restrict__ work) {
+    n_out = fd::device_count(n_out, n_out_dev);
+    const int n_blocks = (n_out + kWorkRows - 1) / kWorkRows;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t o = wave * 64 + lane;
@@ -445,8 +451,10 @@ __global__ void __launch_bounds__(256) block_work_kernel(const int *__restrict__
 
 // single workgroup: prefix over the block works, range j = blocks whose work midpoint falls into the j-th of n_ranges
 // equal slices of the total.  Boundaries are multiples of 8 rows; a range may be empty (one block heavier than a slice).
-__global__ void __launch_bounds__(1024) range_split_kernel(const unsigned *__restrict__ work, int n_blocks, int n_out, int n_ranges,
-                                                           int *__restrict__ ranges) {
+__global__ void __launch_bounds__(1024) range_split_kernel(const unsigned *__restrict__ work, int n_out, const int *__restrict__ n_out_dev,
+                                                           int n_ranges, int *__restrict__ ranges) {
+    n_out = fd::device_count(n_out, n_out_dev);
+    const int n_blocks = (n_out + kWorkRows - 1) / kWorkRows;
     __shared__ unsigned long long s_part[1024];
     __shared__ unsigned long long s_total;
     const int tid = threadIdx.x;
@@ -521,8 +529,8 @@ extern "C" size_t fd_spconv_ranges_workspace_bytes(int64_t n_out) {
     return fd::align_up(sizeof(unsigned) * (size_t)((n_out + kWorkRows - 1) / kWorkRows + 8), 256);
 }
 
-extern "C" int fd_spconv_ranges(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int n_ranges, int32_t *ranges, void *workspace,
-                                size_t workspace_bytes, fd_stream_t stream_) {
+extern "C" int fd_spconv_ranges(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, const int32_t *n_out_dev, int n_ranges,
+                                int32_t *ranges, void *workspace, size_t workspace_bytes, fd_stream_t stream_) {
     FD_REQUIRE(nbr && ranges && workspace, "fd_spconv_ranges: null argument");
     FD_REQUIRE(n_ranges >= 1 && n_out >= 0 && n_out <= nbr_stride && n_out < (1ll << 31), "fd_spconv_ranges: bad sizes");
     FD_REQUIRE(workspace_bytes >= fd_spconv_ranges_workspace_bytes(n_out), "fd_spconv_ranges: workspace too small");
@@ -530,22 +538,22 @@ extern "C" int fd_spconv_ranges(const int32_t *nbr, int64_t nbr_stride, int K, i
     const int n_blocks = (int)((n_out + kWorkRows - 1) / kWorkRows);
     unsigned *work = (unsigned *)workspace;
     if (n_blocks > 0)
-        hipLaunchKernelGGL(block_work_kernel, dim3((unsigned)((n_blocks + 31) / 32)), dim3(256), 0, stream, nbr, nbr_stride, K, (int)n_out, n_blocks, work);
-    hipLaunchKernelGGL(range_split_kernel, dim3(1), dim3(1024), 0, stream, work, n_blocks, (int)n_out, n_ranges, ranges);
+        hipLaunchKernelGGL(block_work_kernel, dim3((unsigned)((n_blocks + 31) / 32)), dim3(256), 0, stream, nbr, nbr_stride, K, (int)n_out, n_out_dev, work);
+    hipLaunchKernelGGL(range_split_kernel, dim3(1), dim3(1024), 0, stream, work, (int)n_out, n_out_dev, n_ranges, ranges);
     return fd::check_launch("fd_spconv_ranges");
 }
 
 namespace fd {
 // returns 1 when launched, 0 when this shape is not covered (caller falls back to the register kernel)
 int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
-                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, int cin, int cout, float *out, const int *ranges,
-                                int n_ranges, hipStream_t stream) {
+                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, const int *n_out_dev, int cin, int cout, float *out,
+                                const int *ranges, int n_ranges, hipStream_t stream) {
     // (input row << 8 | local row) must fit an int32 and the feature matrix a 31-bit buffer range
     if (n_in_bound >= (1ll << 23) || n_in_bound * cin * 4 >= (1ll << 31)) return 0;
     const unsigned in_bytes = (unsigned)(n_in_bound * cin * 4);
     const int dsel = fd::tuning(fd::kTuneV2Depth), tsel = fd::tuning(fd::kTuneV2TM);  // tuning overrides
 #define FD_LAUNCH(CI, CO, T, D) \
-    launch_compact<CI, CO, T, D>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, out, in_bytes, ranges, n_ranges, stream)
+    launch_compact<CI, CO, T, D>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, out, in_bytes, ranges, n_ranges, stream)
 #define FD_CASE(CI, CO, DDEF, TDEF)                                  \
     if (cin == CI && cout == CO) {                                   \
         const int dd = dsel ? dsel : DDEF, tt = tsel ? tsel : TDEF;  \

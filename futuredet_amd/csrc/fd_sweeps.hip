@@ -143,7 +143,7 @@ extern "C" int fd_sweep_assemble(const float *raw, int raw_cols, int keep_cols, 
     hipStream_t stream = fd::as_stream(stream_);
     if (n_rows == 0 || n_sweeps == 0) {
         FD_REQUIRE(n_rows == 0, "fd_sweep_assemble: rows without a sweep descriptor");
-        if (hipMemsetAsync(out_count, 0, sizeof(int32_t), stream) != hipSuccess) return fd::check_launch("fd_sweep_assemble(memset)");
+        fd::fill_words(out_count, 0u, 1, stream);
         return FD_OK;
     }
     FD_REQUIRE(raw && sweeps_dev && out_points, "fd_sweep_assemble: null argument");

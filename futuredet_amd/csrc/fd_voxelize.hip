@@ -32,10 +32,11 @@ struct VoxParams {
 
 __device__ inline unsigned hash_key(int key) { return (unsigned)key * 2654435761u; }
 
-__global__ void __launch_bounds__(256) vox_hash(const float *__restrict__ pts, int n, VoxParams p,
+__global__ void __launch_bounds__(256) vox_hash(const float *__restrict__ pts, int n, const int *__restrict__ n_dev, VoxParams p,
                                                 int *__restrict__ keys, int *__restrict__ first,
                                                 int *__restrict__ cnt, int *__restrict__ pslot) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    n = fd::device_count(n, n_dev);
     if (i >= n) return;
     const float *q = pts + (int64_t)i * p.ndim;
     int c[3];
@@ -95,8 +96,10 @@ __device__ inline void load_flags(const int *pslot, const int *first, const int 
 }
 
 __global__ void __launch_bounds__(kScanThreads) vox_scan1(const int *__restrict__ pslot, const int *__restrict__ first,
-                                                          const int *__restrict__ cnt, int n, int *__restrict__ bsum) {
+                                                          const int *__restrict__ cnt, int n, const int *__restrict__ n_dev,
+                                                          int *__restrict__ bsum) {
     __shared__ int sm[10];
+    n = fd::device_count(n, n_dev);
     int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     int f = 0, c = 0;
 #pragma unroll
@@ -124,10 +127,11 @@ __global__ void __launch_bounds__(kScanThreads) vox_scan2(int *__restrict__ bsum
 }
 
 __global__ void __launch_bounds__(kScanThreads) vox_scan3(const int *__restrict__ pslot, const int *__restrict__ first,
-                                                          const int *__restrict__ cnt, int n, const int *__restrict__ bsum,
-                                                          int max_voxels, int *__restrict__ vid, int *__restrict__ boff,
-                                                          int *__restrict__ vslot, int *__restrict__ num_voxels) {
+                                                          const int *__restrict__ cnt, int n, const int *__restrict__ n_dev,
+                                                          const int *__restrict__ bsum, int max_voxels, int *__restrict__ vid,
+                                                          int *__restrict__ boff, int *__restrict__ vslot, int *__restrict__ num_voxels) {
     __shared__ int sm[10];
+    n = fd::device_count(n, n_dev);
     int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     int ff[kScanItems], cc[kScanItems];
     int f = 0, c = 0;
@@ -159,10 +163,11 @@ __global__ void __launch_bounds__(kScanThreads) vox_scan3(const int *__restrict_
     }
 }
 
-__global__ void __launch_bounds__(256) vox_fill(const int *__restrict__ pslot, int n, const int *__restrict__ vid,
-                                                const int *__restrict__ boff, int *__restrict__ cursor,
+__global__ void __launch_bounds__(256) vox_fill(const int *__restrict__ pslot, int n, const int *__restrict__ n_dev,
+                                                const int *__restrict__ vid, const int *__restrict__ boff, int *__restrict__ cursor,
                                                 int *__restrict__ bucket) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    n = fd::device_count(n, n_dev);
     if (i >= n) return;
     int s = pslot[i];
     if (s < 0) return;
@@ -264,7 +269,7 @@ extern "C" size_t fd_voxelize_workspace_bytes(int64_t n_points, int64_t max_voxe
     return vox_layout(n_points, max_voxels).total;
 }
 
-extern "C" int fd_voxelize(const float *points, int64_t n_points, int ndim, const float *range6, const float *vsize3,
+extern "C" int fd_voxelize(const float *points, int64_t n_points, const int32_t *n_points_dev, int ndim, const float *range6, const float *vsize3,
                            int max_points, int64_t max_voxels, int batch_idx, float *out_voxels, float *out_mean,
                            int mean_stride, int32_t *out_coors, int coor_cols, int32_t *out_num_points,
                            int32_t *out_num_voxels, void *workspace, size_t workspace_bytes, fd_stream_t stream_) {
@@ -292,8 +297,8 @@ extern "C" int fd_voxelize(const float *points, int64_t n_points, int ndim, cons
     p.max_points = max_points;
     p.max_voxels = (int)max_voxels;
     if (n_points == 0 || max_voxels == 0) {
-        if (hipMemsetAsync(out_num_voxels, 0, sizeof(int32_t), stream) != hipSuccess) return fd::check_launch("memset");
-        return FD_OK;
+        fd::fill_words(out_num_voxels, 0u, 1, stream);
+        return fd::check_launch("fd_voxelize(empty)");
     }
     FD_REQUIRE(points, "fd_voxelize: null points");
     VoxWs w = vox_layout(n_points, max_voxels);
@@ -308,17 +313,17 @@ extern "C" int fd_voxelize(const float *points, int64_t n_points, int ndim, cons
     int *bsum = (int *)(ws + w.bsum), *boff = (int *)(ws + w.boff), *vslot = (int *)(ws + w.vslot);
     int *bucket = (int *)(ws + w.bucket);
     const int n = (int)n_points;
-    (void)hipMemsetAsync(keys, 0xff, sizeof(int) * w.table, stream);
-    (void)hipMemsetAsync(first, 0x7f, sizeof(int) * w.table, stream);
-    (void)hipMemsetAsync(cnt, 0, (w.vid - w.cnt), stream);  // cnt + cursor are adjacent
+    fd::fill_words(keys, 0xffffffffu, w.table, stream);   // (kernels, not hipMemsetAsync: see fd::fill_words)
+    fd::fill_words(first, 0x7f7f7f7fu, w.table, stream);
+    fd::fill_words(cnt, 0u, (w.vid - w.cnt) / sizeof(int), stream);  // cnt + cursor are adjacent
     const int nb = (n + 255) / 256;
     const int nsb = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(vox_hash, dim3(nb), dim3(256), 0, stream, points, n, p, keys, first, cnt, pslot);
-    hipLaunchKernelGGL(vox_scan1, dim3(nsb), dim3(kScanThreads), 0, stream, pslot, first, cnt, n, bsum);
+    hipLaunchKernelGGL(vox_hash, dim3(nb), dim3(256), 0, stream, points, n, n_points_dev, p, keys, first, cnt, pslot);
+    hipLaunchKernelGGL(vox_scan1, dim3(nsb), dim3(kScanThreads), 0, stream, pslot, first, cnt, n, n_points_dev, bsum);
     hipLaunchKernelGGL(vox_scan2, dim3(1), dim3(kScanThreads), 0, stream, bsum, nsb);
-    hipLaunchKernelGGL(vox_scan3, dim3(nsb), dim3(kScanThreads), 0, stream, pslot, first, cnt, n, bsum, p.max_voxels,
+    hipLaunchKernelGGL(vox_scan3, dim3(nsb), dim3(kScanThreads), 0, stream, pslot, first, cnt, n, n_points_dev, bsum, p.max_voxels,
                        vid, boff, vslot, out_num_voxels);
-    hipLaunchKernelGGL(vox_fill, dim3(nb), dim3(256), 0, stream, pslot, n, vid, boff, cursor, bucket);
+    hipLaunchKernelGGL(vox_fill, dim3(nb), dim3(256), 0, stream, pslot, n, n_points_dev, vid, boff, cursor, bucket);
     const int64_t vmax = n_points < max_voxels ? n_points : max_voxels;
 #define FD_EMIT(MP)                                                                                                        \
     hipLaunchKernelGGL(vox_emit<MP>, dim3((unsigned)((vmax + 255) / 256)), dim3(256), 0, stream, points, p, out_num_voxels, keys, \

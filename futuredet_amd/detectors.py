@@ -158,11 +158,16 @@ class VoxelNet(SingleStageDetector):
 
     # ------------------------------------------------------------------------------------------------ fast path
     @torch.no_grad()
-    def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True):
+    def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True, counts=None, static=False, expected=None):
         """clouds: list of device float32 [N_i, 5] tensors (one merged multi-sweep cloud per sample);
         voxel_cfg: the config's ``voxel_generator`` dict (range, voxel_size, max_points_in_voxel, max_voxel_num).
-        Returns predict_padded()'s tuple (padded=True) or the list of per-sample dicts."""
+        Returns predict_padded()'s tuple (padded=True) or the list of per-sample dicts.
+        ``counts``: per cloud a device int32[1] with its number of valid rows (fixed-capacity buffers, loading.assemble_device).
+        ``static=True``: no host read-back anywhere -- sparse levels are sized by their row capacities and every kernel takes
+        its count from the device, so the call can be captured into one hipGraph (StaticStep); ``expected`` = typical row
+        counts per level (launch heuristics only).  Results are identical to the default mode."""
         assert not self.training
+        assert not (static and not padded), "the static step returns the padded device tuple"
         mark_stage = getattr(self, "stage_hook", None) or (lambda name: None)
         mark_stage("start")
         dev = clouds[0].device
@@ -179,7 +184,8 @@ class VoxelNet(SingleStageDetector):
         for b, pts in enumerate(clouds):
             sl = slice(b * max_voxels, (b + 1) * max_voxels)
             hip_ops.voxelize(pts, vs, rng, max_points, max_voxels, batch_idx=b, want_voxels=False, want_mean=True,
-                             out=dict(mean=mean[sl], coors=coors[sl], num_points=npts[sl], num_voxels=nvox[b:b + 1]))
+                             out=dict(mean=mean[sl], coors=coors[sl], num_points=npts[sl], num_voxels=nvox[b:b + 1]),
+                             n_points_dev=None if counts is None else counts[b])
         grid = np.round((np.array(rng[3:], np.float32) - np.array(rng[:3], np.float32)) / np.array(vs, np.float32)).astype(np.int64)
 
         def mark(i0):
@@ -189,7 +195,9 @@ class VoxelNet(SingleStageDetector):
 
         mark_stage("voxelize")
         bb = self.backbone
-        idx = bb.build_indexes(mark, B, list(grid), dev, voxels=(coors, nvox, max_voxels))
+        idx = bb.build_indexes(mark, B, list(grid), dev, voxels=(coors, nvox, max_voxels), static=static, expected=expected)
+        # (static: idx[l].n is the level's capacity; the counts are read by whoever wants them from level_counts, later)
+        self.__dict__["last_level_counts"] = torch.cat([ix.n_dev for ix in idx]) if static else [ix.n for ix in idx]
         mark_stage("index")
         # every row of the level-0 index is exactly one voxel, and fd_rows_place writes all cpad channels of it: no fill
         feats0 = torch.empty((max(idx[0].n, 1), cpad), dtype=bb.compute_dtype, device=dev)[: idx[0].n]
@@ -200,7 +208,7 @@ class VoxelNet(SingleStageDetector):
             hip_ops.check(L.fd_rows_place(hip_ops._p(i0.words), hip_ops._p(i0.prefix), i0.B, i0.D, i0.H, i0.W, hip_ops._p(coors[sl]),
                                           hip_ops._p(nvox[b:b + 1]), max_voxels, hip_ops._p(mean[sl]), cpad, hip_ops._p(feats0), cpad,
                                           hip_ops._DT[bb.compute_dtype], hip_ops._stream()), "fd_rows_place")
-        graph = None if (bev_map is not None or _NO_GRAPH) else self._dense_graph(B, idx[4], dev)
+        graph = None if (bev_map is not None or _NO_GRAPH or static) else self._dense_graph(B, idx[4], dev)
         if graph is not None:
             # neck + head have static shapes: replay them as one hipGraph (one launch instead of ~25-60)
             g, static_bev, preds = graph
@@ -221,6 +229,87 @@ class VoxelNet(SingleStageDetector):
             out = self.bbox_head.predict({"metadata": [None] * B}, preds, self.test_cfg)
         mark_stage("decode")
         return out
+
+
+class StaticStep(object):
+    """One whole sweep -- voxelizer, index pyramid, rulebooks, 21 sparse convolutions, RPN, CenterHead, decode, rotated NMS --
+    as ONE hipGraph replay with no host read-back in between.  Shapes are static: the clouds live in a
+    fixed-capacity buffer with their row counts on the device, sparse levels are sized by their row capacities
+    (hip_ops._PyramidPlan.row_caps) and every kernel takes its count from device memory.
+
+        step = StaticStep(model, voxel_cfg, capacity=400000)       # model: VoxelNet in eval mode on a GPU
+        step.warm_up([cloud])                                      # eager sweeps: conv plan choices + typical level counts
+        boxes, scores, labels, counts = step([cloud])              # copies the cloud in, replays; outputs are the graph's
+                                                                   # static tensors (valid until the next call on this stream)
+    One StaticStep belongs to one stream (the one current at capture); sweeps in flight on several streams use one each."""
+
+    def __init__(self, model, voxel_cfg, capacity, batch_size=1, ndim=5):
+        self.model, self.voxel_cfg = model, voxel_cfg
+        self.B, self.capacity, self.ndim = int(batch_size), int(capacity), int(ndim)
+        dev = next(model.parameters()).device
+        self.points = torch.zeros((self.B, self.capacity, self.ndim), dtype=torch.float32, device=dev)
+        self.counts = torch.zeros((self.B,), dtype=torch.int32, device=dev)
+        self.expected = None
+        self.graph = None
+        self.outputs = None
+        self.level_counts = None
+        self.version = None
+
+    def _version_key(self):
+        m = self.model
+        return (weights_version(m), m.backbone.compute_dtype, getattr(m.neck, "use_hip_conv", None))
+
+    def _load(self, clouds):
+        assert len(clouds) == self.B
+        for b, c in enumerate(clouds):
+            n = int(c.shape[0])
+            if n > self.capacity or c.shape[1] != self.ndim:
+                raise ValueError("cloud of %d x %d rows does not fit the step's %d x %d buffer" % (n, c.shape[1], self.capacity, self.ndim))
+            self.points[b, :n].copy_(c, non_blocking=True)
+            self.counts[b:b + 1].fill_(n)
+
+    def _run(self, static):
+        m = self.model
+        return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, counts=[self.counts[b:b + 1] for b in range(self.B)],
+                                static=static, expected=self.expected)
+
+    def warm_up(self, clouds, n=2):
+        """Eager sweeps on representative clouds: lets the dense-conv plan time its variants and records the level counts that
+        steer the sparse-conv launch shapes of the captured step."""
+        self._load(clouds)
+        for _ in range(n):
+            self._run(False)
+        self.expected = [int(v) for v in self.model.last_level_counts]
+        self.graph = None
+
+    def capture(self):
+        m = self.model
+        dev = self.points.device
+        if self.expected is None:
+            raise RuntimeError("StaticStep.warm_up(clouds) must run before the capture")
+        cur = torch.cuda.current_stream(dev)
+        # a capture stream of its own: hip_ops' scratch buffers are keyed by stream, so two steps never share scratch memory
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(cur)
+        with torch.cuda.stream(cap):
+            self._run(True)  # allocates capacity-sized scratch outside the graph's pool once
+        cur.wait_stream(cap)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+            self.outputs = self._run(True)
+            self.level_counts = m.last_level_counts
+        self.graph = g
+        self.version = self._version_key()
+
+    def __call__(self, clouds):
+        if self.graph is None or self.version != self._version_key():
+            if self.expected is None:
+                self.warm_up(clouds)
+            self.capture()
+        self._load(clouds)
+        self.graph.replay()
+        return self.outputs
 
 
 @DETECTORS.register_module

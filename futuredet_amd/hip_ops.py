@@ -62,10 +62,11 @@ def set_tuning(name, value):
 
 # ------------------------------------------------------------------------------------------------ voxelizer
 def voxelize(points, voxel_size, coors_range, max_points, max_voxels, batch_idx=0, want_voxels=True, want_mean=False,
-             mean_stride=None, coor_cols=3, out=None):
+             mean_stride=None, coor_cols=3, out=None, n_points_dev=None):
     """Runs fd_voxelize on device points [N, ndim] float32.  Returns a dict of capacity-sized device tensors
     (voxels / mean / coors / num_points) plus ``num_voxels`` (device int32[1]); nothing is synchronised.
-    ``out`` may supply pre-allocated (sliced) destination tensors with the same keys."""
+    ``out`` may supply pre-allocated (sliced) destination tensors with the same keys.  ``n_points_dev`` (device int32[1]):
+    only the first min(N, n_points_dev[0]) rows are points, the rest is padding of a fixed-capacity buffer."""
     L = _lib.load()
     points = _dev(points, "points", torch.float32)
     n, ndim = points.shape
@@ -87,7 +88,7 @@ def voxelize(points, voxel_size, coors_range, max_points, max_voxels, batch_idx=
     voxels = out.get("voxels") if want_voxels else None
     ws_bytes = L.fd_voxelize_workspace_bytes(n, max_voxels)
     ws = workspace.get("voxelize", ws_bytes, dev)
-    check(L.fd_voxelize(_p(points), n, ndim, rng, vs, int(max_points), int(max_voxels), int(batch_idx), _p(voxels), _p(mean),
+    check(L.fd_voxelize(_p(points), n, _p(n_points_dev), ndim, rng, vs, int(max_points), int(max_voxels), int(batch_idx), _p(voxels), _p(mean),
                         int(mean.shape[1]) if mean is not None else 0, _p(out["coors"]), int(out["coors"].shape[1]),
                         _p(out["num_points"]), _p(out["num_voxels"]), _p(ws), ws.numel(), _stream()), "fd_voxelize")
     return out
@@ -104,9 +105,11 @@ class SparseIndex(object):
         self.words = torch.zeros((self.ncols,), dtype=torch.int64, device=device) if words is None else words
         self.prefix = torch.empty((self.ncols,), dtype=torch.int32, device=device) if prefix is None else prefix
         self.n_dev = None     # device int32[1] view
-        self.n = None         # host int, set by finalize()
+        self.n = None         # host int, set by finalize() (static indexes: the row CAPACITY)
         self.coords = None    # [n,4] int32 (b,z,y,x), rows in index order
         self.device = device
+        self.static = False   # True: the count stays on the device (n_dev); n is a capacity, n_expected a typical count
+        self.n_expected = 0
 
     @property
     def spatial_shape(self):
@@ -159,13 +162,17 @@ class SparseIndex(object):
         K = int(ksize[0] * ksize[1] * ksize[2])
         nstride = max(64, (out_index.n + 63) // 64 * 64)
         nbr = torch.empty((K, nstride), dtype=torch.int32, device=self.device)
+        static = getattr(out_index, "static", False)
         if out_index.n == 0:
             nbr.fill_(-1)
             return nbr
+        # static indexes: the table has the level's row capacity; only the device's count of rows is written (and read)
         check(L.fd_rulebook(_p(self.words), _p(self.prefix), self.B, self.D, self.H, self.W, _p(out_index.coords),
-                            _p(out_index.n_dev), nstride, (ctypes.c_int * 3)(*ksize), (ctypes.c_int * 3)(*stride),
+                            _p(out_index.n_dev), nstride, 0 if static else 1, (ctypes.c_int * 3)(*ksize), (ctypes.c_int * 3)(*stride),
                             (ctypes.c_int * 3)(*pad), _p(nbr), _stream()), "fd_rulebook")
         nbr.n_out = out_index.n
+        nbr.n_dev = out_index.n_dev if static else None
+        nbr.n_expected = out_index.n_expected if static else 0
         return nbr
 
 
@@ -182,14 +189,26 @@ class _PyramidPlan(object):
         self.ncols = [L.fd_index_num_cols(self.B, sh[1], sh[2]) for sh in self.shapes]
         self.ws_bytes = L.fd_index_workspace_bytes(max(self.ncols))
 
+    def row_caps(self, cap0):
+        """Upper bounds of the active rows per level given at most ``cap0`` rows on level 0: a strided convolution turns one
+        input into at most prod(ceil(k / s)) outputs (the taps k with (p + pad - k) % s == 0), and a level cannot have more
+        rows than cells."""
+        caps = [min(int(cap0), self.B * int(np.prod(self.shapes[0])))]
+        for (ks, st, pd), sh in zip(self.geoms, self.shapes[1:]):
+            fan = int(np.prod([-(-k // s) for k, s in zip(ks, st)]))
+            caps.append(min(caps[-1] * fan, self.B * int(np.prod(sh))))
+        return caps
+
 
 _pyramid_plans = {}
 
 
-def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device):
+def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device, static=False, expected=None):
     """All sparse indexes of the backbone with two library calls and ONE host read: level 0 (D,H,W = shape0) marked
     from the voxelizer output ``coors`` [B*n_max, 4] / ``nvox`` [B]; level l from level l-1 by geoms[l-1] =
-    (ksize, stride, pad).  Returns the list of finalised SparseIndex (coords materialised)."""
+    (ksize, stride, pad).  Returns the list of finalised SparseIndex (coords materialised).
+    ``static=True``: NO host read -- every level gets its row capacity (_PyramidPlan.row_caps) as ``n``, the counts stay in
+    ``n_dev`` and ``expected`` (typical counts, e.g. of an earlier sweep) only steers launch heuristics."""
     L = _lib.load()
     key = (int(B), tuple(int(v) for v in shape0), tuple((tuple(k), tuple(s), tuple(p)) for k, s, p in geoms), str(device))
     plan = _pyramid_plans.get(key)
@@ -208,6 +227,7 @@ def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device):
         ix.B, ix.D, ix.H, ix.W, ix.ncols, ix.device = plan.B, sh[0], sh[1], sh[2], nc, device
         ix.words, ix.prefix = words_all[off:off + nc], prefix_all[off:off + nc]
         ix.n_dev, ix.n, ix.coords = counts[l:l + 1], None, None
+        ix.static, ix.n_expected = False, 0
         lv = levels[l]
         lv.D, lv.H, lv.W = sh
         if l:
@@ -219,7 +239,13 @@ def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device):
     ws = workspace.get("index_scan", plan.ws_bytes, device)
     check(L.fd_index_pyramid(_p(coors), _p(nvox), int(n_max), plan.B, len(shapes), levels, _p(counts), _p(ws), ws.numel(), _stream()),
           "fd_index_pyramid")
-    host = counts.tolist()  # the only synchronisation of the backbone
+    if static:
+        host = plan.row_caps(int(B) * int(n_max))
+        for l, ix in enumerate(idx):
+            ix.static = True
+            ix.n_expected = int(expected[l]) if expected is not None else 0
+    else:
+        host = counts.tolist()  # the only synchronisation of the backbone
     total = sum(host)
     coords_all = torch.empty((max(total, 1), 4), dtype=torch.int32, device=device)
     o = 0
@@ -243,12 +269,13 @@ def ranges_for(nbr, cin, cout):
     if not n_out:
         return None, 0
     K, nstride = nbr.shape
-    n = int(L.fd_spconv_num_ranges(n_out, cin, cout, 0))
+    n = int(L.fd_spconv_num_ranges(getattr(nbr, "n_expected", 0) or n_out, cin, cout, 0))
     if n <= 0:
         return None, 0
     ranges = torch.empty((n + 1,), dtype=torch.int32, device=nbr.device)
     ws = workspace.get("spconv_ranges", L.fd_spconv_ranges_workspace_bytes(n_out), nbr.device)
-    check(L.fd_spconv_ranges(_p(nbr), nstride, K, n_out, n, _p(ranges), _p(ws), ws.numel(), _stream()), "fd_spconv_ranges")
+    check(L.fd_spconv_ranges(_p(nbr), nstride, K, n_out, _p(getattr(nbr, "n_dev", None)), n, _p(ranges), _p(ws), ws.numel(), _stream()),
+          "fd_spconv_ranges")
     nbr.ranges = (ranges, n)
     return nbr.ranges
 
@@ -293,6 +320,7 @@ def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=Fal
     # convolutions of a level) get equal-WORK ranges from fd_spconv_ranges; narrow layers and strided convolutions (rulebook
     # used once) take equal row counts -- see fd_spconv_num_ranges for the measurements.
     ranges, n_ranges = None, 0
+    n_dev, n_expected = getattr(nbr, "n_dev", None), getattr(nbr, "n_expected", 0)  # static index: n_out is a capacity
     if dt == 0 and n_out > 0:
         if balanced is None:
             balanced = K == 27 and cin == cout and bool(L.fd_spconv_wants_balanced_ranges(cin, cout, dt))
@@ -301,9 +329,10 @@ def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=Fal
         elif balanced:
             ranges, n_ranges = ranges_for(nbr, cin, cout)
         else:
-            n_ranges = int(L.fd_spconv_num_ranges(n_out, cin, cout, 0))
+            n_ranges = int(L.fd_spconv_num_ranges(n_expected or n_out, cin, cout, 0))
     check(L.fd_spconv_apply(_p(feats), feats.shape[0], _p(_dev(wpacked, "wpacked")), _p(bias), _p(residual), int(bool(relu)),
-                            _p(_dev(nbr, "nbr", torch.int32)), nstride, _p(ranges), n_ranges, K, n_out, cin, cout, dt, _p(out), _stream()),
+                            _p(_dev(nbr, "nbr", torch.int32)), nstride, _p(ranges), n_ranges, K, n_out, _p(n_dev), int(n_expected or 0),
+                            cin, cout, dt, _p(out), _stream()),
           "fd_spconv_apply")
     return out
 

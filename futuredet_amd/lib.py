@@ -35,7 +35,7 @@ SIGNATURES = {
     "fd_last_error": (ctypes.c_char_p, []),
     "fd_tuning_set": (c_int, [ctypes.c_char_p, c_int]),
     "fd_voxelize_workspace_bytes": (c_size_t, [c_i64, c_i64]),
-    "fd_voxelize": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_int,
+    "fd_voxelize": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p, c_void_p, c_int,
                             c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fd_index_num_cols": (c_i64, [c_int, c_int, c_int]),
     "fd_index_workspace_bytes": (c_size_t, [c_i64]),
@@ -45,16 +45,16 @@ SIGNATURES = {
     "fd_index_coords": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fd_index_lookup": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "fd_rows_permute": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p]),
-    "fd_rulebook": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p,
+    "fd_rulebook": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p,
                             c_void_p, c_void_p, c_void_p]),
     "fd_spconv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "fd_spconv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fd_spconv_apply": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p, c_int, c_int, c_i64,
-                                c_int, c_int, c_int, c_void_p, c_void_p]),
+                                c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fd_spconv_num_ranges": (c_int, [c_i64, c_int, c_int, c_int]),
     "fd_spconv_wants_balanced_ranges": (c_int, [c_int, c_int, c_int]),
     "fd_spconv_ranges_workspace_bytes": (c_size_t, [c_i64]),
-    "fd_spconv_ranges": (c_int, [c_void_p, c_i64, c_int, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fd_spconv_ranges": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fd_densify": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_i64,
                            c_i64, c_i64, c_i64, c_void_p]),
     "fd_conv2d_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -38,6 +38,14 @@ const char *fd_last_error(void);
 int fd_tuning_set(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Device-side counts.  The number of voxels of a sweep and the number of active rows of every sparse level exist only
+ * on the device.  Every entry point on the sweep path therefore takes a host-side CAPACITY (n_points, n_max, n_out,
+ * nbr_stride ...) and, optionally, a device pointer to the actual count (n_points_dev, n_dev, n_out_dev): kernels are
+ * launched for the capacity (or a bounded grid) and work on min(capacity, *count).  With the counts left on the device a
+ * whole sweep -- voxelizer to NMS -- is issued without a host read-back and can be captured into one hipGraph
+ * (futuredet_amd.detectors.VoxelNet.forward_points_static).  Passing NULL keeps the plain host-count behaviour.
+ * ------------------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------------
  * Voxelizer (+ fused mean reader).
  * Replaces points_to_voxel(points, voxel_size, coors_range, max_points, reverse_index=True, max_voxels)
  *   det3d/ops/point_cloud/point_cloud_ops.py:112-184 (kernel :7-55), called from
@@ -48,13 +56,15 @@ int fd_tuning_set(const char *name, int value);
  * in first-occurrence order of the input points, the first max_voxels voxels survive, each keeps its first
  * max_points points in input order; c = floor((p - lo) / vs) in float32 with a true division.
  *   points      [n, ndim] float32 rows (x,y,z,...)          ndim <= 8
+ *   n_points_dev  NULL, or device int32[1]: the cloud has min(n_points, *n_points_dev) rows and n_points is the capacity of
+ *                 a padded buffer (futuredet_amd.loading.assemble_device) -- see "Device-side counts" below
  *   out_voxels  [max_voxels, max_points, ndim] or NULL      (zero padded, as the reference returns)
  *   out_mean    [max_voxels, mean_stride] or NULL           (sum of kept points / count; cols >= ndim zeroed)
  *   out_coors   [max_voxels, coor_cols]; coor_cols 3 -> (z,y,x); 4 -> (batch_idx,z,y,x)
  *   out_num_points [max_voxels] int32, out_num_voxels device int32[1]
  * ------------------------------------------------------------------------------------------------- */
 size_t fd_voxelize_workspace_bytes(int64_t n_points, int64_t max_voxels);
-int fd_voxelize(const float *points, int64_t n_points, int ndim, const float *range6_host,
+int fd_voxelize(const float *points, int64_t n_points, const int32_t *n_points_dev, int ndim, const float *range6_host,
                 const float *voxel_size3_host, int max_points, int64_t max_voxels, int batch_idx,
                 float *out_voxels, float *out_mean, int mean_stride, int32_t *out_coors, int coor_cols,
                 int32_t *out_num_points, int32_t *out_num_voxels, void *workspace, size_t workspace_bytes,
@@ -94,9 +104,10 @@ int fd_index_lookup(const uint64_t *words, const int32_t *prefix, int B, int D, 
 /* dst[row_of[j], 0:c_dst] = src[j, 0:c_src] (zero padded to c_dst); rows with row_of<0 skipped */
 int fd_rows_permute(const float *src, int c_src, const int32_t *row_of, const int32_t *n_dev, int64_t n_max,
                     void *dst, int c_dst, int dst_bf16, fd_stream_t stream);
-/* nbr [K, nbr_stride] int32; rows o >= n_out (device count) are filled with -1 up to nbr_stride */
+/* nbr [K, nbr_stride] int32.  fill_tail != 0: rows o >= n_out (device count) are filled with -1 up to nbr_stride;
+ * fill_tail == 0: rows >= n_out are left untouched (capacity-sized tables whose consumers are given the same device count) */
 int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int Din, int Hin, int Win,
-                const int32_t *out_coords, const int32_t *n_out_dev, int64_t nbr_stride, const int *ksize3,
+                const int32_t *out_coords, const int32_t *n_out_dev, int64_t nbr_stride, int fill_tail, const int *ksize3,
                 const int *stride3, const int *pad3, int32_t *nbr, fd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -113,7 +124,9 @@ size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype);
 int fd_spconv_pack_weight(const float *w_kio_host, int K, int cin, int cout, int dtype, void *wpacked_host);
 int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *wpacked, const float *bias, const void *residual,
                     int relu, const int32_t *nbr, int64_t nbr_stride, const int32_t *ranges /* [n_ranges+1] or NULL */,
-                    int n_ranges, int K, int64_t n_out, int cin, int cout, int dtype, void *out_feats, fd_stream_t stream);
+                    int n_ranges, int K, int64_t n_out, const int32_t *n_out_dev /* NULL, or the device's row count */,
+                    int64_t n_expected /* 0, or a typical row count that steers the launch heuristics when n_out is a capacity */,
+                    int cin, int cout, int dtype, void *out_feats, fd_stream_t stream);
 /* Work distribution of fd_spconv_apply (fp32; no reference counterpart -- spconv launches one GEMM per tap).  Workgroup b
  * computes output rows ranges[b] .. ranges[b+1]-1 (consecutive rows = neighbouring voxels), in chunks of <= 128 rows.
  *   ranges == NULL, n_ranges == 0 : one 128-row tile per workgroup
@@ -126,8 +139,8 @@ int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *wpacked, con
 int fd_spconv_num_ranges(int64_t n_out, int cin, int cout, int dtype);
 int fd_spconv_wants_balanced_ranges(int cin, int cout, int dtype); /* 1: use fd_spconv_ranges; 0: equal rows (ranges = NULL) */
 size_t fd_spconv_ranges_workspace_bytes(int64_t n_out);
-int fd_spconv_ranges(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, int n_ranges, int32_t *ranges /*[n_ranges+1]*/,
-                     void *workspace, size_t workspace_bytes, fd_stream_t stream);
+int fd_spconv_ranges(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, const int32_t *n_out_dev, int n_ranges,
+                     int32_t *ranges /*[n_ranges+1]*/, void *workspace, size_t workspace_bytes, fd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Densify.  Replaces SparseConvTensor.dense() + view (scn.py:165-168): out[b, c*D + d, y, x] = feats[row, c].

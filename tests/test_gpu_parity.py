@@ -1013,9 +1013,9 @@ def test_c_abi_reports_errors_instead_of_exiting(hip):
     L = lib.load()
     x = torch.zeros((64, 16), device="cuda")
     cases = [
-        ("fd_voxelize", lambda: L.fd_voxelize(x.data_ptr(), 64, 99, None, None, 10, 100, 0, None, None, 0, None, 3, None, None, None, 0, None)),
-        ("fd_spconv_apply", lambda: L.fd_spconv_apply(x.data_ptr(), 64, x.data_ptr(), None, None, 0, x.data_ptr(), 64, None, 0, 99, 64, 16, 16, 0,
-                                                     x.data_ptr(), None)),
+        ("fd_voxelize", lambda: L.fd_voxelize(x.data_ptr(), 64, None, 99, None, None, 10, 100, 0, None, None, 0, None, 3, None, None, None, 0, None)),
+        ("fd_spconv_apply", lambda: L.fd_spconv_apply(x.data_ptr(), 64, x.data_ptr(), None, None, 0, x.data_ptr(), 64, None, 0, 99, 64, None, 0,
+                                                     16, 16, 0, x.data_ptr(), None)),
         ("fd_rotated_nms", lambda: L.fd_rotated_nms(None, 10, ctypes.c_float(0.2), None, None, None, 0, None)),
         ("fd_conv2d_nhwc_bf16", lambda: L.fd_conv2d_nhwc_bf16(x.data_ptr(), 1, 8, 8, 7, x.data_ptr(), None, 16, 3, 1, 1, 1, x.data_ptr(), 16, 0, 1, 1,
                                                              0, 0, None)),
@@ -1343,3 +1343,62 @@ def test_full_size_backbone_is_deterministic_and_linear(hip):
     lhs, rhs = f(2.5 * x + y), 2.5 * f(x) + f(y)
     assert i2.n > 100000
     assert float((lhs - rhs).abs().max()) <= 1e-4 * float(rhs.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ whole sweep as one hipGraph
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_static_step_graph_is_bit_identical_to_the_eager_sweep(hip, precision):
+    """StaticStep (no host read-back between the voxelizer and the NMS output, the whole sweep replayed as ONE hipGraph with
+    capacity-sized sparse levels and device-side counts) against forward_points on the same clouds: one captured graph, clouds
+    of different sizes (one larger and two much smaller than the warm-up cloud, and an empty one) -- padded outputs and counts
+    must be bit-identical, and the level counts the graph reports must equal the eager host counts."""
+    from futuredet_amd.detectors import StaticStep
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, _ = _build_pair("forecast_n3" if precision == "bf16" else "forecast_n0")
+    if precision == "bf16":
+        net.set_precision(torch.bfloat16)
+    step = StaticStep(net, cfg.voxel_generator, capacity=90000)
+    clouds = [_dev(synthetic_cloud(seed=s, target_points=n)) for s, n in ((3, 40000), (4, 80000), (5, 9000), (6, 300))]
+    clouds.append(torch.zeros((0, 5), device="cuda"))
+    with torch.no_grad():
+        step.warm_up([clouds[0]])
+        for i, c in enumerate(clouds):
+            assert c.shape[0] <= 90000
+            want = net.forward_points([c], cfg.voxel_generator)
+            want_levels = list(net.last_level_counts)
+            got = step([c])
+            torch.cuda.synchronize()
+            assert step.graph is not None
+            cnt_w, cnt_g = want[3].cpu().numpy(), got[3].cpu().numpy()
+            assert np.array_equal(cnt_w, cnt_g), (i, cnt_w, cnt_g)
+            assert step.level_counts.cpu().tolist() == want_levels, (i, step.level_counts.cpu().tolist(), want_levels)
+            for b in range(cnt_w.shape[0]):
+                for s_ in range(cnt_w.shape[1]):
+                    k = int(cnt_w[b, s_])
+                    for name, w, g in (("boxes", want[0], got[0]), ("scores", want[1], got[1]), ("labels", want[2], got[2])):
+                        assert torch.equal(w[b, s_, :k], g[b, s_, :k]), "cloud %d: %s of (sample %d, step %d) differ" % (i, name, b, s_)
+            report("static step (%s) cloud %d (%d pts): detections bit-identical to eager" % (precision, i, c.shape[0]), 0.0, 0.0,
+                   "(levels %s)" % want_levels)
+    with pytest.raises(ValueError):
+        step([torch.zeros((90001, 5), device="cuda")])
+
+
+def test_static_step_follows_weight_updates(hip):
+    """A captured whole-sweep graph must not outlive the weights it was captured with."""
+    from futuredet_amd.detectors import StaticStep
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, _ = _build_pair("forecast_n0", seed=7)
+    cloud = _dev(synthetic_cloud(seed=1, target_points=20000))
+    step = StaticStep(net, cfg.voxel_generator, capacity=32768)
+    with torch.no_grad():
+        first = [t.clone() for t in step([cloud])]
+        g0 = step.graph
+        net.bbox_head.shared_conv[0].weight.mul_(0.5)
+        want = net.forward_points([cloud], cfg.voxel_generator)
+        got = step([cloud])
+        torch.cuda.synchronize()
+    assert step.graph is not g0
+    assert torch.equal(want[3], got[3]) and torch.equal(want[1], got[1]) and torch.equal(want[0], got[0])
+    assert not torch.equal(first[1], got[1])
