@@ -1402,3 +1402,28 @@ def test_static_step_follows_weight_updates(hip):
     assert step.graph is not g0
     assert torch.equal(want[3], got[3]) and torch.equal(want[1], got[1]) and torch.equal(want[0], got[0])
     assert not torch.equal(first[1], got[1])
+
+
+def test_static_step_full_size_matches_eager(hip):
+    """The bench workload (forecast_n0, 300k-point cloud, fp32) through the whole-sweep graph with the real row capacities
+    (level 1: 1.28 M rows, level 2: 1.43 M rows for <= 160k voxels) against the eager sweep, and a second, different cloud
+    through the same graph."""
+    from futuredet_amd.detectors import StaticStep
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, _ = _build_pair("forecast_n0")
+    clouds = [_dev(synthetic_cloud(seed=s, target_points=300000)) for s in (0, 1)]
+    step = StaticStep(net, cfg.voxel_generator, capacity=330000)
+    with torch.no_grad():
+        step.warm_up([clouds[0]])
+        for i, c in enumerate(clouds):
+            want = net.forward_points([c], cfg.voxel_generator)
+            levels = list(net.last_level_counts)
+            got = step([c])
+            torch.cuda.synchronize()
+            assert step.level_counts.cpu().tolist() == levels
+            assert levels[0] > 150000
+            assert torch.equal(want[3], got[3])
+            k = want[3].max().item()
+            assert k > 0 and torch.equal(want[0][:, :, :k], got[0][:, :, :k]) and torch.equal(want[1][:, :, :k], got[1][:, :, :k])
+            report("static step full size cloud %d: bit-identical to eager" % i, 0.0, 0.0, "(levels %s)" % levels)
