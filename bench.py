@@ -88,7 +88,7 @@ def parse():
     return args
 
 
-PROF_EVERY = 10
+PROF_EVERY = 25  # instrumented steps of the timed region: si % PROF_EVERY == PROF_EVERY // 2 (or the middle step of a shorter run)
 
 
 class SpconvProfiler(object):
@@ -259,6 +259,8 @@ def main():
     # whole-sweep graphs: one StaticStep per stream (VoxelNet without a bev_map input).  Instrumented steps (per-launch HIP
     # events around the sparse convs) cannot run inside a graph and take the eager path.
     use_graph = (args.graph == 1 or (args.graph < 0 and args.dtype == "fp32")) and not is_pp and bev is None
+    if use_graph and args.dtype == "fp32" and B * args.max_voxels * 8 >= (1 << 23):
+        use_graph = False  # row capacities beyond the fp32 kernel's 2^23 input rows (StaticStep.capture refuses them)
     static_steps = {}
     capacity = (max(len(host[s]) for s in uniq) + 4095) // 4096 * 4096
 
@@ -337,12 +339,14 @@ def main():
             last = retire_step(window.pop(0))
         return last
 
+    prof_steps = {si for si in range(args.steps) if si % PROF_EVERY == PROF_EVERY // 2} or {args.steps // 2}
+
     def set_prof(si):
-        # The per-launch HIP events of the roofline measurement are taken on every PROF_EVERY-th step of the timed region.
+        # The per-launch HIP events of the roofline measurement are taken on every PROF_EVERY-th step of the timed region (one step of a default run).
         # Such a step runs ALONE (the passes in flight are retired first, the next one starts after it): with two sweeps
         # sharing the GPU a launch's elapsed time contains the other sweep's kernels, which is not the kernel's duration.
         # The drain and the event pairs (~5 us of queue time per launch) are charged to the headline number.
-        prof.enabled = (si % PROF_EVERY == 0)
+        prof.enabled = si in prof_steps
         return prof.enabled and len(streams) > 1
 
     with torch.no_grad():
@@ -426,7 +430,7 @@ def main():
                 forward([resident[s] for s in seeds[mb]])
             prof.enabled = False
             pairs = [prof.pairs[(key, i)] for _, _, _, _, key, i in prof.records]
-        n_prof = (args.steps + PROF_EVERY - 1) // PROF_EVERY  # instrumented steps
+        n_prof = len(prof_steps)  # instrumented steps
         launches = len(ms)
         tot_ms = sum(m for _, _, m in ms)
         tot_bytes = sum(algorithmic_bytes(info, p) for (_, info, _), p in zip(ms, pairs))

@@ -287,6 +287,13 @@ class StaticStep(object):
         dev = self.points.device
         if self.expected is None:
             raise RuntimeError("StaticStep.warm_up(clouds) must run before the capture")
+        mv = self.voxel_cfg["max_voxel_num"]
+        cap0 = self.B * int(mv[1] if isinstance(mv, (list, tuple)) else mv)
+        if m.backbone.compute_dtype == torch.float32 and cap0 * 8 >= (1 << 23):
+            # the pair-compacting fp32 kernel packs (input row, local row) into 32 bits: 2^23 input rows at most; a capacity
+            # beyond that would send every launch to the slower register kernel
+            raise NotImplementedError("StaticStep: %d x max_voxels gives sparse levels a row capacity >= 2^23 (fp32 kernel limit); "
+                                      "use forward_points or a smaller batch" % self.B)
         cur = torch.cuda.current_stream(dev)
         # a capture stream of its own: hip_ops' scratch buffers are keyed by stream, so two steps never share scratch memory
         cap = torch.cuda.Stream(device=dev)

@@ -1427,3 +1427,27 @@ def test_static_step_full_size_matches_eager(hip):
             k = want[3].max().item()
             assert k > 0 and torch.equal(want[0][:, :, :k], got[0][:, :, :k]) and torch.equal(want[1][:, :, :k], got[1][:, :, :k])
             report("static step full size cloud %d: bit-identical to eager" % i, 0.0, 0.0, "(levels %s)" % levels)
+
+
+def test_static_step_at_the_voxel_cap(hip):
+    """Level 0 exactly full: with max_voxel_num = 3000 a 40k-point cloud hits the voxelizer's cap, so the device count of
+    level 0 equals its row capacity (the boundary of every min(capacity, count) in the capacity launches)."""
+    import copy
+
+    from futuredet_amd.detectors import StaticStep
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, _ = _build_pair("forecast_n0")
+    vg = copy.deepcopy(dict(cfg.voxel_generator))
+    vg["max_voxel_num"] = [3000, 3000]
+    cloud = _dev(synthetic_cloud(seed=3, target_points=40000))
+    step = StaticStep(net, vg, capacity=45056)
+    with torch.no_grad():
+        want = net.forward_points([cloud], vg)
+        levels = list(net.last_level_counts)
+        assert levels[0] == 3000
+        for _ in range(2):
+            got = step([cloud])
+            torch.cuda.synchronize()
+            assert step.level_counts.cpu().tolist() == levels
+            assert torch.equal(want[3], got[3]) and torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
