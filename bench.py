@@ -277,6 +277,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # Result exchange between ranks: the weak-scaling mode (every rank its own stream of sweeps) gathers once, after the last
+    # step, like the reference's eval loop; a strong-scaling step is one global batch whose results are gathered per step.
+    per_step_gather = world > 1 and strong
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))]
     n_fwd = [0]
     pinned = {}  # ring of pinned result buffers (a slot is free again long before the ring wraps: results are retired in order)
@@ -293,7 +296,7 @@ def main():
                 clouds = [resident[s] for s in seeds[mb]] if from_host is None else from_host(si, mb, st)
                 prof.begin(mb)
                 p, c = forward(clouds)
-                if world > 1 and not one_dev:
+                if per_step_gather and not one_dev:
                     parts.append((p, c, None, st))
                 else:
                     slot = n_fwd[0] % ring
@@ -319,24 +322,46 @@ def main():
             cs.append(c)
         p = torch.cat(ps, 0) if len(ps) > 1 else ps[0]
         c = torch.cat(cs, 0) if len(cs) > 1 else cs[0]
-        if world > 1:
+        if per_step_gather:
             p, c = dist_infer.gather_results(p, c)
         return p.cpu().clone(), c.cpu().clone()
 
-    def run_steps(first, count, from_host=None, on_enqueue=None):
-        """Steps first .. first+count-1 with at most len(streams) forward passes in flight; returns the last step's result."""
+    def gather_run(kept):
+        """End-of-run exchange of the weak-scaling mode -- what the reference does (tools/dist_test.py:236-237: one all_gather
+        after the loop): every rank receives every rank's detections of all K steps in one fixed-shape all_gather.  Returns
+        the last step's rows of all ranks."""
+        if world == 1 or per_step_gather or not kept:
+            return kept[-1] if kept else None
+        P = torch.cat([p for p, _ in kept], 0)
+        C = torch.cat([c for _, c in kept], 0)
+        n_local = kept[-1][0].shape[0]
+        if not one_dev:
+            P, C = P.to(dev, non_blocking=True), C.to(dev, non_blocking=True)
+        Pg, Cg = dist_infer.gather_results(P, C)  # sample i * W + r  <-  rank r, local i (i = step * n_local + j)
+        return Pg[-n_local * world:].cpu().clone(), Cg[-n_local * world:].cpu().clone()
+
+    def run_steps(first, count, from_host=None, on_enqueue=None, keep=None):
+        """Steps first .. first+count-1 with at most len(streams) forward passes in flight; returns the last step's result
+        (``keep``: list that receives every step's result)."""
         window, last = [], None
+
+        def retire(parts):
+            r = retire_step(parts)
+            if keep is not None:
+                keep.append(r)
+            return r
+
         depth = max(1, len(streams) // max(1, len(schedule(first))))  # steps in flight (a step may hold several passes)
         for si in range(first, first + count):
             alone = on_enqueue is not None and on_enqueue(si)
             if alone:  # an instrumented step runs with nothing else in flight: its kernel durations are the kernels' own
                 while window:
-                    last = retire_step(window.pop(0))
+                    last = retire(window.pop(0))
             window.append(enqueue_step(si, from_host))
             if alone or len(window) > depth - 1:
-                last = retire_step(window.pop(0))
+                last = retire(window.pop(0))
         while window:
-            last = retire_step(window.pop(0))
+            last = retire(window.pop(0))
         return last
 
     prof_steps = {si for si in range(args.steps) if si % PROF_EVERY == PROF_EVERY // 2} or {args.steps // 2}
@@ -363,7 +388,9 @@ def main():
         run_steps(0, args.warmup)
         sync_all()
         t0 = time.perf_counter()
-        host_p, host_c = run_steps(0, args.steps, on_enqueue=set_prof)
+        kept = []
+        run_steps(0, args.steps, on_enqueue=set_prof, keep=kept)
+        host_p, host_c = gather_run(kept)
         sync_all()
         dt = time.perf_counter() - t0
         prof.enabled = False
@@ -387,7 +414,9 @@ def main():
             run_steps(0, min(2, args.steps), from_host)  # allocate the staging buffers outside the clock
             sync_all()
             t1 = time.perf_counter()
-            run_steps(0, args.steps, from_host)
+            kept = []
+            run_steps(0, args.steps, from_host, keep=kept)
+            gather_run(kept)
             sync_all()
             dt_host = time.perf_counter() - t1
 
@@ -412,7 +441,8 @@ def main():
                                   ("global batch %d over %d rank(s), micro-batch %d, %d passes in flight per GPU" % (args.global_batch, world, B, len(streams))) if strong
                                   else ("%d per GPU per step, %d distinct clouds per GPU in rotation, %d passes in flight per GPU%s" % (B, len(seeds), len(streams), ", each pass one whole-sweep hipGraph replay" if use_graph else "")),
                                   "PointPillars(PillarFeatureNet+Scatter)" if is_pp else "VoxelNet+SpMiddleResNetFHD", args.dtype),
-                   "parallelism": "sample-sharded x%d (no data-path collective; one fixed-shape all_gather of the detections per step)" % world,
+                   "parallelism": "sample-sharded x%d (no data-path collective; one fixed-shape all_gather of the detections %s)"
+                                  % (world, "per step" if per_step_gather or world == 1 else "after the last step, as the reference's eval loop does"),
                    "detections_last_step": int(host_c.sum())},
     }
     if rank == 0 and is_pp:

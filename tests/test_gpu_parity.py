@@ -1273,6 +1273,40 @@ def test_two_ranks_on_one_gpu_equal_single_process(hip, tmp_path):
             _attribute("2 ranks on one GPU: gathered sample %d vs single process" % sid, _rows(got[sid]), _rows(want), cfg.test_cfg)
 
 
+def test_two_ranks_weak_scaling_gathers_once_after_the_run(hip, tmp_path):
+    """The default (weak-scaling) N > 1 mode on a 1-GPU box: each of 2 ranks runs its own stream of sweeps (pool seeds
+    rank * pool + slot) as whole-sweep hipGraphs, results are exchanged by ONE all_gather after the last step (the reference's
+    tools/dist_test.py:236-237); the dump holds the last step's detections of both ranks, rank-interleaved."""
+    import json
+    import subprocess
+    import sys
+
+    from futuredet_amd import dist_infer
+    from futuredet_amd.synth import synthetic_cloud
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = os.path.join(str(tmp_path), "gathered_weak.npz")
+    env = dict(os.environ, FD_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29900 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--points", "30000", "--pool", "2", "--no-cpu-baseline", "--no-host-leg", "--dump", dump]
+    out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 3
+    assert "after the last step" in line["config"]["parallelism"] and "hipGraph" in line["config"]["workload"]
+    g = np.load(dump)
+    got = dist_infer.unpack_results(torch.from_numpy(g["packed"]), torch.from_numpy(g["counts"]))
+    assert len(got) == 2
+    cfg, net, _ = _build_pair("forecast_n0")
+    with torch.no_grad():
+        for r in range(2):  # last step (index 2) uses pool slot 2 % 2 = 0 -> seed (r * pool + 0) * B + 0
+            seed = r * 2
+            want = net.forward_points([_dev(synthetic_cloud(seed=seed, target_points=30000))], cfg.voxel_generator, padded=False)[0]
+            _attribute("2 ranks weak scaling: rank %d last step vs single process" % r, _rows(got[r]), _rows(want), cfg.test_cfg)
+
+
 def test_weights_reload_invalidates_captured_graph(hip):
     """The neck+head hipGraph and the folded / packed weight caches must not survive a weight change: run (graph
     captured), load other weights, run again -- the result must match the oracle with the NEW weights and differ from the
