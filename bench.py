@@ -258,8 +258,8 @@ def main():
 
     # whole-sweep graphs: one StaticStep per stream (VoxelNet without a bev_map input).  Instrumented steps (per-launch HIP
     # events around the sparse convs) cannot run inside a graph and take the eager path.
-    use_graph = (args.graph == 1 or (args.graph < 0 and args.dtype == "fp32")) and not is_pp and bev is None
-    if use_graph and args.dtype == "fp32" and B * args.max_voxels * 8 >= (1 << 23):
+    use_graph = (args.graph == 1 or (args.graph < 0 and args.dtype == "fp32")) and bev is None
+    if use_graph and not is_pp and args.dtype == "fp32" and B * args.max_voxels * 8 >= (1 << 23):
         use_graph = False  # row capacities beyond the fp32 kernel's 2^23 input rows (StaticStep.capture refuses them)
     static_steps = {}
     capacity = (max(len(host[s]) for s in uniq) + 4095) // 4096 * 4096

@@ -151,6 +151,125 @@ __global__ void __launch_bounds__(256) idx_coords(const unsigned long long *__re
     }
 }
 
+// ---- all levels of a pyramid in one set of launches (fd_index_pyramid): the words of every level exist before any prefix is
+//      needed, so the three scan phases and the coordinate pass run once over the concatenated blocks of all levels
+//      (5 levels: 15 + 5 launches of ~5 us each become 3 + 1)
+constexpr int kMaxLevels = 8;
+struct PyramidLevels {
+    int n;
+    int blk0[kMaxLevels + 1];   // first scan block of level l in the fused grid
+    int cblk0[kMaxLevels + 1];  // first coordinate block (256 columns each)
+    const unsigned long long *words[kMaxLevels];
+    int *prefix[kMaxLevels];
+    int *coords[kMaxLevels];
+    IndexGeom geom[kMaxLevels];
+};
+
+__device__ __forceinline__ int level_of(const int *first, int n, int blk) {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxLevels; ++i)
+        if (i < n && blk >= first[i]) l = i;
+    return l;
+}
+
+__global__ void __launch_bounds__(kScanThreads) idx_scan1_ml(PyramidLevels L, int *__restrict__ bsum) {
+    __shared__ int sm[4];
+    const int l = level_of(L.blk0, L.n, blockIdx.x);
+    const unsigned long long *words = L.words[l];
+    const int64_t ncols = L.geom[l].num_cols();
+    int64_t base = (int64_t)(blockIdx.x - L.blk0[l]) * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < ncols) s += __popcll(words[base + k]);
+    int total;
+    block_excl_scan(s, total, sm);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// one workgroup per level
+__global__ void __launch_bounds__(kScanThreads) idx_scan2_ml(PyramidLevels L, int *__restrict__ bsum, int *__restrict__ counts) {
+    __shared__ int sm[4];
+    const int l = blockIdx.x;
+    int *bs = bsum + L.blk0[l];
+    const int nblocks = L.blk0[l + 1] - L.blk0[l];
+    int run = 0;
+    for (int base = 0; base < nblocks; base += kScanThreads) {
+        int j = base + threadIdx.x;
+        int v = j < nblocks ? bs[j] : 0;
+        int total;
+        int e = block_excl_scan(v, total, sm);
+        if (j < nblocks) bs[j] = run + e;
+        run += total;
+    }
+    if (threadIdx.x == 0) counts[l] = run;
+}
+
+__global__ void __launch_bounds__(kScanThreads) idx_scan3_ml(PyramidLevels L, const int *__restrict__ bsum) {
+    __shared__ int sm[4];
+    const int l = level_of(L.blk0, L.n, blockIdx.x);
+    const unsigned long long *words = L.words[l];
+    int *prefix = L.prefix[l];
+    const int64_t ncols = L.geom[l].num_cols();
+    int64_t base = (int64_t)(blockIdx.x - L.blk0[l]) * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int pc[kScanItems];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        pc[k] = (base + k < ncols) ? __popcll(words[base + k]) : 0;
+        s += pc[k];
+    }
+    int total;
+    int e = block_excl_scan(s, total, sm) + bsum[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < ncols) prefix[base + k] = e;
+        e += pc[k];
+    }
+}
+
+__global__ void __launch_bounds__(256) idx_coords_ml(PyramidLevels L) {
+    const int l = level_of(L.cblk0, L.n, blockIdx.x);
+    int *coords = L.coords[l];
+    if (!coords) return;
+    const IndexGeom g = L.geom[l];
+    int64_t col = (int64_t)(blockIdx.x - L.cblk0[l]) * blockDim.x + threadIdx.x;
+    if (col >= g.num_cols()) return;
+    unsigned long long w = L.words[l][col];
+    if (!w) return;
+    int b, y, x;
+    fd::col_to_byx(g, col, b, y, x);
+    int row = L.prefix[l][col];
+    while (w) {
+        int z = __builtin_ctzll(w);
+        w &= w - 1;
+        reinterpret_cast<int4 *>(coords)[row++] = make_int4(b, z, y, x);
+    }
+}
+
+bool fill_levels(PyramidLevels &L, int B, int n_levels, const fd_index_level *levels) {
+    L.n = n_levels;
+    int64_t blk = 0, cblk = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const fd_index_level &lv = levels[l];
+        L.geom[l] = fd::make_geom(B, lv.D, lv.H, lv.W);
+        L.words[l] = (const unsigned long long *)lv.words;
+        L.prefix[l] = lv.prefix;
+        L.coords[l] = lv.coords;
+        L.blk0[l] = (int)blk;
+        L.cblk0[l] = (int)cblk;
+        const int64_t nc = L.geom[l].num_cols();
+        blk += (nc + kScanTile - 1) / kScanTile;
+        cblk += (nc + 255) / 256;
+    }
+    for (int l = n_levels; l <= kMaxLevels; ++l) {
+        L.blk0[l] = (int)blk;
+        L.cblk0[l] = (int)cblk;
+    }
+    return blk < (1ll << 31) && cblk < (1ll << 31);
+}
+
 __device__ inline int lookup_row(const unsigned long long *words, const int *prefix, const IndexGeom &g, int b, int z, int y,
                                  int x) {
     if (z < 0 || z >= g.D || y < 0 || y >= g.H || x < 0 || x >= g.W) return -1;
@@ -273,6 +392,7 @@ extern "C" int64_t fd_index_num_cols(int B, int H, int W) {
 }
 
 extern "C" size_t fd_index_workspace_bytes(int64_t num_cols) {
+    // block sums of one scan; fd_index_pyramid scans all its levels with one set of launches and checks the sum itself
     return fd::align_up(sizeof(int) * (size_t)((num_cols + kScanTile - 1) / kScanTile + 1), 256);
 }
 
@@ -411,19 +531,29 @@ extern "C" int fd_index_pyramid(const int32_t *coords, const int32_t *n_dev, int
             int rc = fd_index_downsample(pv.words, B, pv.D, pv.H, pv.W, lv.ksize, lv.stride, lv.pad, lv.words, stream);
             if (rc != FD_OK) return rc;
         }
-        int rc = fd_index_scan(lv.words, fd_index_num_cols(B, lv.H, lv.W), lv.prefix, counts_dev + l, workspace, workspace_bytes, stream);
-        if (rc != FD_OK) return rc;
     }
-    return FD_OK;
+    PyramidLevels L;
+    FD_REQUIRE(fill_levels(L, B, n_levels, levels), "fd_index_pyramid: grid too large");
+    const int total_blocks = L.blk0[n_levels];
+    if (workspace_bytes < sizeof(int) * (size_t)(total_blocks + 1)) {
+        fd::set_error("fd_index_pyramid: workspace %zu < %zu (block sums of all levels)", workspace_bytes, sizeof(int) * (size_t)(total_blocks + 1));
+        return FD_EWORKSPACE;
+    }
+    int *bsum = (int *)workspace;
+    hipStream_t st = fd::as_stream(stream);
+    hipLaunchKernelGGL(idx_scan1_ml, dim3(total_blocks), dim3(kScanThreads), 0, st, L, bsum);
+    hipLaunchKernelGGL(idx_scan2_ml, dim3(n_levels), dim3(kScanThreads), 0, st, L, bsum, counts_dev);
+    hipLaunchKernelGGL(idx_scan3_ml, dim3(total_blocks), dim3(kScanThreads), 0, st, L, (const int *)bsum);
+    return fd::check_launch("fd_index_pyramid");
 }
 
 extern "C" int fd_index_pyramid_coords(int B, int n_levels, const fd_index_level *levels, fd_stream_t stream) {
     FD_REQUIRE(levels && n_levels >= 1 && n_levels <= 8, "fd_index_pyramid_coords: bad argument");
-    for (int l = 0; l < n_levels; ++l) {
-        const fd_index_level &lv = levels[l];
-        if (!lv.coords) continue;  // empty level
-        int rc = fd_index_coords(lv.words, lv.prefix, B, lv.D, lv.H, lv.W, lv.coords, stream);
-        if (rc != FD_OK) return rc;
-    }
-    return FD_OK;
+    PyramidLevels L;
+    FD_REQUIRE(fill_levels(L, B, n_levels, levels), "fd_index_pyramid_coords: grid too large");
+    bool any = false;
+    for (int l = 0; l < n_levels; ++l) any = any || levels[l].coords != nullptr;  // (NULL: empty level)
+    if (!any) return FD_OK;
+    hipLaunchKernelGGL(idx_coords_ml, dim3(L.cblk0[n_levels]), dim3(256), 0, fd::as_stream(stream), L);
+    return fd::check_launch("fd_index_pyramid_coords");
 }

@@ -257,7 +257,7 @@ class StaticStep(object):
 
     def _version_key(self):
         m = self.model
-        return (weights_version(m), m.backbone.compute_dtype, getattr(m.neck, "use_hip_conv", None))
+        return (weights_version(m), getattr(m.backbone, "compute_dtype", None), m.neck.compute_dtype, getattr(m.neck, "use_hip_conv", None))
 
     def _load(self, clouds):
         assert len(clouds) == self.B
@@ -279,7 +279,7 @@ class StaticStep(object):
         self._load(clouds)
         for _ in range(n):
             self._run(False)
-        self.expected = [int(v) for v in self.model.last_level_counts]
+        self.expected = [int(v) for v in self.model.last_level_counts]  # (empty for PointPillars: no sparse levels)
         self.graph = None
 
     def capture(self):
@@ -289,7 +289,7 @@ class StaticStep(object):
             raise RuntimeError("StaticStep.warm_up(clouds) must run before the capture")
         mv = self.voxel_cfg["max_voxel_num"]
         cap0 = self.B * int(mv[1] if isinstance(mv, (list, tuple)) else mv)
-        if m.backbone.compute_dtype == torch.float32 and cap0 * 8 >= (1 << 23):
+        if getattr(m.backbone, "compute_dtype", None) == torch.float32 and isinstance(m, VoxelNet) and cap0 * 8 >= (1 << 23):
             # the pair-compacting fp32 kernel packs (input row, local row) into 32 bits: 2^23 input rows at most; a capacity
             # beyond that would send every launch to the slower register kernel
             raise NotImplementedError("StaticStep: %d x max_voxels gives sparse levels a row capacity >= 2^23 (fp32 kernel limit); "
@@ -356,7 +356,9 @@ class PointPillars(SingleStageDetector):
         return self.bbox_head.predict(example, preds, self.test_cfg)
 
     @torch.no_grad()
-    def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True):
+    def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True, counts=None, static=False, expected=None):
+        """Same contract as VoxelNet.forward_points.  This path never reads anything back (pillar count and point counts stay on
+        the device), so ``static`` changes nothing here; ``counts`` = device row counts of fixed-capacity cloud buffers."""
         assert not self.training
         mark_stage = getattr(self, "stage_hook", None) or (lambda name: None)
         mark_stage("start")
@@ -367,6 +369,7 @@ class PointPillars(SingleStageDetector):
         max_voxels = int(mv[1] if isinstance(mv, (list, tuple)) else mv)
         max_points = int(voxel_cfg["max_points_in_voxel"])
         ndim = clouds[0].shape[1]
+        self.__dict__["last_level_counts"] = []
         voxels = torch.empty((B * max_voxels, max_points, ndim), dtype=torch.float32, device=dev)
         coors = torch.empty((B * max_voxels, 4), dtype=torch.int32, device=dev)
         npts = torch.empty((B * max_voxels,), dtype=torch.int32, device=dev)
@@ -376,8 +379,11 @@ class PointPillars(SingleStageDetector):
         for b, pts in enumerate(clouds):
             sl = slice(b * max_voxels, (b + 1) * max_voxels)
             hip_ops.voxelize(pts, vs, rng, max_points, max_voxels, batch_idx=b, want_voxels=True, coor_cols=4,
-                             out=dict(voxels=voxels[sl], coors=coors[sl], num_points=npts[sl], num_voxels=nvox[b:b + 1]))
+                             out=dict(voxels=voxels[sl], coors=coors[sl], num_points=npts[sl], num_voxels=nvox[b:b + 1]),
+                             n_points_dev=None if counts is None else counts[b])
         mark_stage("voxelize")
+        if static:
+            self.__dict__["last_level_counts"] = nvox
         for b in range(B):
             sl = slice(b * max_voxels, (b + 1) * max_voxels)
             feats = self.reader(voxels[sl], npts[sl], coors[sl], n_dev=nvox[b:b + 1])

@@ -187,7 +187,7 @@ class _PyramidPlan(object):
         for ks, st, pd in geoms:
             self.shapes.append(tuple((i + 2 * p - (k - 1) - 1) // s + 1 for i, k, s, p in zip(self.shapes[-1], ks, st, pd)))
         self.ncols = [L.fd_index_num_cols(self.B, sh[1], sh[2]) for sh in self.shapes]
-        self.ws_bytes = L.fd_index_workspace_bytes(max(self.ncols))
+        self.ws_bytes = L.fd_index_workspace_bytes(sum(self.ncols) + 2048 * len(self.ncols))  # block sums of all levels at once
 
     def row_caps(self, cap0):
         """Upper bounds of the active rows per level given at most ``cap0`` rows on level 0: a strided convolution turns one

@@ -325,8 +325,8 @@ int fd_forecast_groups(const double *centers3, int n, double match_thresh, int32
  * _coords above, issued back to back): level 0 is marked from the voxelizer's coords of every sample
  * (coords [B * n_max_per_sample, 4], n_dev[b] = voxel count of sample b or NULL), level l > 0 is derived from
  * level l-1 with its ksize/stride/pad (the strided SparseConv3d of scn.py:110,120,130,141); counts_dev[l] receives
- * the active count of level l.  words of every level must be zero-filled by the caller; workspace as for
- * fd_index_scan of the largest level.  fd_index_pyramid_coords materialises coords for the levels whose pointer is
+ * the active count of level l.  words of every level must be zero-filled by the caller; all levels are scanned by one
+ * set of launches: workspace >= fd_index_workspace_bytes(sum of the levels' fd_index_num_cols + 2048 * n_levels).  fd_index_pyramid_coords materialises coords for the levels whose pointer is
  * set (after the host has read the counts and allocated them). */
 typedef struct fd_index_level {
     int32_t D, H, W;

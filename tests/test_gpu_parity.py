@@ -1485,3 +1485,27 @@ def test_static_step_at_the_voxel_cap(hip):
             torch.cuda.synchronize()
             assert step.level_counts.cpu().tolist() == levels
             assert torch.equal(want[3], got[3]) and torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+
+
+def test_static_step_pointpillars(hip):
+    """The PointPillars configs through StaticStep (voxelizer with point slots -> pillar reader -> scatter -> RPN -> head ->
+    decode as one hipGraph on a fixed-capacity cloud buffer): bit-identical to forward_points for clouds of several sizes."""
+    from futuredet_amd import build_detector
+    from futuredet_amd.configs import pointpillars_config
+    from futuredet_amd.detectors import StaticStep
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims
+
+    cfg = pointpillars_config("car")
+    net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    net.load_state_dict(tame_box_dims(seeded_state_dict(net, 7)), strict=False)
+    net = net.cuda().eval()
+    step = StaticStep(net, cfg.voxel_generator, capacity=65536)
+    with torch.no_grad():
+        for i, (seed, n) in enumerate(((3, 30000), (4, 60000), (5, 2000))):
+            c = _dev(synthetic_cloud(seed=seed, target_points=n))
+            want = net.forward_points([c], cfg.voxel_generator)
+            got = step([c])
+            torch.cuda.synchronize()
+            assert torch.equal(want[3], got[3]) and torch.equal(want[0], got[0]) and torch.equal(want[1], got[1]) and torch.equal(want[2], got[2])
+            assert int(want[3].sum()) > 0
+            report("static step PointPillars cloud %d: bit-identical to eager" % i, 0.0, 0.0, "(%d pillars)" % int(step.level_counts.cpu()[0]))
