@@ -428,18 +428,24 @@ int launch_compact(const float *in, const void *wp, const float *bias, const flo
 
 // ---------------------------------------------------------------------------------------------- work-balanced ranges
 // work of an 8-row block in 1/32 of a 16-pair MFMA group: 2 per pair, + 1 per (block, tap) that has pairs (its share of
-// the list padding: half a group per tap and 128-row chunk), + 4 for the per-row cost of prologue / epilogue.
+// the list padding: half a group per tap and 128-row chunk), + kRowCost for the per-row cost of prologue / compaction /
+// epilogue: the phase trace puts those at ~10 groups per 128-row chunk = 20 units per block (swept 4 ... 48: 20-32 is the
+// flat optimum, 128->128 -2.5 %, 64->64 -1 % against the 4 of the first version, which let sparse regions grow ranges past
+// 128 rows, i.e. into a second chunk with its own padding and prologue).  An iterative refinement with the kernel's exact
+// group count per range was tried and is worse (98 ... 156 groups per wave instead of 120 ... 151): the cost of a range
+// jumps by ~23 groups when it crosses 128 rows, which a boundary interpolation cannot follow.
 // One wave covers 64 rows = 8 blocks with one ballot per tap; lane i < 8 accumulates block i.
 constexpr int kWorkRows = 8;
+constexpr int kRowCost = 24;
 __global__ void __launch_bounds__(256) block_work_kernel(const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
-                                                         const int *__restrict__ n_out_dev, unsigned *__restrict__ work) {
+                                                         const int *__restrict__ n_out_dev, unsigned row_cost, unsigned *__restrict__ work) {
     n_out = fd::device_count(n_out, n_out_dev);
     const int n_blocks = (n_out + kWorkRows - 1) / kWorkRows;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t o = wave * 64 + lane;
     if (wave * 8 >= n_blocks) return;
-    unsigned w = 4u;
+    unsigned w = row_cost;
     for (int k = 0; k < K; ++k) {
         const bool v = o < n_out && nbr[(int64_t)k * nbr_stride + o] >= 0;
         const unsigned long long m = __ballot(v);
@@ -538,7 +544,8 @@ extern "C" int fd_spconv_ranges(const int32_t *nbr, int64_t nbr_stride, int K, i
     const int n_blocks = (int)((n_out + kWorkRows - 1) / kWorkRows);
     unsigned *work = (unsigned *)workspace;
     if (n_blocks > 0)
-        hipLaunchKernelGGL(block_work_kernel, dim3((unsigned)((n_blocks + 31) / 32)), dim3(256), 0, stream, nbr, nbr_stride, K, (int)n_out, n_out_dev, work);
+        hipLaunchKernelGGL(block_work_kernel, dim3((unsigned)((n_blocks + 31) / 32)), dim3(256), 0, stream, nbr, nbr_stride, K, (int)n_out, n_out_dev,
+                           (unsigned)(fd::tuning(fd::kTuneV2RowCost) ? fd::tuning(fd::kTuneV2RowCost) : kRowCost), work);
     hipLaunchKernelGGL(range_split_kernel, dim3(1), dim3(1024), 0, stream, work, (int)n_out, n_out_dev, n_ranges, ranges);
     return fd::check_launch("fd_spconv_ranges");
 }
