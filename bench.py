@@ -58,8 +58,8 @@ PRESETS = {  # BASELINE.json configs[1..4]
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.json configs[] preset (1-based as in VERDICT)")
     ap.add_argument("--variant", default="forecast_n0", choices=["forecast_n0", "forecast_n3", "forecast_n3dtf", "pp_n3dtf"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
@@ -88,7 +88,7 @@ def parse():
     return args
 
 
-PROF_EVERY = 25  # instrumented steps of the timed region: si % PROF_EVERY == PROF_EVERY // 2 (or the middle step of a shorter run)
+PROF_EVERY = 100  # instrumented steps of the timed region: si % PROF_EVERY == PROF_EVERY // 2 (or the middle step of a shorter run)
 
 
 class SpconvProfiler(object):
