@@ -252,11 +252,150 @@ inline double tile_cost(int Ho, int Wo, int B, int cout, const TileChoice &c, in
     return (double)rounds * (mb * c.nbw + 0.35);
 }
 
+// ---------------------------------------------------------------------------------------------- pointwise (1x1) convolution
+// A 1x1 convolution is the GEMM [pixels x Cin] x [Cin x Cout] on NHWC rows that are already contiguous: no halo, so no LDS
+// staging at all.  A workgroup takes 16 * NPB consecutive pixels; its four waves take NCB 16-channel blocks each.  Per
+// 16-channel slice a lane loads one float4 of its pixel's row per pixel block (the B operand of the transposed product) and
+// one float4 of packed weights per channel block (A operand, the fd_conv2d_f32_pack_weight layout with one tap), two
+// slices in flight.  Same epilogue as the direct kernel (bias, ReLU, channel-offset / pixel-stride / pixel-shuffle placement).
+// Measured (us): 128->256 at 180 x 180 47 (direct kernel with a 1x1 tap) -> 36; 256->256 at 90 x 90 35 -> 17 (MIOpen: 26 / 16).
+template <int NPB, int NCB>
+__global__ void __launch_bounds__(256) conv1x1_f32(const float *__restrict__ x, const float4 *__restrict__ wp, const float *__restrict__ bias,
+                                                   float *__restrict__ y, ConvParamsF p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int64_t n_px = (int64_t)p.B * p.Ho * p.Wo;
+    const int64_t px0 = (int64_t)blockIdx.x * (16 * NPB);
+    const int nb0 = ((int)blockIdx.y * 4 + wave) * NCB;  // first 16-channel block of this wave
+    if (nb0 * 16 >= p.Cout_pad) return;                   // (no barrier in this kernel)
+    const int nsl = p.Cin / 16;
+    const float *xp[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        int64_t px = px0 + i * 16 + lm;
+        px = px < n_px ? px : n_px - 1;  // padding pixels read the last row; their results are not stored
+        xp[i] = x + px * p.cin_stride + lq * 4;
+    }
+    const float4 *wq[NCB];
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+        const int nb = nb0 + j < (p.Cout_pad >> 4) ? nb0 + j : (p.Cout_pad >> 4) - 1;
+        wq[j] = wp + (int64_t)nb * nsl * 64 + lane;
+    }
+    f32x4 acc[NPB][NCB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 b0[NPB], b1[NPB], a0[NCB], a1[NCB];  // two slices in flight (four measured slower: registers, not latency, bind)
+    auto load = [&](int s, float4(&bb)[NPB], float4(&aa)[NCB]) {
+        const int sc = s < nsl ? s : nsl - 1;
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) bb[i] = *reinterpret_cast<const float4 *>(xp[i] + sc * 16);
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) aa[j] = wq[j][(int64_t)sc * 64];
+    };
+// (one accumulator's four k-steps back to back: measured faster than walking all accumulators per k-step, 36 vs 45 us on
+// 128->256 at 180 x 180)
+#define FD_PW_STEP(BB, AA)                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NPB; ++i) _Pragma("unroll") for (int j = 0; j < NCB; ++j) {                  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].x, BB[i].x, acc[i][j], 0, 0, 0);                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].y, BB[i].y, acc[i][j], 0, 0, 0);                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].z, BB[i].z, acc[i][j], 0, 0, 0);                        \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].w, BB[i].w, acc[i][j], 0, 0, 0);                        \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+    load(0, b0, a0);
+    for (int s = 0; s < nsl; s += 2) {
+        load(s + 1, b1, a1);
+        FD_PW_STEP(b0, a0)
+        if (s + 1 >= nsl) break;
+        load(s + 2, b0, a0);
+        FD_PW_STEP(b1, a1)
+    }
+#undef FD_PW_STEP
+    // epilogue: lane (pixel lm of block i, quad lq) holds channels 16 (nb0 + j) + 4 lq .. + 3 of its pixel
+    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
+    const bool wide = ((p.cout_total | p.co_off) & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+        const int co = (nb0 + j) * 16 + lq * 4;
+        int co_out = co, limit = p.Cout_real, ooy = p.ooy, oox = p.oox;
+        if (co >= p.Cout_real) continue;
+        if (p.cout_sub > 0) {  // pixel shuffle: (sub-convolution, channel)
+            const int sub = co / p.cout_sub;
+            co_out = co - sub * p.cout_sub;
+            limit = p.cout_sub;
+            ooy = sub / p.osx;
+            oox = sub - ooy * p.osx;
+        }
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) {
+            bv.x = bias[co_out];
+            if (co_out + 1 < limit) bv.y = bias[co_out + 1];
+            if (co_out + 2 < limit) bv.z = bias[co_out + 2];
+            if (co_out + 3 < limit) bv.w = bias[co_out + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int64_t px = px0 + i * 16 + lm;
+            if (px >= n_px) continue;
+            const int ox = (int)(px % p.Wo);
+            const int64_t t = px / p.Wo;
+            const int oy = (int)(t % p.Ho);
+            const int64_t b = t / p.Ho;
+            float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const int64_t yy = (int64_t)oy * p.osy + ooy, xx = (int64_t)ox * p.osx + oox;
+            float *dst = y + ((b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co_out;
+            if (wide && co_out + 3 < limit) {
+                *reinterpret_cast<float4 *>(dst) = v;
+            } else {
+                dst[0] = v.x;
+                if (co_out + 1 < limit) dst[1] = v.y;
+                if (co_out + 2 < limit) dst[2] = v.z;
+                if (co_out + 3 < limit) dst[3] = v.w;
+            }
+        }
+    }
+}
+
+// pointwise variants: (pixel blocks, channel blocks per wave); tile ids kNumTiles + 1 ...
+constexpr int kNumPointwise = 4;
+inline int launch_pointwise(const float *x, const void *wp, const float *bias, float *y, const ConvParamsF &p, int variant, hipStream_t stream) {
+    const int64_t n_px = (int64_t)p.B * p.Ho * p.Wo;
+    auto go = [&](auto kern, int npb, int ncb) {
+        dim3 grid((unsigned)((n_px + 16 * npb - 1) / (16 * npb)), (unsigned)((p.Cout_pad / 16 + 4 * ncb - 1) / (4 * ncb)));
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, x, (const float4 *)wp, bias, y, p);
+    };
+    switch (variant) {
+        case 0: go(conv1x1_f32<4, 4>, 4, 4); break;  // 64 pixels x 256 channels per workgroup
+        case 1: go(conv1x1_f32<2, 4>, 2, 4); break;  // 32 x 256
+        case 2: go(conv1x1_f32<4, 2>, 4, 2); break;  // 64 x 128
+        case 3: go(conv1x1_f32<2, 2>, 2, 2); break;  // 32 x 128
+        default: return 0;
+    }
+    return 1;
+}
+
 template <int KS, int S>
 int dispatch_tile(const float *x, const void *wp, const float *bias, float *y, const ConvParamsF &p, int tile, hipStream_t stream) {
     const int n_cu = fd::device_cu_count();
     int best = -1;
     double bc = 1e30;
+    if constexpr (KS == 1) {
+        // plain NHWC input (no channel groups): the pointwise GEMM kernel; tile 0 picks the variant that fills the chip
+        if (p.groups <= 1 && (tile == 0 || tile > kNumTiles)) {
+            int v = tile > kNumTiles ? tile - kNumTiles - 1 : -1;
+            if (v < 0) {
+                const int64_t n_px = (int64_t)p.B * p.Ho * p.Wo;
+                const int wide_wgs = (int)((n_px + 63) / 64) * ((p.Cout_pad / 16 + 15) / 16);
+                v = wide_wgs >= n_cu ? 0 : 3;  // (measured: 128->256 at 180 x 180 -> variant 0, 256->256 at 90 x 90 -> variant 3)
+            }
+            return launch_pointwise(x, wp, bias, y, p, v, stream);
+        }
+    }
     if (tile >= 1 && tile <= kNumTiles) {
         best = tile - 1;  // the caller's choice (e.g. measured once per layer shape by the host plan)
     } else {
@@ -315,7 +454,7 @@ extern "C" int fd_conv2d_f32_pack_weight(const float *w, int cout, int cin, int 
     return FD_OK;
 }
 
-extern "C" int fd_conv2d_f32_num_tiles(void) { return kNumTiles; }
+extern "C" int fd_conv2d_f32_num_tiles(void) { return kNumTiles + kNumPointwise; }  // (the last kNumPointwise ids: 1x1 convolutions only)
 
 extern "C" int fd_conv2d_nhwc_f32(const float *x, int B, int H, int W, int cin, const void *wpacked, const float *bias, int cout, int ks,
                                   int stride, int pad, int relu, float *y, int cout_total, int co_off, int osy, int osx, int ooy, int oox,
@@ -325,7 +464,8 @@ extern "C" int fd_conv2d_nhwc_f32(const float *x, int B, int H, int W, int cin, 
     FD_REQUIRE((ks == 3 && (stride == 1 || stride == 2) && pad == 1) || (ks == 1 && stride == 1 && pad == 0),
                "fd_conv2d_nhwc_f32: supported: 3x3 stride 1|2 pad 1, 1x1 stride 1 pad 0");
     FD_REQUIRE(B > 0 && H > 0 && W > 0 && cout > 0 && osy >= 1 && osx >= 1, "fd_conv2d_nhwc_f32: bad shape");
-    FD_REQUIRE(tile >= 0 && tile <= kNumTiles, "fd_conv2d_nhwc_f32: tile must be 0 (library heuristic) or 1..%d", kNumTiles);
+    FD_REQUIRE(tile >= 0 && tile <= kNumTiles + (ks == 1 ? kNumPointwise : 0), "fd_conv2d_nhwc_f32: tile must be 0 (library heuristic) or 1..%d for this kernel size",
+               kNumTiles + (ks == 1 ? kNumPointwise : 0));
     ConvParamsF p;
     p.B = B; p.H = H; p.W = W; p.Cin = cin;
     p.Ho = (H + 2 * pad - ks) / stride + 1;
@@ -353,7 +493,7 @@ extern "C" int fd_conv2d_shuffle_nhwc_f32(const float *x, int B, int H, int W, i
     FD_REQUIRE(x && wpacked && y, "fd_conv2d_shuffle_nhwc_f32: null argument");
     FD_REQUIRE(cin % 16 == 0 && cin >= 16 && cout_sub > 0 && cout_sub % 4 == 0 && k >= 2 && k <= 4 && B > 0 && H > 0 && W > 0,
                "fd_conv2d_shuffle_nhwc_f32: need cin %% 16 == 0, cout_sub %% 4 == 0, 2 <= k <= 4");
-    FD_REQUIRE(tile >= 0 && tile <= kNumTiles, "fd_conv2d_shuffle_nhwc_f32: tile must be 0..%d", kNumTiles);
+    FD_REQUIRE(tile >= 0 && tile <= kNumTiles + kNumPointwise, "fd_conv2d_shuffle_nhwc_f32: tile must be 0..%d", kNumTiles + kNumPointwise);
     ConvParamsF p;
     p.B = B; p.H = H; p.W = W; p.Cin = cin; p.Ho = H; p.Wo = W;
     p.Cout_real = cout_sub * k * k;

@@ -492,14 +492,14 @@ def test_conv2d_nhwc_bf16_vs_torch(hip, cfg):
 F32_CONV_CASES = [(3, 1, 64, 128, 37, 45, 0), (3, 2, 32, 128, 40, 33, 0), (3, 1, 128, 64, 20, 20, 0), (3, 1, 96, 11, 19, 35, 0),
                   (1, 1, 128, 256, 23, 18, 0), (3, 1, 256, 256, 16, 16, 0), (3, 1, 384, 23, 30, 26, 0)] + \
                  [(3, 1, 48, 70, 29, 31, k) for k in range(1, 17)] + [(3, 2, 16, 130, 33, 27, k) for k in (1, 3, 9, 12, 14)] + \
-                 [(1, 1, 80, 40, 21, 22, k) for k in (2, 10, 13)]
+                 [(1, 1, 80, 40, 21, 22, k) for k in (2, 10, 13, 17, 18, 19, 20)] + [(1, 1, 48, 300, 9, 7, k) for k in (0, 17, 20)]
 
 
 @pytest.mark.parametrize("cfg", F32_CONV_CASES, ids=lambda c: "k%ds%d_%d-%d_%dx%d_t%d" % c)
 def test_conv2d_nhwc_f32_vs_torch(hip, cfg):
     """Hand-written fp32 MFMA conv vs torch conv2d in float64 on the host: partial tiles, stride 2, 1x1, Cout that is not
-    a multiple of 16 / 64, channel-offset (concat) writes, every tile shape of the dispatcher (tile = 1..16 selects one;
-    0 = the library heuristic).  fp32 FMA chains of <= 9 * 384 terms: |d| <= 1e-4 * max(1, |ref|)."""
+    a multiple of 16 / 64, channel-offset (concat) writes, every tile shape of the dispatcher (tile = 1..16 selects one,
+    17..20 the pointwise GEMM variants of a 1x1 convolution; 0 = the library heuristic).  fp32 FMA chains of <= 9 * 384 terms: |d| <= 1e-4 * max(1, |ref|)."""
     ks, stride, cin, cout, H, W, tile = cfg
     rng = np.random.default_rng(cin + cout + H + tile)
     x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32))
@@ -509,7 +509,7 @@ def test_conv2d_nhwc_f32_vs_torch(hip, cfg):
     wpk = hip.pack_conv2d_weight_f32(w).cuda()
     xn = x.cuda().permute(0, 2, 3, 1).contiguous()
     out = torch.full((2, ref.shape[2], ref.shape[3], cout + 5), 7.0, dtype=torch.float32, device="cuda")
-    assert hip.conv2d_f32_num_tiles() == 16
+    assert hip.conv2d_f32_num_tiles() == 20  # 16 direct-kernel tiles + 4 pointwise (1x1 only) variants
     hip.conv2d_nhwc_f32(xn, wpk, b.cuda(), cout, ks, stride, True, out=out, co_off=3, tile=tile)
     got = out[..., 3:3 + cout].permute(0, 3, 1, 2).cpu()
     assert_close("conv2d_nhwc_f32 k%d s%d %d->%d %dx%d tile %d" % cfg, got.numpy(), ref.numpy(), 1e-4)

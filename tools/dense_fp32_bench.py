@@ -48,6 +48,11 @@ for name, cin, cout, hw, ks, st in LAYERS:
     for t in [int(v) for v in args.tiles.split(",")]:
         us = timeit(lambda: hip_ops.conv2d_nhwc_f32(xn, wpk, b, cout, ks, st, True, out=out, tile=t), args.iters)
         line += " | t%d %7.1f us %6.1f TF" % (t, us, fl / us / 1e6)
+    if ks == 1:  # pointwise GEMM variants (tile ids after the direct-kernel tiles) and the direct kernel with one tap (tile 1)
+        nt = hip_ops.conv2d_f32_num_tiles()
+        for t in [1] + list(range(nt - 3, nt + 1)):
+            us = timeit(lambda: hip_ops.conv2d_nhwc_f32(xn, wpk, b, cout, ks, st, True, out=out, tile=t), args.iters)
+            line += " | %s %7.1f us %6.1f TF" % ("direct" if t == 1 else "p%d" % (t - nt + 4), us, fl / us / 1e6)
     if ks == 3 and st == 1:
         wpw = hip_ops.pack_conv2d_weight_wino(w.cpu()).cuda()
         for t in range(1, hip_ops.conv2d_wino_f32_num_tiles() + 1):
