@@ -378,9 +378,12 @@ int pick_rg(int64_t n_out, int cin, int cout) {
 
 }  // namespace
 
+// fp32 32 -> 32: the 32x32x2 fragment layout of fd_spconv_c32.hip follows the 16x16x4 one in the same buffer
+inline bool has_c32_layout(int cin, int cout, int dtype) { return dtype == 0 && cout == 32 && cin == 32; }
+
 extern "C" size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype) {
     if (K <= 0 || cin <= 0 || cout <= 0) return 0;
-    return (size_t)K * cin * cout * (dtype == 0 ? 4 : 2);
+    return (size_t)K * cin * cout * (dtype == 0 ? 4 : 2) * (has_c32_layout(cin, cout, dtype) ? 2 : 1);
 }
 
 extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, int dtype, void *dst) {
@@ -408,6 +411,14 @@ extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, i
                         for (int j = 0; j < 4; ++j)
                             d[((((int64_t)k * NC + c) * NB + nb) * 64 + lane) * 4 + j] =
                                 W(k, 16 * c + 4 * (lane >> 4) + j, 16 * nb + (lane & 15));
+        if (has_c32_layout(cin, cout, dtype)) {  // [K][cin / 8][lane][4]: channel 8 c + 4 (lane / 32) + j, output channel lane % 32
+            float *e = d + (int64_t)K * cin * cout;
+            for (int k = 0; k < K; ++k)
+                for (int c = 0; c < cin / 8; ++c)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 4; ++j)
+                            e[(((int64_t)k * (cin / 8) + c) * 64 + lane) * 4 + j] = W(k, 8 * c + 4 * (lane >> 5) + j, lane & 31);
+        }
     } else if (cin >= 32) {
         FD_REQUIRE(cin % 32 == 0, "fd_spconv_pack_weight: bf16 needs cin 16 or a multiple of 32");
         const int NC = cin / 32;
@@ -440,6 +451,13 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
     if (n_expected <= 0 || n_expected > n_out) n_expected = n_out;  // only steers launch heuristics
     if (n_out == 0) return FD_OK;  // an empty active set (empty cloud): nothing to compute, buffers may be null
     FD_REQUIRE(in_feats && wpacked && nbr && out_feats, "fd_spconv_apply: null argument");
+    if (dtype == 0 && !fd::tuning(fd::kTuneSpconvV1) && has_c32_layout(cin, cout, dtype) && fd::tuning(fd::kTuneSpconvC32) >= 0) {
+        // 32-column layers: 32-pair items on the 32x32x2 MFMA (fd_spconv_c32.hip); its weight layout follows the 16x16x4 one
+        const void *w32 = (const char *)wpacked + (size_t)K * cin * cout * 4;
+        if (fd::spconv_f32_c32_dispatch((const float *)in_feats, w32, bias, (const float *)residual, relu, nbr, nbr_stride, K, n_in, (int)n_out,
+                                        n_out_dev, cin, cout, (float *)out_feats, ranges, n_ranges, fd::as_stream(stream)))
+            return fd::check_launch("fd_spconv_apply(c32)");
+    }
     if (dtype == 0 && !fd::tuning(fd::kTuneSpconvV1)) {
         // fp32 is MFMA-bound: the pair-compacting kernel (fd_spconv_v2.hip) feeds the matrix core no zero rows
         if (fd::spconv_f32_compact_dispatch((const float *)in_feats, wpacked, bias, (const float *)residual, relu, nbr, nbr_stride, K, n_in,

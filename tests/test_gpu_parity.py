@@ -159,6 +159,13 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
         hip.set_tuning(v1_knob, 0)
     for other in ys[1:]:
         assert np.array_equal(ys[0], other), "row-group variants must agree bit for bit (same fma chain per row)"
+    if dtype == "f32" and (cin, cout) == (32, 32):
+        # 32 -> 32 has two pair-compacting kernels: 32-pair items on the 32x32x2 MFMA (default) and 16-pair items on 16x16x4
+        try:
+            hip.set_tuning("spconv_c32", -1)
+            ys.append(run())
+        finally:
+            hip.set_tuning("spconv_c32", 0)
     # oracle in original row order, mapped to index order
     if dtype == "bf16":
         feats = torch.from_numpy(feats).bfloat16().float().numpy()
@@ -173,6 +180,8 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
     tol = 1e-4 if dtype == "f32" else 2e-2
     assert_close("spconv_apply %s %d->%d default kernel vs oracle" % (dtype, cin, cout), y_default, ref_sorted, tol)
     assert_close("spconv_apply %s %d->%d register kernel vs oracle" % (dtype, cin, cout), ys[0], ref_sorted, tol)
+    if dtype == "f32" and (cin, cout) == (32, 32):
+        assert_close("spconv_apply f32 32->32 16-pair compacting kernel vs oracle", ys[-1], ref_sorted, tol)
 
 
 # the four conv geometries of SpMiddleResNetFHD (scn.py:99-143) x channel pairs from 16 to 128
