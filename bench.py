@@ -380,10 +380,15 @@ def main():
                 forward([resident[s] for s in seeds[0]])
                 if use_graph:
                     from futuredet_amd.detectors import StaticStep
-                    step = StaticStep(net, cfg.voxel_generator, capacity, batch_size=B, ndim=host[uniq[0]].shape[1])
-                    step.warm_up([resident[s] for s in seeds[0]])
-                    step.capture()
-                    static_steps[st.cuda_stream] = step
+                    try:
+                        step = StaticStep(net, cfg.voxel_generator, capacity, batch_size=B, ndim=host[uniq[0]].shape[1])
+                        step.warm_up([resident[s] for s in seeds[0]])
+                        step.capture()
+                        static_steps[st.cuda_stream] = step
+                    except Exception as e:  # the eager launches are always available (the line then says so)
+                        print("[bench] whole-sweep graph unavailable (%r); running eager launches" % (e,), file=sys.stderr)
+                        use_graph = False
+                        static_steps.clear()
         torch.cuda.synchronize()
         run_steps(0, args.warmup)
         sync_all()
