@@ -489,7 +489,7 @@ def main():
             "traffic": traffic,
             "achieved_is": "algorithmic gather/scatter bytes B_gs (SURVEY 8d) / launch time, NOT physical HBM bytes; the kernel is fp32-MFMA/issue "
                            "bound -- see mfma and traffic_frac_of_peak",
-            "kernel": "spconv_f32_compact / spconv_bf16 (fd_spconv_apply)", "launches_per_step": launches // max(n_prof, 1),
+            "kernel": "spconv_f32_compact / spconv_f32_c32 / spconv_bf16 (fd_spconv_apply)", "launches_per_step": launches // max(n_prof, 1),
             "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(tot_bytes / max(launches, 1)),
             "compulsory_bytes_per_launch": int(tot_comp / max(launches, 1)),
             "traffic_frac_of_peak": round(traffic / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
