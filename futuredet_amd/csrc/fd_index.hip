@@ -343,16 +343,14 @@ __global__ void __launch_bounds__(256) rows_place(const unsigned long long *__re
 __global__ void __launch_bounds__(256) rulebook_kernel(const unsigned long long *__restrict__ in_words, const int *__restrict__ in_prefix,
                                                        IndexGeom gi, const int *__restrict__ out_coords, const int *__restrict__ n_out_dev,
                                                        int64_t nbr_stride, int fill_tail, DownParams dp, int *__restrict__ nbr) {
-    const int kyx = dp.k[1] * dp.k[2];
     const int n_out = fd::device_count((int)(nbr_stride < 0x7fffffff ? nbr_stride : 0x7fffffff), n_out_dev);
     // rows written: all of the table's row capacity (tail = -1), or only the device's count when the consumers clamp to it
     // themselves (capacity-sized tables of the sync-free step: the launch must not cost what the capacity suggests)
     const int64_t n_rows = fill_tail ? nbr_stride : (int64_t)n_out;
-    const int64_t total = n_rows * kyx;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t o = t % n_rows;  // rows fastest -> coalesced nbr writes
-        const int q = (int)(t / n_rows);
-        const int ky = q / dp.k[2], kx = q % dp.k[2];
+    // blockIdx.y = (ky, kx); rows grid-stride in x (no 64-bit division per element)
+    const int q = blockIdx.y;
+    const int ky = q / dp.k[2], kx = q - ky * dp.k[2];
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_rows; o += (int64_t)gridDim.x * blockDim.x) {
         if (o >= n_out) {
             for (int kz = 0; kz < dp.k[0]; ++kz) nbr[((int64_t)(kz * dp.k[1] + ky) * dp.k[2] + kx) * nbr_stride + o] = -1;
             continue;
@@ -500,11 +498,12 @@ extern "C" int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, i
     FD_REQUIRE(fill_dp(dp, ksize3, stride3, pad3) == 0, "fd_rulebook: unsupported kernel/stride/pad");
     if (nbr_stride <= 0) return FD_OK;
     IndexGeom gi = fd::make_geom(B, Din, Hin, Win);
-    // grid-stride over (row, ky, kx): the launch is bounded, whatever the row capacity of the table
-    int64_t blocks = (nbr_stride * dp.k[1] * dp.k[2] + 255) / 256;
-    const int64_t cap = (int64_t)fd::device_cu_count() * 32;
+    // grid: x = rows (grid-stride, bounded whatever the row capacity of the table), y = (ky, kx)
+    const int kyx = dp.k[1] * dp.k[2];
+    int64_t blocks = (nbr_stride + 255) / 256;
+    const int64_t cap = ((int64_t)fd::device_cu_count() * 32 + kyx - 1) / kyx;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(rulebook_kernel, dim3((unsigned)blocks), dim3(256), 0, fd::as_stream(stream),
+    hipLaunchKernelGGL(rulebook_kernel, dim3((unsigned)blocks, (unsigned)kyx), dim3(256), 0, fd::as_stream(stream),
                        (const unsigned long long *)in_words, in_prefix, gi, out_coords, n_out_dev, nbr_stride, fill_tail, dp, nbr);
     return fd::check_launch("fd_rulebook");
 }
