@@ -433,7 +433,9 @@ int launch_compact(const float *in, const void *wp, const float *bias, const flo
 // flat optimum, 128->128 -2.5 %, 64->64 -1 % against the 4 of the first version, which let sparse regions grow ranges past
 // 128 rows, i.e. into a second chunk with its own padding and prologue).  An iterative refinement with the kernel's exact
 // group count per range was tried and is worse (98 ... 156 groups per wave instead of 120 ... 151): the cost of a range
-// jumps by ~23 groups when it crosses 128 rows, which a boundary interpolation cannot follow.
+// jumps by ~23 groups when it crosses 128 rows, which a boundary interpolation cannot follow; with the ranges capped at
+// 128 rows (one chunk each) the refinement converges but the layer time does not move (348 vs 352 us): the group count per
+// workgroup is not what sets the kernel's duration.
 // One wave covers 64 rows = 8 blocks with one ballot per tap; lane i < 8 accumulates block i.
 constexpr int kWorkRows = 8;
 constexpr int kRowCost = 24;
