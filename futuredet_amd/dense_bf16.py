@@ -9,7 +9,6 @@ Built lazily from the torch modules (so state_dict loading is unchanged) and cac
 import os
 
 import torch
-from torch import nn
 
 from . import hip_ops
 from .nn_utils import fold_stack
