@@ -1518,3 +1518,33 @@ def test_static_step_pointpillars(hip):
             assert torch.equal(want[3], got[3]) and torch.equal(want[0], got[0]) and torch.equal(want[1], got[1]) and torch.equal(want[2], got[2])
             assert int(want[3].sum()) > 0
             report("static step PointPillars cloud %d: bit-identical to eager" % i, 0.0, 0.0, "(%d pillars)" % int(step.level_counts.cpu()[0]))
+
+
+def test_static_step_batch_of_two_random_sizes(hip):
+    """StaticStep with two clouds per sweep (batch column, per-sample voxel counts on the device) over a sequence of random
+    cloud sizes, including an empty sample next to a full one: every replay equals the eager sweep bit for bit."""
+    from futuredet_amd.detectors import StaticStep
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, _ = _build_pair("forecast_n3")
+    rng = np.random.default_rng(5)
+    step = StaticStep(net, cfg.voxel_generator, capacity=49152, batch_size=2)
+    sizes = [(20000, 30000), (45000, 0), (300, 41000), (0, 0), (33000, 33000)] + [tuple(int(v) for v in rng.integers(0, 44000, 2)) for _ in range(5)]
+    with torch.no_grad():
+        for i, (na, nb) in enumerate(sizes):
+            clouds = []
+            for j, n in enumerate((na, nb)):
+                c = _dev(synthetic_cloud(seed=100 + 2 * i + j, target_points=max(n, 300)))
+                clouds.append(c[:n] if n < 300 else c[:min(c.shape[0], 49152)])
+            want = net.forward_points(clouds, cfg.voxel_generator)
+            levels = list(net.last_level_counts)
+            got = step(clouds)
+            torch.cuda.synchronize()
+            assert step.level_counts.cpu().tolist() == levels, (i, step.level_counts.cpu().tolist(), levels)
+            assert torch.equal(want[3], got[3]), (i, want[3], got[3])
+            cw = want[3].cpu().numpy()
+            for b in range(cw.shape[0]):
+                for s_ in range(cw.shape[1]):
+                    k = int(cw[b, s_])
+                    assert torch.equal(want[0][b, s_, :k], got[0][b, s_, :k]) and torch.equal(want[1][b, s_, :k], got[1][b, s_, :k])
+    report("static step B=2, %d random size pairs: bit-identical to eager" % len(sizes), 0.0, 0.0)
