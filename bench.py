@@ -9,15 +9,16 @@ One "step" = one pass of the hot path over one batch of synthetic 10-sweep cloud
 voxelize(+mean) -> sparse indexes/rulebooks -> 21 sparse convs -> densify -> RPN -> CenterHead -> decode + rotated
 NMS -> detections copied to the host.  Workload at N=1: BASELINE.json configs[1] (forecast_n0 cars, one 300k-point
 cloud, fp32).  Consecutive steps process DIFFERENT clouds (a pool of --pool seeds, all staged in HBM before the clock
-starts), so no step finds its own rulebooks / features warm in L2 or the Infinity Cache.  Up to --inflight (default 2)
-forward passes are in flight per GPU, each on its own HIP stream with its own workspaces and its own captured neck+head
-graph: while the host waits for one sweep's five level counts or its detections, the other sweep's kernels keep the GPU
-busy and fill the tails of each other's launches.  Every step still runs start to finish inside the timed region;
+starts), so no step finds its own rulebooks / features warm in L2 or the Infinity Cache.  Up to --inflight (default 4)
+forward passes are in flight per GPU, each on its own HIP stream with its own workspaces and its own captured whole-sweep
+hipGraph (fp32): the sweeps' kernels fill the tails of each other's launches (idle CUs at the end of a kernel, second
+partial rounds of workgroups, single-workgroup kernels).  Every step still runs start to finish inside the timed region;
 ms_per_step is the throughput figure (time / steps), a single sweep's latency is that of --inflight 1.
 Samples are independent, so ranks shard them with no data-path collective: by default every rank processes --batch
 clouds per step (weak scaling); ``--config 4`` is BASELINE configs[3], a global batch of 64 clouds (seeds 0..63) split
-rank-strided like DistributedSampler(shuffle=False) and run in micro-batches of 8 (strong scaling).  Every step's
-detections are gathered to all ranks with one fixed-shape all_gather inside the timed region.
+rank-strided like DistributedSampler(shuffle=False) and run in micro-batches of 8 (strong scaling).  Detections reach
+all ranks through one fixed-shape all_gather inside the timed region: after the last step in the weak-scaling mode (as the
+reference's eval loop does), per step in the strong-scaling mode.
 
 Rank 0 prints ONE JSON line:
   value              sweeps/s, clouds resident in HBM when the clock starts -> detections on the host (the contract's
@@ -66,12 +67,13 @@ def parse():
     ap.add_argument("--points", type=int, default=300000)
     ap.add_argument("--batch", type=int, default=1, help="clouds per rank per forward pass")
     ap.add_argument("--global-batch", type=int, default=0, help=">0: a step = this many clouds in total, split over the ranks (strong scaling)")
-    ap.add_argument("--pool", type=int, default=4, help="distinct clouds per rank to rotate through (weak-scaling mode)")
+    ap.add_argument("--pool", type=int, default=5, help="distinct clouds per rank to rotate through (weak-scaling mode); coprime with --inflight so "
+                    "that a stream does not see the same cloud on consecutive passes")
     ap.add_argument("--graph", type=int, default=-1, help="1: every pass is ONE hipGraph replay of the whole sweep (detectors.StaticStep: no host "
                     "read-back between voxelizer and NMS); 0: eager launches with the one mid-sweep read of the level counts; -1 (default): 1 for "
                     "fp32, 0 for bf16 (measured: the graph gains 2-3 %% on the fp32 sweep and loses 1-3 %% on the bf16 configs, whose "
                     "kernels are short enough for the per-node cost of a graph launch to show)")
-    ap.add_argument("--inflight", type=int, default=2, help="forward passes in flight per GPU, each on its own HIP stream (1 = strictly serial)")
+    ap.add_argument("--inflight", type=int, default=4, help="forward passes in flight per GPU, each on its own HIP stream (1 = strictly serial)")
     ap.add_argument("--channels-last", type=int, default=-1)
     ap.add_argument("--voxel-xy", type=float, default=0.075, help="x/y voxel size (0.05 = the finer grid of BASELINE configs[4])")
     ap.add_argument("--max-voxels", type=int, default=160000)

@@ -5,6 +5,7 @@ d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}
 print('$name', d['value'], d['ms_per_step'], d.get('value_host_to_host'), r.get('spconv_ms_per_step'), r.get('frac'), (r.get('mfma') or {}).get('frac'))"; }
 run default --stage-times
 grep stage $out/default.err | tail -2
+run inflight2 --inflight 2
 run serial --inflight 1 --stage-times
 grep stage $out/serial.err | tail -2
 run nograph --graph 0
