@@ -70,9 +70,9 @@ def parse():
     ap.add_argument("--pool", type=int, default=5, help="distinct clouds per rank to rotate through (weak-scaling mode); coprime with --inflight so "
                     "that a stream does not see the same cloud on consecutive passes")
     ap.add_argument("--graph", type=int, default=-1, help="1: every pass is ONE hipGraph replay of the whole sweep (detectors.StaticStep: no host "
-                    "read-back between voxelizer and NMS); 0: eager launches with the one mid-sweep read of the level counts; -1 (default): 1 for "
-                    "fp32, 0 for bf16 (measured: the graph gains 2-3 %% on the fp32 sweep and loses 1-3 %% on the bf16 configs, whose "
-                    "kernels are short enough for the per-node cost of a graph launch to show)")
+                    "read-back between voxelizer and NMS); 0: eager launches with the one mid-sweep read of the level counts; -1 (default): 1 "
+                    "for micro-batches below 8 clouds (measured with four passes in flight: fp32 +10 %%, bf16 n3 +10 %%, n3dtf +17 %%, "
+                    "PointPillars +60 %%; at 8 clouds per pass the kernels are long enough that the graph changes nothing, -1.6 %%)")
     ap.add_argument("--inflight", type=int, default=4, help="forward passes in flight per GPU, each on its own HIP stream (1 = strictly serial)")
     ap.add_argument("--channels-last", type=int, default=-1)
     ap.add_argument("--voxel-xy", type=float, default=0.075, help="x/y voxel size (0.05 = the finer grid of BASELINE configs[4])")
@@ -260,7 +260,7 @@ def main():
 
     # whole-sweep graphs: one StaticStep per stream (VoxelNet without a bev_map input).  Instrumented steps (per-launch HIP
     # events around the sparse convs) cannot run inside a graph and take the eager path.
-    use_graph = (args.graph == 1 or (args.graph < 0 and args.dtype == "fp32")) and bev is None
+    use_graph = (args.graph == 1 or (args.graph < 0 and B < 8)) and bev is None
     if use_graph and not is_pp and args.dtype == "fp32" and B * args.max_voxels * 8 >= (1 << 23):
         use_graph = False  # row capacities beyond the fp32 kernel's 2^23 input rows (StaticStep.capture refuses them)
     static_steps = {}
