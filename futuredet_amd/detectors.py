@@ -268,8 +268,18 @@ class StaticStep(object):
             self.points[b, :n].copy_(c, non_blocking=True)
             self.counts[b:b + 1].fill_(n)
 
+    def __del__(self):
+        try:
+            hip_ops.workspace.release(id(self))
+        except Exception:
+            pass
+
     def _run(self, static):
         m = self.model
+        if static:  # the captured sweep keeps scratch buffers of its own (not those of whatever stream it is captured on)
+            with hip_ops.workspace.scope(id(self)):
+                return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg,
+                                        counts=[self.counts[b:b + 1] for b in range(self.B)], static=True, expected=self.expected)
         return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, counts=[self.counts[b:b + 1] for b in range(self.B)],
                                 static=static, expected=self.expected)
 

@@ -1,6 +1,7 @@
 """Torch-tensor front end of the C ABI (include/futuredet_hip.h).  Tensors are device memory plumbing only:
 every function passes raw pointers + the current HIP stream to libfuturedet_hip.so.  No CPU fallbacks."""
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -36,14 +37,36 @@ def _p(t):
 
 
 class _Workspace(object):
-    """Grow-only per-(tag, device, stream) scratch buffers so steady-state steps do no allocation.  The stream is part
-    of the key: sweeps in flight on different streams (bench.py --inflight, serving) must not share scratch memory."""
+    """Grow-only per-(tag, device, owner) scratch buffers so steady-state steps do no allocation.  The owner is the current
+    stream -- sweeps in flight on different streams (bench.py --inflight, serving) must not share scratch memory -- or, inside
+    ``with workspace.scope(token)``, the token: a captured whole-sweep graph keeps scratch of its own whatever stream it was
+    captured on (torch hands out streams from a pool, so two captures can meet on one stream handle)."""
 
     def __init__(self):
         self._bufs = {}
+        self._scope = threading.local()
+
+    def scope(self, token):
+        ws = self
+
+        class _Scope(object):
+            def __enter__(self_):
+                self_.prev = getattr(ws._scope, "token", None)
+                ws._scope.token = token
+
+            def __exit__(self_, *exc):
+                ws._scope.token = self_.prev
+
+        return _Scope()
+
+    def release(self, token):
+        """Drops the buffers of a scope (the owner of the token is going away)."""
+        for key in [k for k in self._bufs if k[2] == ("scope", token)]:
+            del self._bufs[key]
 
     def get(self, tag, nbytes, device):
-        key = (tag, device.index, _stream().value)
+        token = getattr(self._scope, "token", None)
+        key = (tag, device.index, ("scope", token) if token is not None else _stream().value)
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
