@@ -90,7 +90,7 @@ def parse():
     return args
 
 
-PROF_EVERY = 100  # instrumented steps of the timed region: si % PROF_EVERY == PROF_EVERY // 2 (or the middle step of a shorter run)
+PROF_EVERY = 100  # instrumented steps of the timed region: the last one and every PROF_EVERY-th before it
 
 
 class SpconvProfiler(object):
@@ -366,10 +366,13 @@ def main():
             last = retire(window.pop(0))
         return last
 
-    prof_steps = {si for si in range(args.steps) if si % PROF_EVERY == PROF_EVERY // 2} or {args.steps // 2}
+    # one instrumented step per PROF_EVERY steps, counted from the END of the timed region: the last step is always one.  An
+    # instrumented step runs alone, i.e. the passes in flight are retired first -- which the end of the run does anyway, so the
+    # last step costs the run only its own un-overlapped time, whatever K the caller asks for
+    prof_steps = {si for si in range(args.steps) if (args.steps - 1 - si) % PROF_EVERY == 0}
 
     def set_prof(si):
-        # The per-launch HIP events of the roofline measurement are taken on every PROF_EVERY-th step of the timed region (one step of a default run).
+        # The per-launch HIP events of the roofline measurement are taken on the last step of the timed region (and every PROF_EVERY-th before it).
         # Such a step runs ALONE (the passes in flight are retired first, the next one starts after it): with two sweeps
         # sharing the GPU a launch's elapsed time contains the other sweep's kernels, which is not the kernel's duration.
         # The drain and the event pairs (~5 us of queue time per launch) are charged to the headline number.
