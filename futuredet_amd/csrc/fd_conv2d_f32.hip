@@ -464,6 +464,8 @@ extern "C" int fd_conv2d_nhwc_f32(const float *x, int B, int H, int W, int cin, 
     FD_REQUIRE((ks == 3 && (stride == 1 || stride == 2) && pad == 1) || (ks == 1 && stride == 1 && pad == 0),
                "fd_conv2d_nhwc_f32: supported: 3x3 stride 1|2 pad 1, 1x1 stride 1 pad 0");
     FD_REQUIRE(B > 0 && H > 0 && W > 0 && cout > 0 && osy >= 1 && osx >= 1, "fd_conv2d_nhwc_f32: bad shape");
+    FD_REQUIRE(co_off >= 0 && co_off + cout <= cout_total, "fd_conv2d_nhwc_f32: channel window [%d, %d) outside the %d output channels", co_off,
+               co_off + cout, cout_total);
     FD_REQUIRE(tile >= 0 && tile <= kNumTiles + (ks == 1 ? kNumPointwise : 0), "fd_conv2d_nhwc_f32: tile must be 0 (library heuristic) or 1..%d for this kernel size",
                kNumTiles + (ks == 1 ? kNumPointwise : 0));
     ConvParamsF p;
@@ -494,6 +496,8 @@ extern "C" int fd_conv2d_shuffle_nhwc_f32(const float *x, int B, int H, int W, i
     FD_REQUIRE(cin % 16 == 0 && cin >= 16 && cout_sub > 0 && cout_sub % 4 == 0 && k >= 2 && k <= 4 && B > 0 && H > 0 && W > 0,
                "fd_conv2d_shuffle_nhwc_f32: need cin %% 16 == 0, cout_sub %% 4 == 0, 2 <= k <= 4");
     FD_REQUIRE(tile >= 0 && tile <= kNumTiles + kNumPointwise, "fd_conv2d_shuffle_nhwc_f32: tile must be 0..%d", kNumTiles + kNumPointwise);
+    FD_REQUIRE(co_off >= 0 && co_off + cout_sub <= cout_total, "fd_conv2d_shuffle_nhwc_f32: channel window [%d, %d) outside the %d output channels",
+               co_off, co_off + cout_sub, cout_total);
     ConvParamsF p;
     p.B = B; p.H = H; p.W = W; p.Cin = cin; p.Ho = H; p.Wo = W;
     p.Cout_real = cout_sub * k * k;
@@ -532,6 +536,8 @@ extern "C" int fd_conv2d_grouped_nhwc_f32(const float *x, int B, int H, int W, i
         p.goff[g] = off;
         off += c;
     }
+    FD_REQUIRE(co_off >= 0 && co_off + off <= cout_total, "fd_conv2d_grouped_nhwc_f32: channel window [%d, %d) outside the %d output channels", co_off,
+               co_off + off, cout_total);
     if (groups == 1) p.groups = 1, p.Cout_real = counts_host[0];
     // one 16-channel block per workgroup: the pixel-split layouts (tile 10 = 8x16 pixels, 12 = 8x8)
     if (tile != 12) tile = 10;

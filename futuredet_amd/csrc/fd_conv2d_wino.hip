@@ -263,16 +263,17 @@ __global__ void __launch_bounds__(256, (TY * TX * NBW <= 16) ? FD_WINO_OCC16 : (
 }
 
 template <int TY, int TX, int NBW>
-void launch_wino(const float *x, const void *wp, const float *bias, float *y, WinoParams p, hipStream_t stream) {
+bool launch_wino(const float *x, const void *wp, const float *bias, float *y, WinoParams p, hipStream_t stream) {
     constexpr int PH = 2 * TY + 2, PW = 2 * TX + 2;
     const size_t lds = (size_t)PH * PW * 64 + (size_t)16 * TY * TX * 64;
     p.tiles_x = (p.W + 2 * TX - 1) / (2 * TX);
     p.tiles_y = (p.H + 2 * TY - 1) / (2 * TY);
     auto kern = conv2d_wino_f32<TY, TX, NBW>;
     static std::atomic<uint64_t> lds_set{0};
-    if (lds > 65536) (void)fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_set);
+    if (lds > 65536 && !fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_set)) return false;
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)((p.Cout_real + 64 * NBW - 1) / (64 * NBW)));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, x, (const float4 *)wp, bias, y, p);
+    return true;
 }
 
 constexpr int kNumWinoTiles = 6;
@@ -324,6 +325,8 @@ extern "C" int fd_conv2d_wino_nhwc_f32(const float *x, int B, int H, int W, int 
     FD_REQUIRE(cin % 16 == 0 && cin >= 16, "fd_conv2d_wino_nhwc_f32: cin must be a multiple of 16 (got %d)", cin);
     FD_REQUIRE(B > 0 && H > 0 && W > 0 && cout > 0, "fd_conv2d_wino_nhwc_f32: bad shape");
     FD_REQUIRE(tile >= 0 && tile <= kNumWinoTiles, "fd_conv2d_wino_nhwc_f32: tile must be 0..%d", kNumWinoTiles);
+    FD_REQUIRE(co_off >= 0 && co_off + cout <= cout_total, "fd_conv2d_wino_nhwc_f32: channel window [%d, %d) outside the %d output channels", co_off,
+               co_off + cout, cout_total);
     WinoParams p;
     p.B = B; p.H = H; p.W = W; p.Cin = cin;
     p.Cout_real = cout;
@@ -332,13 +335,18 @@ extern "C" int fd_conv2d_wino_nhwc_f32(const float *x, int B, int H, int W, int 
     p.tiles_x = p.tiles_y = 0;
     hipStream_t s = fd::as_stream(stream);
     if (tile == 0) tile = 6;  // 8 x 8 pixels x 64 channels, three workgroups per CU: the fastest shape on every RPN / head layer measured
+    bool ok;
     switch (tile) {
-        case 1: launch_wino<4, 8, 2>(x, wpacked, bias, y, p, s); break;   // 8 x 16 pixels x 128 channels, 256 accumulator registers
-        case 2: launch_wino<6, 8, 2>(x, wpacked, bias, y, p, s); break;   // 12 x 16 pixels x 128 channels, 384
-        case 3: launch_wino<4, 8, 1>(x, wpacked, bias, y, p, s); break;   // 8 x 16 pixels x 64 channels, 128
-        case 4: launch_wino<8, 8, 1>(x, wpacked, bias, y, p, s); break;   // 16 x 16 pixels x 64 channels, 256
-        case 5: launch_wino<4, 4, 2>(x, wpacked, bias, y, p, s); break;   // 8 x 8 pixels x 128 channels, 128 (two workgroups per CU)
-        default: launch_wino<4, 4, 1>(x, wpacked, bias, y, p, s); break;  // 8 x 8 pixels x 64 channels, 64 (three per CU)
+        case 1: ok = launch_wino<4, 8, 2>(x, wpacked, bias, y, p, s); break;   // 8 x 16 pixels x 128 channels, 256 accumulator registers
+        case 2: ok = launch_wino<6, 8, 2>(x, wpacked, bias, y, p, s); break;   // 12 x 16 pixels x 128 channels, 384
+        case 3: ok = launch_wino<4, 8, 1>(x, wpacked, bias, y, p, s); break;   // 8 x 16 pixels x 64 channels, 128
+        case 4: ok = launch_wino<8, 8, 1>(x, wpacked, bias, y, p, s); break;   // 16 x 16 pixels x 64 channels, 256
+        case 5: ok = launch_wino<4, 4, 2>(x, wpacked, bias, y, p, s); break;   // 8 x 8 pixels x 128 channels, 128 (two workgroups per CU)
+        default: ok = launch_wino<4, 4, 1>(x, wpacked, bias, y, p, s); break;  // 8 x 8 pixels x 64 channels, 64 (three per CU)
+    }
+    if (!ok) {
+        fd::set_error("fd_conv2d_wino_nhwc_f32: the runtime refused tile %d's dynamic LDS request", tile);
+        return FD_EINVAL;
     }
     return fd::check_launch("fd_conv2d_wino_nhwc_f32");
 }

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(128) det_to_global_kernel(DetArgs a) {
 // every connected component an id; networkx enumerates components in the order of their smallest member, so the id of a
 // box is the rank of its component's smallest index.  One workgroup: min-label propagation over the adjacency
 // (distance_matrix on all three coordinates, float64, numpy's rounding order), then the rank.
-constexpr int kMaxGroupN = 1024;
+constexpr int kMaxGroupN = 8192;  // labels of one (sample, class) live in LDS; a thread owns boxes i, i + 1024, ...
 __device__ inline double dist3d(const double *a, const double *b) {
     const double ad = __dadd_rn(__dadd_rn(__dmul_rn(a[0], a[0]), __dmul_rn(a[1], a[1])), __dmul_rn(a[2], a[2]));
     const double bd = __dadd_rn(__dadd_rn(__dmul_rn(b[0], b[0]), __dmul_rn(b[1], b[1])), __dmul_rn(b[2], b[2]));
@@ -197,23 +197,32 @@ __device__ inline double dist3d(const double *a, const double *b) {
 
 __global__ void __launch_bounds__(1024) forecast_groups_kernel(const double *__restrict__ centers, int n, double thresh, int *__restrict__ ids) {
     __shared__ int s_label[kMaxGroupN];
-    __shared__ int s_changed;
-    const int i = threadIdx.x;
-    if (i < n) s_label[i] = i;
+    constexpr int kPer = kMaxGroupN / 1024;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 1024) s_label[i] = i;
     __syncthreads();
     for (int it = 0; it < n; ++it) {  // a label travels at least one hop per sweep: at most n sweeps
-        if (i == 0) s_changed = 0;
-        __syncthreads();
-        int best = i < n ? s_label[i] : 0;
-        if (i < n)
-            for (int j = 0; j < n; ++j)
-                if (s_label[j] < best && dist3d(centers + (size_t)i * 3, centers + (size_t)j * 3) < thresh) best = s_label[j];
-        __syncthreads();
-        if (i < n && best != s_label[i]) { s_label[i] = best; s_changed = 1; }
-        __syncthreads();
-        if (!s_changed) break;
+        int best[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int i = tid + u * 1024;
+            best[u] = i < n ? s_label[i] : 0;
+            if (i < n)
+                for (int j = 0; j < n; ++j)
+                    if (s_label[j] < best[u] && dist3d(centers + (size_t)i * 3, centers + (size_t)j * 3) < thresh) best[u] = s_label[j];
+        }
+        __syncthreads();  // every read of this sweep is done before a label changes
+        int changed = 0;
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const int i = tid + u * 1024;
+            if (i < n && best[u] != s_label[i]) { s_label[i] = best[u]; changed = 1; }
+        }
+        // the vote IS the barrier: every thread leaves it with the same answer (the flag-in-LDS form let thread 0 reset the
+        // flag for the next sweep while a slower wave had not read it yet)
+        if (!__syncthreads_or(changed)) break;
     }
-    if (i < n) {
+    for (int i = tid; i < n; i += 1024) {
         const int lab = s_label[i];
         int rank = 0;
         for (int r = 0; r < lab; ++r) rank += (s_label[r] == r);

@@ -34,7 +34,7 @@ class _Conv(object):
         # fp32 3x3 stride 1: the Winograd F(2x2,3x3) kernel is the second formulation; its transformed weights are packed too
         self.wino = (dtype == torch.float32 and self.ks == 3 and stride == 1 and USE_WINOGRAD)
         self.wpk_wino = hip_ops.pack_conv2d_weight_wino(w_oihw) if self.wino else None
-        self.choice = {}  # fp32: input shape -> measured-best (formulation, workgroup tile)
+        self.choice = {}  # fp32: input shape -> measured-best workgroup tile of the layer's (fixed) formulation
 
     def _run(self, choice, x, out, co_off, kw):
         kind, tile = choice
@@ -43,8 +43,12 @@ class _Conv(object):
         return self.fn(x, self.wpk, self.bias, self.cout, self.ks, self.stride, self.relu, out=out, co_off=co_off, tile=tile, **kw)
 
     def _pick(self, x, out, co_off, kw):
-        """fp32 only: times every formulation / tile shape once for this layer and input shape (eager calls only -- during a
-        graph capture the defaults are used) and remembers the fastest.  A few milliseconds per layer, once."""
+        """fp32 only: times the workgroup tile shapes of this layer's formulation once per input shape (eager calls only --
+        during a graph capture the default is used) and remembers the fastest.  The FORMULATION is fixed by rule (Winograd
+        for every 3x3 stride-1 layer, direct otherwise): Winograd and direct round differently, so a timing-dependent
+        choice between them would make the network's output bits depend on noise and differ between ranks.  Tile shapes of
+        one formulation give bit-identical results (every output element sums its channels and taps in the same order
+        whatever the tile; tests/test_gpu_parity.py::test_dense_conv_tiles_bit_identical), so only speed is tuned."""
         key = tuple(x.shape)
         c = self.choice.get(key)
         if c is not None:
@@ -54,9 +58,10 @@ class _Conv(object):
             return default
         if out is None:
             out = self._run(default, x, None, co_off, kw)
-        cands = [("direct", t) for t in range(0, hip_ops.conv2d_f32_num_tiles() + 1)]
-        if self.wino and not kw:  # (the Winograd entry point has no pixel-stride placement; 3x3 layers never need it)
-            cands += [("wino", t) for t in range(1, hip_ops.conv2d_wino_f32_num_tiles() + 1)]
+        if default[0] == "wino":  # (the Winograd entry point has no pixel-stride placement; 3x3 layers never need it)
+            cands = [("wino", t) for t in range(0, hip_ops.conv2d_wino_f32_num_tiles() + 1)]
+        else:
+            cands = [("direct", t) for t in range(0, hip_ops.conv2d_f32_num_tiles() + 1)]
         best, best_ms = default, float("inf")
         for cand in cands:
             try:
@@ -173,7 +178,6 @@ class HeadPlan(object):
         self.ff = bool(head.forecast_feature)
         self.tasks = []
         self.pre = []
-        self._cat = None
         for ti, task in enumerate(head.tasks):
             if self.ff:
                 st = fold_stack(task.forecast_conv, torch.float32, False)
@@ -218,13 +222,14 @@ class HeadPlan(object):
         hc = last.cout
         if self.ff:
             B, H, W, _ = x.shape
-            if self._cat is None or self._cat[0].shape[:3] != (B, H, W) or self._cat[0].device != x.device:
-                self._cat = [torch.zeros((B, H, W, 2 * hc), dtype=self.dtype, device=x.device) for _ in range(2)]
-            # task 0 reads [x | feats of the previous frame] through zero weights: clear that half so a non-finite value
-            # of an earlier frame (0 * Inf = NaN) cannot leak into this one
-            self._cat[0][..., hc:].zero_()
-            last(x, out=self._cat[0], co_off=0)
-            self._cat[1][..., :hc].copy_(self._cat[0][..., :hc])
+            # The two concat buffers belong to THIS call: sweeps in flight on other streams (and the graphs captured for
+            # them) must not share them -- a capture takes them from its own graph pool, an eager call from the caching
+            # allocator on its own stream.
+            cat = [torch.empty((B, H, W, 2 * hc), dtype=self.dtype, device=x.device) for _ in range(2)]
+            # task 0 reads [x | uninitialised] through zero weights: clear that half (0 * Inf = NaN otherwise)
+            cat[0][..., hc:].zero_()
+            last(x, out=cat[0], co_off=0)
+            cat[1][..., :hc].copy_(cat[0][..., :hc])
         else:
             x = last(x)
         rets = []
@@ -232,8 +237,8 @@ class HeadPlan(object):
             d = {}
             if self.ff:
                 p0, p1 = self.pre[ti]
-                x = p1(p0(self._cat[ti & 1]))                       # feats_i, contiguous for this task's heads
-                self._cat[(ti + 1) & 1][..., hc:].copy_(x)          # and behind x for the next task's concat
+                x = p1(p0(cat[ti & 1]))                             # feats_i, contiguous for this task's heads
+                cat[(ti + 1) & 1][..., hc:].copy_(x)                # and behind x for the next task's concat
                 d["feats"] = x.permute(0, 3, 1, 2)
             z = c2(c1(x)).permute(0, 3, 1, 2).float()  # [B, sum(couts), H, W]
             o = 0

@@ -318,7 +318,7 @@ int fd_det_to_global_boxes(const float *box3d9, int n, const double *cs_rotation
                            double *quat, double *velocity, float *size, fd_stream_t stream);
 /* multi_future's grouping (det3d/datasets/nuscenes/nuscenes.py:299-339 with network_split :283-297): boxes whose centres
  * (all three coordinates, distance_matrix :100-110) are closer than match_thresh are linked; ids[i] = index of box i's
- * connected component, components numbered by their smallest member (networkx's enumeration order).  n <= 1024. */
+ * connected component, components numbered by their smallest member (networkx's enumeration order).  n <= 8192. */
 int fd_forecast_groups(const double *centers3, int n, double match_thresh, int32_t *ids, fd_stream_t stream);
 
 /* The whole index pyramid of the backbone in one call (the same launches as fd_index_mark / _downsample / _scan /

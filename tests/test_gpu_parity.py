@@ -1548,3 +1548,65 @@ def test_static_step_batch_of_two_random_sizes(hip):
                     k = int(cw[b, s_])
                     assert torch.equal(want[0][b, s_, :k], got[0][b, s_, :k]) and torch.equal(want[1][b, s_, :k], got[1][b, s_, :k])
     report("static step B=2, %d random size pairs: bit-identical to eager" % len(sizes), 0.0, 0.0)
+
+
+def test_static_steps_in_flight_on_two_streams_do_not_share_head_buffers(hip):
+    """the forecast_feature head (n3dtf) lays its concat out in two ping-pong buffers.  They must belong to a
+    call / a captured graph, not to the plan: two StaticSteps on different streams, fed DIFFERENT clouds and replayed
+    concurrently many times, must each reproduce their serial result bit for bit."""
+    from futuredet_amd.detectors import StaticStep
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, _ = _build_pair("forecast_n3dtf")
+    clouds = [_dev(synthetic_cloud(seed=s, target_points=n)) for s, n in ((11, 60000), (12, 25000))]
+    streams = [torch.cuda.Stream() for _ in clouds]
+    steps = [StaticStep(net, cfg.voxel_generator, capacity=65536) for _ in clouds]
+    with torch.no_grad():
+        want = [[t.clone() for t in net.forward_points([c], cfg.voxel_generator)] for c in clouds]
+        for st, s, c in zip(steps, streams, clouds):  # warm-up + capture, serially
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                st.warm_up([c])
+                st([c])
+            s.synchronize()
+        for rep in range(12):
+            outs = []
+            for st, s, c in zip(steps, streams, clouds):
+                with torch.cuda.stream(s):
+                    outs.append([t.clone() for t in st([c])])
+            torch.cuda.synchronize()
+            for i, (w, g) in enumerate(zip(want, outs)):
+                assert torch.equal(w[3], g[3]), (rep, i)
+                k = int(w[3].max())
+                assert k > 0 and torch.equal(w[0][:, :, :k], g[0][:, :, :k]) and torch.equal(w[1][:, :, :k], g[1][:, :, :k]), (rep, i)
+    report("n3dtf: two whole-sweep graphs in flight on two streams, 12 rounds: each bit-identical to its serial result", 0.0, 0.0)
+
+
+def test_dense_conv_tiles_bit_identical(hip):
+    """The fp32 conv plan tunes only the workgroup tile of a layer's fixed formulation: every tile shape of
+    the direct kernel, and every tile shape of the Winograd kernel, must give the same bits (the per-element summation order
+    does not depend on the tile), so a timing-dependent tile choice cannot change results between runs or ranks."""
+    rng = np.random.default_rng(3)
+    for (ks, stride, cin, cout, H, W) in ((3, 1, 64, 128, 37, 45), (3, 2, 32, 128, 40, 33), (1, 1, 128, 256, 23, 18), (3, 1, 128, 70, 30, 26)):
+        x = torch.from_numpy(rng.standard_normal((2, H, W, cin)).astype(np.float32)).cuda()
+        w = torch.from_numpy((rng.standard_normal((cout, cin, ks, ks)) * (2.0 / (cin * ks * ks)) ** 0.5).astype(np.float32))
+        b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).cuda()
+        wpk = hip.pack_conv2d_weight_f32(w).cuda()
+        ref, n_ok = None, 0
+        for tile in range(0, hip.conv2d_f32_num_tiles() + 1):
+            try:
+                y = hip.conv2d_nhwc_f32(x, wpk, b, cout, ks, stride, True, tile=tile)
+            except hip.FutureDetHipError:
+                continue  # (pointwise variants refuse a 3x3 layer and vice versa)
+            ref = y if ref is None else ref
+            assert torch.equal(ref, y), "direct k%d s%d %d->%d: tile %d changes the result" % (ks, stride, cin, cout, tile)
+            n_ok += 1
+        assert n_ok >= 4
+        if ks == 3 and stride == 1:
+            wpw = hip.pack_conv2d_weight_wino(w).cuda()
+            ref = None
+            for tile in range(0, hip.conv2d_wino_f32_num_tiles() + 1):
+                y = hip.conv2d_wino_nhwc_f32(x, wpw, b, cout, True, tile=tile)
+                ref = y if ref is None else ref
+                assert torch.equal(ref, y), "winograd %d->%d: tile %d changes the result" % (cin, cout, tile)
+    report("dense fp32 convs: all tile shapes of one formulation bit-identical", 0.0, 0.0)

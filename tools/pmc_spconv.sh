@@ -22,7 +22,7 @@ for f in sorted(glob.glob("$out/${tag}_spconv_pmc_*.csv")):
     cnt = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
-        if "spconv_f32_compact" not in k:
+        if "spconv_" not in k:
             continue
         k = k.split("(")[0]
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
