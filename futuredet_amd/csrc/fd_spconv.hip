@@ -380,10 +380,12 @@ int pick_rg(int64_t n_out, int cin, int cout) {
 
 // fp32 32 -> 32: the 32x32x2 fragment layout of fd_spconv_c32.hip follows the 16x16x4 one in the same buffer
 inline bool has_c32_layout(int cin, int cout, int dtype) { return dtype == 0 && cout == 32 && cin == 32; }
+// bf16 with 16 input channels: the tap-pair layout of fd_spconv_bf16.hip (two taps stacked along K = 32) follows the 16x16x16 one
+inline int64_t pair_layout_elems(int K, int cin, int cout, int dtype) { return (dtype == 1 && cin == 16) ? (int64_t)((K + 1) / 2) * 32 * cout : 0; }
 
 extern "C" size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype) {
     if (K <= 0 || cin <= 0 || cout <= 0) return 0;
-    return (size_t)K * cin * cout * (dtype == 0 ? 4 : 2) * (has_c32_layout(cin, cout, dtype) ? 2 : 1);
+    return (size_t)K * cin * cout * (dtype == 0 ? 4 : 2) * (has_c32_layout(cin, cout, dtype) ? 2 : 1) + (size_t)pair_layout_elems(K, cin, cout, dtype) * 2;
 }
 
 extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, int dtype, void *dst) {
@@ -437,6 +439,15 @@ extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, i
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 4; ++j)
                         d[(((int64_t)k * NB + nb) * 64 + lane) * 4 + j] = tobf(W(k, 4 * (lane >> 4) + j, 16 * nb + (lane & 15)));
+        // tap pairs [ceil(K/2)][NB][lane][8]: quads 0,1 = channels 0..7 / 8..15 of tap 2u, quads 2,3 = those of tap 2u + 1 (zeros past K)
+        uint16_t *e = d + (int64_t)K * cin * cout;
+        for (int u = 0; u < (K + 1) / 2; ++u)
+            for (int nb = 0; nb < NB; ++nb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int q = lane >> 4, k = 2 * u + (q >> 1);
+                        e[(((int64_t)u * NB + nb) * 64 + lane) * 8 + j] = k < K ? tobf(W(k, 8 * (q & 1) + j, 16 * nb + (lane & 15))) : (uint16_t)0;
+                    }
     }
     return FD_OK;
 }
@@ -463,6 +474,13 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
         if (fd::spconv_f32_compact_dispatch((const float *)in_feats, wpacked, bias, (const float *)residual, relu, nbr, nbr_stride, K, n_in,
                                             (int)n_out, n_out_dev, cin, cout, (float *)out_feats, ranges, n_ranges, fd::as_stream(stream)))
             return fd::check_launch("fd_spconv_apply(compact)");
+    }
+    if (dtype == 1 && fd::tuning(fd::kTuneBf16GP) >= 0) {
+        // bf16: register accumulators + LDS-shared weights (fd_spconv_bf16.hip); 16 input channels read the tap-pair weight layout
+        const void *w = cin == 16 ? (const void *)((const char *)wpacked + (size_t)K * cin * cout * 2) : wpacked;
+        if (fd::spconv_bf16_ws_dispatch(in_feats, w, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out, n_out_dev, n_expected, cin, cout, out_feats,
+                                        fd::as_stream(stream)))
+            return fd::check_launch("fd_spconv_apply(bf16 ws)");
     }
     if (dtype == 1 && cin >= 32 && cout >= 64 && !fd::tuning(fd::kTuneSpconvBf16V1) && n_in * cin * 2 < (1ll << 31)) {
         // bf16, wide layers: column-split workgroups (shared gather through LDS, per-wave weight slices)

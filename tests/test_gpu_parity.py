@@ -1035,7 +1035,7 @@ def test_c_abi_reports_errors_instead_of_exiting(hip):
         ("fd_pillar_encode", lambda: L.fd_pillar_encode(x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 4, 99, 5, 0, ctypes.c_float(1), ctypes.c_float(1),
                                                        ctypes.c_float(0), ctypes.c_float(0), x.data_ptr(), x.data_ptr(), x.data_ptr(), 64, None, None,
                                                        None, 0, 0, x.data_ptr(), 64, None)),
-        ("fd_forecast_groups", lambda: L.fd_forecast_groups(x.data_ptr(), 5000, ctypes.c_double(0.25), x.data_ptr(), None)),
+        ("fd_forecast_groups", lambda: L.fd_forecast_groups(x.data_ptr(), 9000, ctypes.c_double(0.25), x.data_ptr(), None)),
         ("fd_det_to_global_boxes", lambda: L.fd_det_to_global_boxes(x.data_ptr(), 4, (ctypes.c_double * 4)(1, 0, 0, 0), None, None, None, x.data_ptr(),
                                                                    x.data_ptr(), x.data_ptr(), x.data_ptr(), None)),
         ("fd_forecast_chains", lambda: L.fd_forecast_chains(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 99, 8, ctypes.c_double(1.0),
@@ -1610,3 +1610,36 @@ def test_dense_conv_tiles_bit_identical(hip):
                 ref = y if ref is None else ref
                 assert torch.equal(ref, y), "winograd %d->%d: tile %d changes the result" % (cin, cout, tile)
     report("dense fp32 convs: all tile shapes of one formulation bit-identical", 0.0, 0.0)
+
+
+def test_forecast_groups_beyond_one_box_per_thread(hip):
+    """fd_forecast_groups with more boxes than the workgroup has threads (the reference's multi_future has no 1024-box
+    limit; here 8192): connected components of the 'closer than match_thresh' graph, numbered by their smallest member,
+    against scipy's connected_components on the float64 distance matrix.  Chains of up to ~60 boxes exercise the label sweeps."""
+    from scipy.sparse.csgraph import connected_components
+
+    rng = np.random.default_rng(9)
+    for n in (1500, 3000):
+        # clusters of random walks (long chains) plus isolated boxes
+        pts = []
+        while len(pts) < n:
+            L = int(rng.integers(1, 60))
+            p = rng.uniform(-50, 50, 3)
+            for _ in range(L):
+                pts.append(p.copy())
+                p = p + rng.uniform(-0.12, 0.12, 3)
+        c = np.asarray(pts[:n], np.float64)
+        c = c[rng.permutation(n)]
+        d = np.sqrt(np.maximum(((c[:, None] - c[None]) ** 2).sum(-1), 0.0))
+        adj = d < 0.25
+        _, lab = connected_components(adj, directed=False)
+        first = {}
+        for i, l in enumerate(lab):
+            first.setdefault(l, i)
+        order = {l: r for r, l in enumerate(sorted(first, key=first.get))}
+        want = np.array([order[l] for l in lab], np.int32)
+        # pairs within 1e-9 of the threshold could legitimately differ (distance formula): none in this draw
+        assert not (np.abs(d - 0.25) < 1e-9).any()
+        got = hip.forecast_groups(torch.from_numpy(c).cuda(), 0.25).cpu().numpy()
+        assert np.array_equal(got, want), (n, int((got != want).sum()))
+    report("forecast groups, 1500 / 3000 boxes: component ids equal scipy's", 0.0, 0.0)
