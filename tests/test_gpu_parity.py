@@ -124,8 +124,9 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
     """fd_spconv_apply (+bias +residual +relu) vs the oracle's pair-list indice_conv, element-wise
     |d| <= tol * max(1, |ref|): fp32 1e-4 (north_star allows 1e-3; an fp32 FMA chain of 27*cin terms lands near 1e-6),
     bf16 (config 3) 2e-2.  Every kernel variant is run: fp32 = the pair-compacting kernel (default) and the
-    register-resident kernel at 1 / 2 / 4 row groups per wave; bf16 = column-split (default where it applies) and the
-    register kernel.  Variants of one kernel agree bit for bit; different kernels agree within the tolerance."""
+    register-resident kernel at 1 / 2 / 4 row groups per wave; bf16 = the LDS-shared-weights kernel (default; 1-4 row groups per
+    wave x ring depth 2 / 4), the column-split kernel and the register kernel.  Variants of one kernel agree bit for bit;
+    different kernels agree within the tolerance."""
     from oracle import ops as oops
 
     rng = np.random.default_rng(cin * 7 + cout)
@@ -147,9 +148,22 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
     wpk = hip.pack_spconv_weight(torch.from_numpy(w), tdt).cuda()
     run = lambda: hip.spconv_apply(x, wpk, _dev(bias), nbr, src.n, cout, residual=res, relu=True).float().cpu().numpy()  # noqa: E731
     v1_knob = "spconv_v1" if dtype == "f32" else "spconv_bf16_v1"
+    y_ws = []
     try:
         y_default = run()
-        hip.set_tuning(v1_knob, 1)
+        if dtype == "bf16":
+            # the round-3 kernel (fd_spconv_bf16.hip): rows per wave x gather-ring depth variants must agree bit for bit with
+            # the default (fixed summation order: taps ascending, channel chunks ascending)
+            for rg in (1, 2, 3, 4):
+                for depth in (2, 4):
+                    hip.set_tuning("bf16_rg", rg)
+                    hip.set_tuning("bf16_depth", depth)
+                    y_ws.append(run())
+            hip.set_tuning("bf16_rg", 0)
+            hip.set_tuning("bf16_depth", 0)
+            hip.set_tuning("bf16_gp", -1)  # the older kernels: column split (default where it applies) ...
+            y_old = run()
+        hip.set_tuning(v1_knob, 1)          # ... and the register kernel
         ys = []
         for rg in (1, 2, 4):  # every row-group variant of the register kernel
             hip.set_tuning("spconv_rg", rg)
@@ -157,6 +171,11 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
     finally:
         hip.set_tuning("spconv_rg", 0)
         hip.set_tuning(v1_knob, 0)
+        hip.set_tuning("bf16_rg", 0)
+        hip.set_tuning("bf16_depth", 0)
+        hip.set_tuning("bf16_gp", 0)
+    for other in y_ws:
+        assert np.array_equal(y_default, other), "bf16: rows-per-wave / ring-depth variants must agree bit for bit"
     for other in ys[1:]:
         assert np.array_equal(ys[0], other), "row-group variants must agree bit for bit (same fma chain per row)"
     if dtype == "f32" and (cin, cout) == (32, 32):
@@ -180,6 +199,8 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
     tol = 1e-4 if dtype == "f32" else 2e-2
     assert_close("spconv_apply %s %d->%d default kernel vs oracle" % (dtype, cin, cout), y_default, ref_sorted, tol)
     assert_close("spconv_apply %s %d->%d register kernel vs oracle" % (dtype, cin, cout), ys[0], ref_sorted, tol)
+    if dtype == "bf16":
+        assert_close("spconv_apply bf16 %d->%d round-2 kernel vs oracle" % (cin, cout), y_old, ref_sorted, tol)
     if dtype == "f32" and (cin, cout) == (32, 32):
         assert_close("spconv_apply f32 32->32 16-pair compacting kernel vs oracle", ys[-1], ref_sorted, tol)
 

@@ -16,7 +16,18 @@ def arg(name, default):
     return args[args.index(name) + 1] if name in args else default
 
 
-key = "%s/%s/%s/b%s" % (arg("--variant", "forecast_n0"), arg("--dtype", "fp32"), arg("--points", "300000"), arg("--batch", "1"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (the presets behind --config and the kernel-source fingerprint)
+
+preset = bench.PRESETS.get(int(arg("--config", "0")), {})
+
+
+def opt(name, field, default):  # an explicit flag wins over the preset, as in bench.py
+    return arg(name, preset.get(field, default))
+
+
+key = "%s/%s/%s/b%s" % (opt("--variant", "variant", "forecast_n0"), opt("--dtype", "dtype", "fp32"), opt("--points", "points", "300000"),
+                        opt("--batch", "batch", "1"))
 SIMDS = 1024
 XCCS = 8  # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs; MfmaUtil's denominator is its per-XCD maximum (~ sum / 8)
 
@@ -99,4 +110,11 @@ print(json.dumps({key: rec}, indent=1))
 path = os.path.join(out, "%s_pmc.json" % tag)
 old = json.load(open(path)) if os.path.isfile(path) else {}
 old[key] = rec
+# the kernel sources these counters belong to (bench.py reports them only for the same fingerprint); tools/publish_profiles.py adds the commit
+sha = bench.kernel_sources_sha16()
+if old.get("_meta", {}).get("csrc_sha16") not in (None, sha):
+    old = {key: rec}  # records of other sources do not mix
+old["_meta"] = {"csrc_sha16": sha, "commit": None,
+                "how": "tools/pmc_round.sh: rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES} -- python bench.py "
+                       "<workload flags> --inflight 1 --graph 0 --steps 4 --warmup 2; FETCH_SIZE x2 (gfx950 wide-read correction); last two passes"}
 json.dump(old, open(path, "w"), indent=1)

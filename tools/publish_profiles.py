@@ -17,6 +17,27 @@ for name in ("bench_default.json", "bench_profiled.json", "bench_serial_profiled
         shutil.copyfile(p, os.path.join(dst, "%s_%s" % (rnd, name)))
     else:
         print("missing", p)
+# stamp the PMC record with the commit it is published at (the GPU box has no .git); several tags may be merged into one file
+pj = os.path.join(dst, "%s_pmc.json" % rnd)
+if os.path.isfile(pj):
+    import json
+    import subprocess
+
+    d = json.load(open(pj))
+    extra = sys.argv[3:]  # further tags whose records (same kernel sources) are merged in
+    for t in extra:
+        q = os.path.join(src, "%s_pmc.json" % t)
+        if os.path.isfile(q):
+            e = json.load(open(q))
+            if e.get("_meta", {}).get("csrc_sha16") == d.get("_meta", {}).get("csrc_sha16"):
+                d.update({k: v for k, v in e.items() if k != "_meta"})
+            else:
+                print("not merged (different kernel sources):", q)
+    try:
+        d.setdefault("_meta", {})["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=root).decode().strip()
+    except Exception:
+        pass
+    json.dump(d, open(pj, "w"), indent=1)
 if os.path.isfile(os.path.join(src, "parity_report.txt")):
     shutil.copyfile(os.path.join(src, "parity_report.txt"), os.path.join(dst, "%s_parity_report.txt" % rnd))
 
