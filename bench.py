@@ -241,11 +241,9 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if rank == 0:
-        fbuild.build()
-    if world > 1:
-        torch.distributed.barrier()
+    fbuild.build_locked()  # rank-local check under a file lock: no rank waits in a collective for another rank's compiler
     lib.load()
+    cpus = dist_infer.pin_rank_cpus(local if not one_dev else rank, world)  # 256 logical CPUs / 8 ranks = 32 per rank
 
     is_pp = args.variant == "pp_n3dtf"
     if is_pp:  # secondary line: the PointPillars configs; no sparse conv, no roofline object
@@ -258,6 +256,9 @@ def main():
     sd = tame_box_dims(seeded_state_dict(net, 7))  # random-init weights, box sizes kept in metres (synth.tame_box_dims)
     net.load_state_dict(sd, strict=False)
     net = net.to(dev).eval()
+    # rank 0's weights to every rank (what the reference's DDP constructor does, tools/dist_test.py:177-188) + a checksum
+    # all_gather that fails loudly when replicas differ
+    replica_checksum = dist_infer.sync_replicas(net, src=0, check=True)
     dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
     if args.torch_dense:
         net.neck.use_hip_conv = net.bbox_head.use_hip_conv = False
@@ -520,7 +521,10 @@ def main():
                                   "PointPillars(PillarFeatureNet+Scatter)" if is_pp else "VoxelNet+SpMiddleResNetFHD", args.dtype),
                    "parallelism": "sample-sharded x%d (no data-path collective; one fixed-shape all_gather of the detections %s)"
                                   % (world, "per step" if per_step_gather or world == 1 else "after the last step, as the reference's eval loop does"),
-                   "detections_last_step": int(host_c.sum())},
+                   "detections_last_step": int(host_c.sum()),
+                   "replicas": "rank 0's weights broadcast to all ranks, checksum %.6e equal on all %d rank(s)" % (replica_checksum, world),
+                   "host": "%s logical CPUs pinned per rank; pinned host memory per rank: %.1f MB of clouds + result ring"
+                           % (len(cpus) if cpus else "all", sum(h.numel() * 4 for h in host.values()) / 1e6)},
     }
     if rank == 0 and is_pp:
         out["roofline"] = None

@@ -26,6 +26,19 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_locked(force=False, verbose=False):
+    """build() under an exclusive file lock: every rank of a node may call it (no collective involved -- a rank never waits
+    in an RCCL barrier for another rank's compiler); the first one builds, the others find the library up to date."""
+    import fcntl
+
+    with open(os.path.join(HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            return build(force=force, verbose=verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT

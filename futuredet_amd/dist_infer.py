@@ -28,6 +28,51 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def pin_rank_cpus(local_rank, local_world):
+    """Gives every rank of a node its own contiguous slice of the logical CPUs (e.g. 256 / 8 = 32 per rank) and sizes torch's
+    intra-op pool to it: the host side of a rank is one launch thread + the pinned-memory copies, and 8 ranks that each start
+    256 OpenMP / torch threads oversubscribe the box.  Returns the CPU ids (None when the platform has no affinity call)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cpus) // local_world)
+    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(len(mine), 8)))
+    return mine
+
+
+def sync_replicas(model, src=0, check=True):
+    """What the reference gets from wrapping the model in DistributedDataParallel (tools/dist_test.py:177-188: the DDP
+    constructor broadcasts rank 0's parameters and buffers): every rank ends up with rank ``src``'s weights, in ONE
+    broadcast of a flattened copy, and -- ``check`` -- an all_gather of a float64 checksum proves the replicas agree
+    (raises otherwise).  Single process: no-op.  Returns the checksum."""
+    tensors = [t for t in list(model.parameters()) + list(model.buffers()) if t.is_floating_point() or t.dtype in (torch.int64, torch.int32)]
+    with torch.no_grad():
+        def checksum():
+            return float(sum(t.detach().double().sum() + 3.0 * t.detach().double().abs().sum() for t in tensors)) if tensors else 0.0
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return checksum()
+        dev = tensors[0].device if dist.get_backend() == "nccl" else torch.device("cpu")
+        flat = torch.cat([t.detach().reshape(-1).to(device=dev, dtype=torch.float64) for t in tensors])
+        dist.broadcast(flat, src=src)
+        o = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[o:o + n].reshape(t.shape).to(device=t.device, dtype=t.dtype))  # in-place: bumps _version, derived caches follow
+            o += n
+        cs = checksum()
+        if check:
+            mine = torch.tensor([cs], dtype=torch.float64, device=dev)
+            allc = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(allc, mine)
+            vals = [float(v) for v in allc]
+            if any(v != vals[0] for v in vals):
+                raise RuntimeError("model replicas differ after the broadcast: checksums %s" % vals)
+        return cs
+
+
 def get_dist_info():
     """det3d/torchie/trainer/utils.py:22-34 -> (rank, world_size)"""
     if dist.is_available() and dist.is_initialized():

@@ -1664,3 +1664,59 @@ def test_forecast_groups_beyond_one_box_per_thread(hip):
         got = hip.forecast_groups(torch.from_numpy(c).cuda(), 0.25).cpu().numpy()
         assert np.array_equal(got, want), (n, int((got != want).sum()))
     report("forecast groups, 1500 / 3000 boxes: component ids equal scipy's", 0.0, 0.0)
+
+
+def _run_bench_ranks(tmp_path, n, extra, name, timeout=1500):
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = os.path.join(str(tmp_path), name + ".npz")
+    env = dict(os.environ, FD_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 30100 + (os.getpid() % 700)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", str(n), "--no-cpu-baseline", "--no-host-leg", "--dump", dump] + extra
+    out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    return line, np.load(dump)
+
+
+def test_eight_ranks_on_one_gpu_weak_scaling(hip, tmp_path):
+    """VERDICT r2 #7b: the driver's `--gpus 8` command shape with 8 ranks sharing cuda:0 (collectives over gloo): 8 processes, rank-local
+    build check, rank-0 weight broadcast + checksum, per-rank CPU slices, whole-sweep graphs per rank, ONE gather after the last
+    step.  The last step's detections of all 8 ranks equal single-process runs of the same seeds."""
+    from futuredet_amd import dist_infer
+    from futuredet_amd.synth import synthetic_cloud
+
+    line, g = _run_bench_ranks(tmp_path, 8, ["--steps", "3", "--warmup", "1", "--points", "20000", "--pool", "2", "--inflight", "2"], "weak8")
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["steps"] == 3 and line["value"] > 0
+    assert "checksum" in line["config"]["replicas"] and "all 8 rank" in line["config"]["replicas"]
+    got = dist_infer.unpack_results(torch.from_numpy(g["packed"]), torch.from_numpy(g["counts"]))
+    assert len(got) == 8
+    cfg, net, _ = _build_pair("forecast_n0")
+    with torch.no_grad():
+        for r in range(8):  # last step (index 2) uses pool slot 0 -> seed (r * pool + 0) * B
+            want = net.forward_points([_dev(synthetic_cloud(seed=r * 2, target_points=20000))], cfg.voxel_generator, padded=False)[0]
+            _attribute("8 ranks weak scaling: rank %d last step vs single process" % r, _rows(got[r]), _rows(want), cfg.test_cfg)
+
+
+def test_eight_ranks_on_one_gpu_config4_strong_scaling(hip, tmp_path):
+    """BASELINE configs[3] in the shape the driver would launch it (`--config 4 --gpus 8`: forecast_n3 bf16, global batch 64 = seeds
+    0..63 split rank-strided, micro-batches of 8 per rank, per-step gather), with smaller clouds so that eight processes share one
+    GPU: the 64 gathered samples come back in global order and equal a single-process bf16 run of the same seeds."""
+    from futuredet_amd import dist_infer
+    from futuredet_amd.synth import synthetic_cloud
+
+    line, g = _run_bench_ranks(tmp_path, 8, ["--config", "4", "--points", "15000", "--steps", "1", "--warmup", "1", "--inflight", "1"], "strong8")
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["dtype"] == "bf16" and "global batch 64 over 8" in line["config"]["workload"]
+    got = dist_infer.unpack_results(torch.from_numpy(g["packed"]), torch.from_numpy(g["counts"]))
+    assert len(got) == 64
+    cfg, net, _ = _build_pair("forecast_n3")
+    net.set_precision(torch.bfloat16)
+    with torch.no_grad():
+        for sid in (0, 1, 7, 8, 9, 31, 63):  # rank sid % 8, local sample sid // 8
+            want = net.forward_points([_dev(synthetic_cloud(seed=sid, target_points=15000))], cfg.voxel_generator, padded=False)[0]
+            a, b = _rows(got[sid]), _rows(want)
+            assert a.shape == b.shape and np.array_equal(a, b), "sample %d of the 8-rank run differs from the single-process bf16 run" % sid
