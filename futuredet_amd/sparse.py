@@ -121,17 +121,13 @@ class SparseConvolution(SparseModule):
         hit = self._packed.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
-        scale = shift = None
-        if bn is not None:
-            from .nn_utils import bn_affine
-
-            scale, shift = bn_affine(bn)
         K = int(np.prod(self.kernel_size))
         w = self.weight.detach().float().reshape(K, self.in_channels, self.out_channels)
         b = self.bias.detach().float() if self.bias is not None else None
-        if scale is not None:
-            w = w * scale.view(1, 1, -1)
-            b = (b * scale if b is not None else torch.zeros_like(scale)) + shift
+        if bn is not None:
+            from .nn_utils import fold_bn
+
+            w, b = fold_bn(w, b, bn, 2)
         cin_p, cout_p = pad_channels(self.in_channels), pad_channels(self.out_channels)
         wp = torch.zeros((K, cin_p, cout_p), dtype=torch.float32, device=w.device)
         wp[:, : self.in_channels, : self.out_channels] = w

@@ -90,14 +90,16 @@ def match_rows(got, want, tol=1e-3):
     return [int(i) for i in np.nonzero(d.min(1) > tol)[0]], [int(i) for i in np.nonzero(d.min(0) > tol)[0]]
 
 
-def attribute_detection_diffs(name, got, want, iou_fn, score_thr, iou_thr, n_box=9, max_frac=0.02, iou_eps=IOU_EPS_E2E, topk_cut=None):
+def attribute_detection_diffs(name, got, want, iou_fn, score_thr, iou_thr, n_box=9, max_frac=0.02, iou_eps=IOU_EPS_E2E, topk_cut=None,
+                              row_tol=1e-3, score_eps=SCORE_EPS, topk_eps=TOPK_EPS):
     """got / want: [K, n_box + 2] rows (box, score, label).  Every row without a counterpart within 1e-3 must be
     explained by (a) a score within SCORE_EPS of the threshold or within TOPK_EPS of ``topk_cut`` (the nms_pre_max-th best
     candidate score of the oracle, when more than nms_pre_max cells pass the threshold), (b) an IoU within ``iou_eps`` of the
     NMS threshold with a box of the same label -- or an IoU that crosses the threshold when an angle moves by one ulp --, or (c) an IoU above the threshold with another unmatched row that is itself explained (the
     cascade of (a)/(b): its suppressor appeared or vanished; every chain must start at a root of kind (a) or (b)).
+    ``row_tol`` / ``score_eps`` / ``topk_eps`` default to the fp32 values; the bf16 comparisons pass the eps that a 2e-2 map error implies.
     Returns the number of unmatched rows."""
-    ug, uw = match_rows(got, want)
+    ug, uw = match_rows(got, want, row_tol)
     n_un = len(ug) + len(uw)
     report(name + " detections", float(n_un), max_frac * (len(got) + len(want)), "(unmatched rows of %d + %d)" % (len(got), len(want)))
     if n_un == 0:
@@ -108,7 +110,7 @@ def attribute_detection_diffs(name, got, want, iou_fn, score_thr, iou_thr, n_box
     # roots: rows that sit at a decision boundary themselves
     explained = []
     for side, row in unmatched:
-        root = abs(float(row[n_box]) - score_thr) <= SCORE_EPS or (topk_cut is not None and abs(float(row[n_box]) - topk_cut) <= TOPK_EPS)
+        root = abs(float(row[n_box]) - score_thr) <= score_eps or (topk_cut is not None and abs(float(row[n_box]) - topk_cut) <= topk_eps)
         if not root:
             same = allrows[lab == row[n_box + 1]]
             a, b = nms_layout(row[None, :n_box]), nms_layout(same[:, :n_box])

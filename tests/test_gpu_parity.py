@@ -1128,24 +1128,265 @@ def _hip_maps(net, cfg, v, c, n):
         return bb, net.neck(bb)
 
 
-def _check_bf16_vs_fp32_oracle(tag, got, x, want, obev):
-    """bf16 carries 8 mantissa bits through ~45 layers: the BEV map must agree within 4e-2 of its scale, and the detections
-    that the oracle scores well clear of the threshold must be found at the same place (0.3 m) by the bf16 path."""
-    scale = float(obev.abs().max())
-    err = float((x.float().cpu() - obev).abs().max()) / scale
-    report(tag + " bf16 BEV map vs fp32 oracle (of scale)", err, 4e-2)
-    assert err <= 4e-2
-    wb, ws, wl = want["box3d_lidar"].numpy(), want["scores"].numpy(), want["label_preds"].numpy()
-    gb, gl = got["box3d_lidar"].float().cpu().numpy(), got["label_preds"].cpu().numpy()
-    assert len(gb) > 0.8 * len(wb)
-    strong = ws > 0.3
-    assert strong.sum() > 20
-    found = 0
-    for b, l in zip(wb[strong], wl[strong]):
-        d = np.abs(gb[gl == l][:, :2] - b[:2]).max(1) if (gl == l).any() else np.array([9.0])
-        found += d.min() < 0.3
-    report(tag + " bf16 strong detections found", float(strong.sum() - found), 0.1 * strong.sum(), "(missing of %d)" % strong.sum())
-    assert found >= 0.9 * strong.sum(), (found, strong.sum())
+BF16_ULP = 8e-3  # one bf16 ulp relative to the value (2^-8 .. 2^-7): the bound for a layer fed IDENTICAL inputs
+
+
+def _bf16_example(cfg, cloud):
+    from oracle import ops as oops
+
+    vg = cfg.voxel_generator
+    v, c, n = oops.points_to_voxel(cloud, vg["voxel_size"], vg["range"], vg["max_points_in_voxel"], True, vg["max_voxel_num"][1])
+    ex = dict(voxels=torch.from_numpy(v), coordinates=torch.from_numpy(np.pad(c, ((0, 0), (1, 0)))), num_points=torch.from_numpy(n),
+              num_voxels=torch.tensor([len(n)]), shape=np.array([_grid_of(vg)]), metadata=[None])
+    return v, c, n, ex
+
+
+def _check_bf16(tag, cfg, net, onet, cloud, got, min_rows=20):
+    """The HIP bf16 path end to end against the oracle's bf16 configuration (oracle/bf16.py: weights and per-layer activations
+    rounded to bf16, fp32 accumulate) on one cloud.  Element-wise equality to a tolerance cannot be asked of ~45 chained bf16
+    layers: the two implementations sum in different orders, so a pre-rounding value near a rounding boundary rounds differently
+    (one ulp, 2^-8 relative), and downstream layers amplify such flips (measured: 1 ulp after stage 1, 5e-2 after stage 2,
+    0.3 on a few elements of the 128-channel stage, 0.8 on single elements of the neck output).  What IS asserted here: the
+    DISTRIBUTION of the deviation (mean <= 3e-2, 70 % of the active elements within 2e-2 * max(1, |ref|); achieved: mean 2e-3 .. 1.2e-2,
+    88-99 %, growing with the size of the cloud) for the backbone BEV, the neck output and every head map, and that the detections
+    agree except for attributed near-threshold decisions.  The element-wise bound (one ulp) is asserted per LAYER with identical
+    inputs in test_bf16_every_layer_teacher_forced; the decode on identical maps in test_bf16_decode_on_identical_maps.
+    The distance to the fp32 oracle is reported (it measures bf16 itself)."""
+    from oracle import bf16 as obf
+    from oracle import ops as oops
+
+    v, c, n, ex = _bf16_example(cfg, cloud)
+    obb, obev, opreds, odet = obf.run(onet, ex, cfg.test_cfg)
+    with torch.no_grad():
+        feats32 = onet.reader(ex["voxels"], ex["num_points"])
+        fbb, _ = onet.backbone(feats32, ex["coordinates"], 1, ex["shape"][0])
+        fbev = onet.neck(fbb)
+    bb, x = _hip_maps(net, cfg, v, c, n)
+    with torch.no_grad():
+        preds = net.bbox_head(x)
+
+    def dist(name, g, r):
+        g, r = np.asarray(g, np.float64), np.asarray(r, np.float64)
+        d = np.abs(g - r) / np.maximum(1.0, np.abs(r))
+        act = (g != 0) | (r != 0)  # (the BEV map is mostly empty cells, identical zeros on both sides)
+        d = d[act] if act.any() else d.reshape(-1)
+        mean, frac, mx = float(d.mean()), float((d > 2e-2).mean()), float(d.max())
+        report(tag + " bf16 %s: mean" % name, mean, 3e-2, "(frac > 2e-2: %.2e, max %.3f, active elements %d)" % (frac, mx, d.size))
+        assert mean <= 3e-2 and frac <= 0.3, (name, mean, frac, mx)
+
+    dist("backbone BEV vs bf16 oracle", bb.float().cpu().numpy(), obb.numpy())
+    dist("neck output vs bf16 oracle", x.float().cpu().numpy(), obev.numpy())
+    for ti, (pg, po) in enumerate(zip(preds, opreds)):
+        for k in po:
+            if k != "feats":
+                dist("head task %d %s vs bf16 oracle" % (ti, k), pg[k].float().cpu().numpy(), po[k].numpy())
+    scale = float(fbev.abs().max())
+    report(tag + " bf16 neck output vs FP32 oracle (max, of scale; reported, not gated)", float((x.float().cpu() - fbev).abs().max()) / scale, 1.0)
+    return _attribute_bf16_detections(tag, cfg, _rows(got), _rows(odet[0]), opreds, preds, min_rows)
+
+
+def _attribute_bf16_detections(tag, cfg, g, w, opreds, dpreds, min_rows=20):
+    """End-to-end bf16 detections: every detection of the bf16 oracle must be found by the device (same time step, centre within
+    0.3 m) or be ATTRIBUTED to the map deviation at its own cell: the device's score there fell below the score threshold / the
+    nms_pre_max cut, a device detection overlapping it above the NMS threshold took its place, or it fell out of the
+    nms_post_max best.  (Row-by-row equality is not available: yaw = atan2 of two maps that deviate by up to 0.25 and velocities
+    deviate by up to 0.5 on single cells.)  Returns the counts per category; asserts that nothing stays unexplained."""
+    from oracle import ops as oops
+
+    tc = cfg.test_cfg
+    thr, iou_thr = tc["score_threshold"], tc["nms"]["nms_iou_threshold"]
+    pre_max, post_max = int(tc["nms"]["nms_pre_max_size"]), int(tc["nms"]["nms_post_max_size"])
+    assert len(w) >= min_rows
+    dense = len(opreds) > 1
+    cat = dict(found=0, score=0, pre_cut=0, nms=0, post_cut=0, unexplained=0)
+    cache = {}
+    for row in w:
+        lab = int(row[10])
+        cand = g[g[:, 10] == lab]
+        if len(cand) and np.abs(cand[:, :2] - row[:2]).max(1).min() < 0.3:
+            cat["found"] += 1
+            continue
+        ti = lab if dense else 0
+        if ti not in cache:  # the oracle's decoded centre of every cell of this task's maps, and both score maps
+            po = opreds[ti]
+            reg = po["reg"][0].permute(1, 2, 0)
+            H, W = reg.shape[:2]
+            ys, xs = torch.meshgrid([torch.arange(0, H), torch.arange(0, W)], indexing="ij")
+            cx = (xs + reg[..., 0]) * tc["out_size_factor"] * tc["voxel_size"][0] + tc["pc_range"][0]
+            cy = (ys + reg[..., 1]) * tc["out_size_factor"] * tc["voxel_size"][1] + tc["pc_range"][1]
+            so = torch.sigmoid(po["hm"][0].float()).max(0).values
+            sd = torch.sigmoid(dpreds[ti]["hm"][0].float().cpu()).max(0).values
+            kth = float(torch.topk(sd.flatten(), pre_max).values[-1]) if int((sd > thr).sum()) > pre_max else None
+            cache[ti] = (cx.numpy().ravel(), cy.numpy().ravel(), so.numpy().ravel(), sd.numpy().ravel(), kth)
+        cx, cy, so, sd, kth = cache[ti]
+        cell = int(np.argmin(np.abs(cx - row[0]) + np.abs(cy - row[1]) + 10.0 * np.abs(so - row[9])))
+        assert abs(cx[cell] - row[0]) < 1e-3 and abs(cy[cell] - row[1]) < 1e-3, "oracle detection not found among its own cells"
+        s_dev = float(sd[cell])
+        if s_dev <= thr + 1.5e-2:
+            cat["score"] += 1
+        elif kth is not None and s_dev <= kth + 1.5e-2:
+            cat["pre_cut"] += 1
+        elif len(cand) and float(oops.boxes_iou_bev(nms_layout(row[None, :9]), nms_layout(cand[:, :9])).max()) > iou_thr - 6e-2:
+            cat["nms"] += 1
+        elif len(cand) >= post_max and float(cand[:, 9].min()) >= s_dev - 1.5e-2:
+            cat["post_cut"] += 1
+        else:
+            cat["unexplained"] += 1
+    report(tag + " bf16 detections vs bf16 oracle: not found", float(len(w) - cat["found"]), float(len(w)),
+           "(of %d: score %d, pre-max cut %d, NMS %d, post-max cut %d, unexplained %d)" % (len(w), cat["score"], cat["pre_cut"], cat["nms"], cat["post_cut"], cat["unexplained"]))
+    assert cat["unexplained"] == 0, cat
+    assert cat["found"] >= 0.8 * len(w), cat
+    return cat
+
+
+def _rows_by_coord(hip_coords, ora_coords):
+    """permutation p with hip row r  <->  oracle row p[r] (both [n,4] b,z,y,x)"""
+    key = lambda q: ((q[:, 0].astype(np.int64) * 64 + q[:, 1]) * 8192 + q[:, 2]) * 8192 + q[:, 3]  # noqa: E731
+    kh, ko = key(hip_coords), key(ora_coords)
+    so = np.argsort(ko)
+    pos = np.searchsorted(ko[so], kh)
+    assert np.array_equal(ko[so][pos], kh), "active sets differ"
+    return so[pos]
+
+
+@pytest.mark.parametrize("variant,points", [("forecast_n3", 300000), ("forecast_n3dtf", 40000)])
+def test_bf16_every_layer_teacher_forced(hip, variant, points):
+    """bf16 parity with teeth: every fused layer of the bf16 configuration -- the 21 sparse convolutions (with their
+    folded BatchNorm, residual and ReLU), every RPN convolution / deblock, the head's shared, forecast, first and final convolutions --
+    is run on the DEVICE with the INPUT the bf16 oracle had for that layer (oracle/bf16.py trace), and its output must equal the
+    oracle's output element-wise within ONE bf16 ulp (8e-3 * max(1, |ref|)): with identical inputs only the fp32 summation order
+    differs, which can move the final rounding by an ulp and no further.  Full-size cloud (config 3) and the forecast_feature head."""
+    from futuredet_amd import hip_ops, sparse as fsparse
+    from futuredet_amd.dense_bf16 import HeadPlan, RPNPlan
+    from futuredet_amd.synth import synthetic_cloud
+    from oracle import bf16 as obf
+
+    cfg, net, onet = _build_pair(variant)
+    net.set_precision(torch.bfloat16)
+    cloud = synthetic_cloud(seed=0, target_points=points)
+    v, c, n, ex = _bf16_example(cfg, cloud)
+    with obf.tracing() as tr:
+        obf.run(onet, ex, cfg.test_cfg)
+    sp = [r for r in tr if r["kind"] == "sparse"]
+    dn = [r for r in tr if r["kind"] == "dense"]
+    assert len(sp) == 21
+    bf16 = torch.bfloat16
+    worst = 0.0
+
+    # ---- sparse backbone: same execution order as SpMiddleResNetFHD.run_fused
+    bb = net.backbone
+    coors = _dev(np.pad(c, ((0, 0), (1, 0)))).int().contiguous()
+    idx = bb.build_indexes(lambda i0: i0.mark(coors), 1, [int(g) for g in _grid_of(cfg.voxel_generator)], coors.device)
+    perm = {}
+
+    def to_hip(level, sparse_t, cpad):
+        o = sparse_t.indices.numpy()
+        if level not in perm:
+            perm[level] = _rows_by_coord(idx[level].coords.cpu().numpy(), o)
+        f = sparse_t.features.numpy()[perm[level]]
+        out = np.zeros((f.shape[0], cpad), np.float32)
+        out[:, : f.shape[1]] = f
+        return _dev(out).to(bf16)
+
+    layers = []
+    for lvl, (conv, bn, blocks, is_subm_in) in enumerate(bb._stages()):
+        src = lvl if is_subm_in else lvl - 1
+        layers.append((conv, bn, src, lvl, False))
+        for blk in blocks:
+            layers.append((blk.conv1, blk.bn1, lvl, lvl, False))
+            layers.append((blk.conv2, blk.bn2, lvl, lvl, True))
+    assert len(layers) == 21
+    for li, ((conv, bn, src, dst, has_res), rec) in enumerate(zip(layers, sp)):
+        wpk, bias, cin_p, cout_p = conv.packed_weight(bf16, bn)
+        ks, st, pd = conv.geometry()
+        nbr = idx[src].rulebook(idx[dst], ks, st, pd)
+        x_in = to_hip(src, rec["x"], cin_p)
+        res = to_hip(dst, rec["residual"], cout_p) if has_res else None
+        assert (rec["residual"] is not None) == has_res
+        y = hip_ops.spconv_apply(x_in, wpk, bias, nbr, idx[dst].n, cout_p, residual=res, relu=True)
+        want = to_hip(dst, rec["y"], cout_p).float().cpu().numpy()
+        e = rel_err(y.float().cpu().numpy(), want)
+        worst = max(worst, e)
+        assert e <= BF16_ULP, "sparse layer %d (%d -> %d channels, level %d -> %d): %.3e" % (li, cin_p, cout_p, src, dst, e)
+    report("%s bf16 teacher-forced: 21 sparse layers, worst element" % variant, worst, BF16_ULP)
+
+    # ---- dense layers: the conv plan's own objects, NHWC bf16
+    nhwc = lambda t: _dev(t.numpy()).to(bf16).permute(0, 2, 3, 1).contiguous()  # noqa: E731
+    back = lambda t: t.float().permute(0, 3, 1, 2).cpu().numpy()  # noqa: E731
+    rp, hp = RPNPlan(net.neck, bf16), HeadPlan(net.bbox_head, bf16)
+    worst_d, k = 0.0, 0
+
+    def check(name, got, ref):
+        nonlocal worst_d
+        e = rel_err(got, ref.numpy())
+        worst_d = max(worst_d, e)
+        assert e <= BF16_ULP, "%s: %.3e" % (name, e)
+
+    for i, stack in enumerate(rp.blocks):
+        for j, conv in enumerate(stack):
+            check("rpn block %d conv %d" % (i, j), back(conv(nhwc(dn[k]["x"]))), dn[k]["y"])
+            k += 1
+        jd = i - rp.start
+        if jd >= 0:
+            kind, kk, op, cout = rp.deblocks[jd]
+            x_in = nhwc(dn[k]["x"])
+            B, H, W, _ = x_in.shape
+            if kind == "conv":
+                y = op(x_in)
+            elif kind == "up":
+                y = torch.empty((B, H * kk, W * kk, cout), dtype=bf16, device="cuda")
+                for sub, dy, dx in op:
+                    sub(x_in, out=y, co_off=0, osy=kk, osx=kk, ooy=dy, oox=dx)
+            else:
+                raise AssertionError("deblock kind %s is not part of the bf16 CenterPoint plan" % kind)
+            check("rpn deblock %d" % jd, back(y), dn[k]["y"])
+            k += 1
+    for conv in hp.shared:
+        check("head shared conv", back(conv(nhwc(dn[k]["x"]))), dn[k]["y"])
+        k += 1
+    for ti, (c1, c2, names, couts) in enumerate(hp.tasks):
+        if hp.ff:
+            p0, p1 = hp.pre[ti]
+            x_in = nhwc(dn[k]["x"])
+            if ti == 0:  # the plan's first forecast conv of task 0 reads [x | zeros] through zero weights
+                x_in = torch.cat([x_in, torch.zeros_like(x_in)], dim=-1)
+            check("head task %d forecast conv 0" % ti, back(p0(x_in)), dn[k]["y"])
+            check("head task %d forecast conv 1" % ti, back(p1(nhwc(dn[k + 1]["x"]))), dn[k + 1]["y"])
+            k += 2
+        # oracle order per head name: first conv, final conv; the plan fuses all first convs (c1) and all final convs (c2)
+        firsts, finals = dn[k: k + 2 * len(names): 2], dn[k + 1: k + 2 * len(names): 2]
+        k += 2 * len(names)
+        y1 = back(c1(nhwc(firsts[0]["x"])))
+        hc = firsts[0]["y"].shape[1]
+        for hi, name in enumerate(names):
+            check("head task %d %s first conv" % (ti, name), y1[:, hi * hc:(hi + 1) * hc], firsts[hi]["y"])
+        y2 = back(c2(nhwc(torch.cat([f["y"] for f in firsts], dim=1))))
+        o = 0
+        for hi, name in enumerate(names):
+            check("head task %d %s final conv" % (ti, name), y2[:, o:o + couts[hi]], finals[hi]["y"])
+            o += couts[hi]
+    assert k == len(dn), (k, len(dn))
+    report("%s bf16 teacher-forced: %d dense layers, worst element" % (variant, len(dn)), worst_d, BF16_ULP)
+
+
+def test_bf16_decode_on_identical_maps(hip):
+    """The decode + rotated NMS of the bf16 configuration on IDENTICAL head maps: the bf16 oracle's maps (300k-point cloud, n3) go
+    through the device's predict and must give the oracle's detections at the fp32 criterion (rows within 1e-3, differences attributed)."""
+    from futuredet_amd.synth import synthetic_cloud
+    from oracle import bf16 as obf
+
+    cfg, net, onet = _build_pair("forecast_n3")
+    cloud = synthetic_cloud(seed=0, target_points=300000)
+    _, _, _, ex = _bf16_example(cfg, cloud)
+    _, _, opreds, odet = obf.run(onet, ex, cfg.test_cfg)
+    preds = [{k: _dev(v.numpy()) for k, v in p.items()} for p in opreds]
+    with torch.no_grad():
+        got = net.bbox_head.predict({"metadata": [None]}, preds, cfg.test_cfg)[0]
+    sc = torch.sigmoid(opreds[0]["hm"].float()).flatten()
+    k = int(cfg.test_cfg["nms"]["nms_pre_max_size"])
+    topk_cut = float(torch.topk(sc, k).values[-1]) if int((sc > cfg.test_cfg["score_threshold"]).sum()) > k else None
+    assert len(odet[0]["scores"]) > 100
+    _attribute("bf16 maps of the oracle through the device decode (config 3)", _rows(got), _rows(odet[0]), cfg.test_cfg, topk_cut=topk_cut)
 
 
 def test_voxelnet_bf16_end_to_end_vs_fp32_oracle(hip):
@@ -1157,12 +1398,10 @@ def test_voxelnet_bf16_end_to_end_vs_fp32_oracle(hip):
     cfg, net, onet = _build_pair("forecast_n3")
     net.set_precision(torch.bfloat16)
     cloud = synthetic_cloud(seed=0, target_points=30000)
-    v, c, n, _, obev, want = _oracle_run(cfg, onet, cloud)
     with torch.no_grad():
         for _ in range(2):  # second call replays the captured graph
             got = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
-    _, x = _hip_maps(net, cfg, v, c, n)
-    _check_bf16_vs_fp32_oracle("30k n3", got, x, want, obev)
+    _check_bf16("30k n3", cfg, net, onet, cloud, got)
 
 
 # ------------------------------------------------------------------------------------------------ full size (BASELINE configs 2-5)
@@ -1191,12 +1430,10 @@ def test_full_size_config3_bf16_vs_oracle(hip):
     cfg, net, onet = _build_pair("forecast_n3")
     net.set_precision(torch.bfloat16)
     cloud = synthetic_cloud(seed=0, target_points=300000)
-    v, c, n, _, obev, want = _oracle_run(cfg, onet, cloud)
     with torch.no_grad():
         for _ in range(2):
             got = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
-    _, x = _hip_maps(net, cfg, v, c, n)
-    _check_bf16_vs_fp32_oracle("full size config 3 (n3 300k)", got, x, want, obev)
+    _check_bf16("full size config 3 (n3 300k)", cfg, net, onet, cloud, got)
 
 
 def test_config4_per_rank_batch8_bf16(hip):
@@ -1219,9 +1456,7 @@ def test_config4_per_rank_batch8_bf16(hip):
             bitwise += int(g.shape == w.shape and np.array_equal(g, w))
             _attribute("config 4 batch-of-8 sample %d vs its single-sample run" % b, g, w, cfg.test_cfg)
     report("config 4 samples bit-identical to single-sample runs", float(8 - bitwise), 8.0, "(count of samples that differ in any bit)")
-    v, c, n, _, obev, want = _oracle_run(cfg, onet, clouds[3])
-    _, x = _hip_maps(net, cfg, v, c, n)
-    _check_bf16_vs_fp32_oracle("config 4 sample 3 of the batch", batch[3], x, want, obev)
+    _check_bf16("config 4 sample 3 of the batch", cfg, net, onet, clouds[3], batch[3])
 
 
 def test_full_size_config5_pedestrian_fine_grid_fp32_vs_oracle(hip):
@@ -1265,8 +1500,7 @@ def test_full_size_config5_pedestrian_fine_grid_fp32_vs_oracle(hip):
     with torch.no_grad():
         for _ in range(2):
             got16 = net.forward_points([_dev(cloud)], vg, padded=False)[0]
-    _, x16 = _hip_maps(net, cfg, v, c, n)
-    _check_bf16_vs_fp32_oracle("full size config 5 (ped n3 500k, 0.05 m)", got16, x16, want, obev)
+    _check_bf16("full size config 5 (ped n3 500k, 0.05 m)", cfg, net, onet, cloud, got16)
 
 
 def test_two_ranks_on_one_gpu_equal_single_process(hip, tmp_path):

@@ -279,3 +279,48 @@ def test_oracle_det_to_global_and_forecast_ids_match_reference_golden(golden):
         assert (np.abs(got - g[key]) / np.maximum(1.0, np.abs(g[key]))).max() <= 1e-12, key
     assert np.array_equal(of.forecast_ids(g["mf_translation"][g["mf_is_car"]]), g["mf_ids"])
     assert len(of.forecast_ids(np.zeros((0, 3)))) == 0
+
+
+def test_bf16_oracle_is_a_rounding_of_the_fp32_oracle():
+    """oracle/bf16.py (weights and per-layer activations rounded to bf16, fp32 accumulate) on a small cloud: every value it
+    produces is bf16-representable, it stays within a few percent of the fp32 oracle's maps (it measures bf16, ~45 layers of
+    8-bit mantissas), and its fold is exact: with all weights already bf16-representable and BatchNorm at identity, a single
+    dense layer equals conv2d on the same values."""
+    import torch
+    from torch import nn
+
+    from futuredet_amd import build_detector
+    from futuredet_amd.configs import centerpoint_config
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims
+    from oracle import bf16 as obf
+    from oracle import model as omodel
+    from oracle import ops as oops
+
+    cfg = centerpoint_config("forecast_n3")
+    net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    sd = tame_box_dims(seeded_state_dict(net, 7))
+    onet = omodel.VoxelNet(cfg.model["reader"], cfg.model["backbone"], cfg.model["neck"], cfg.model["bbox_head"], test_cfg=cfg.test_cfg).eval()
+    onet.load_state_dict(sd, strict=False)
+    cloud = synthetic_cloud(seed=2, target_points=6000)
+    vg = cfg.voxel_generator
+    v, c, n = oops.points_to_voxel(cloud, vg["voxel_size"], vg["range"], vg["max_points_in_voxel"], True, vg["max_voxel_num"][1])
+    grid = np.round((np.array(vg["range"][3:], np.float32) - np.array(vg["range"][:3], np.float32)) / np.array(vg["voxel_size"], np.float32)).astype(np.int64)
+    ex = dict(voxels=torch.from_numpy(v), coordinates=torch.from_numpy(np.pad(c, ((0, 0), (1, 0)))), num_points=torch.from_numpy(n),
+              num_voxels=torch.tensor([len(n)]), shape=np.array([grid]), metadata=[None])
+    bb, bev, preds, det = obf.run(onet, ex, cfg.test_cfg)
+    for t in (bb, bev, preds[0]["hm"], preds[0]["vel"]):
+        assert torch.equal(t, t.to(torch.bfloat16).float()), "every layer output of the bf16 configuration is bf16-representable"
+    with torch.no_grad():
+        f = onet.reader(ex["voxels"], ex["num_points"])
+        fbb, _ = onet.backbone(f, ex["coordinates"], 1, ex["shape"][0])
+        fbev = onet.neck(fbb)
+    assert float((bev - fbev).abs().max()) <= 5e-2 * float(fbev.abs().max())
+    assert len(det[0]["scores"]) > 0
+    # exactness of one folded layer
+    conv, bn = nn.Conv2d(32, 16, 3, padding=1, bias=False), nn.BatchNorm2d(16).eval()
+    with torch.no_grad():
+        conv.weight.copy_(conv.weight.to(torch.bfloat16).float())
+        bn.running_var.fill_(1.0 - bn.eps)  # scale = weight / sqrt(var + eps) = 1 exactly
+    x = torch.randn(1, 32, 9, 7).to(torch.bfloat16).float()
+    want = torch.relu(torch.nn.functional.conv2d(x, conv.weight, None, padding=1)).to(torch.bfloat16).float()
+    assert torch.equal(obf.dense_stack([conv, bn, nn.ReLU()], x), want)
