@@ -309,10 +309,8 @@ def main():
     def forward(clouds):
         step = static_steps.get(torch.cuda.current_stream(dev).cuda_stream) if (use_graph and not prof.enabled) else None
         if step is not None:
-            boxes, scores, labels, counts = step(clouds)
-        else:
-            boxes, scores, labels, counts = net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded=True)
-        return dist_infer.pack_results(boxes, scores, labels, counts)
+            return step(clouds)  # (packed [B,S,post,11], counts [B,S]) written by the decode's last kernel
+        return net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded="packed")
 
     def sync_all():
         if world > 1:
@@ -426,7 +424,7 @@ def main():
                 if use_graph:
                     from futuredet_amd.detectors import StaticStep
                     try:
-                        step = StaticStep(net, cfg.voxel_generator, capacity, batch_size=B, ndim=host[uniq[0]].shape[1])
+                        step = StaticStep(net, cfg.voxel_generator, capacity, batch_size=B, ndim=host[uniq[0]].shape[1], packed=True)
                         step.warm_up([resident[s] for s in seeds[0]])
                         step.capture()
                         static_steps[st.cuda_stream] = step

@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(256) footprint_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------- stage 1: score keys
+constexpr int kMaxSteps = 16;
 struct DecCfg {
     int H, W, HW;
     float osf, vx, vy, px, py, thr;
@@ -186,25 +187,38 @@ struct DecCfg {
     int pre_max, post_max;
 };
 
-__device__ inline void cell_center(const DecCfg &c, const float *reg, int cell, float &x, float &y) {
+// A head map as the kernels read it: element (group g, channel ch, BEV cell) of a float32 or bf16 tensor at
+// base[g * gs + ch * cs + cell * ps].  NCHW planes: cs = H*W, ps = 1; a channel slice of an NHWC head output: cs = 1, ps = C_total
+// -- which is how the decode reads the convolution plan's output in place (no .float() / .contiguous() passes in between).
+struct MapView {
+    const void *p;
+    int64_t gs, cs, ps;
+    int bf16;
+};
+__device__ inline float ld(const MapView &m, int g, int ch, int cell) {
+    const int64_t o = (int64_t)g * m.gs + (int64_t)ch * m.cs + (int64_t)cell * m.ps;
+    return m.bf16 ? __uint_as_float(((unsigned)reinterpret_cast<const unsigned short *>(m.p)[o]) << 16) : reinterpret_cast<const float *>(m.p)[o];
+}
+inline MapView as_view(const fd_map_view &v) { return MapView{v.data, v.group_stride, v.channel_stride, v.cell_stride, v.dtype}; }
+
+__device__ inline void cell_center(const DecCfg &c, const MapView &reg, int g, int cell, float &x, float &y) {
     // center_head.py:641-649: xs = (j + reg_x) * out_size_factor * voxel_size[0] + pc_range[0], left to right in f32
     const int i = cell / c.W, j = cell - i * c.W;
-    float xs = __fadd_rn((float)j, reg[cell]);
-    float ys = __fadd_rn((float)i, reg[c.HW + cell]);
+    float xs = __fadd_rn((float)j, ld(reg, g, 0, cell));
+    float ys = __fadd_rn((float)i, ld(reg, g, 1, cell));
     x = __fadd_rn(__fmul_rn(__fmul_rn(xs, c.osf), c.vx), c.px);
     y = __fadd_rn(__fmul_rn(__fmul_rn(ys, c.osf), c.vy), c.py);
 }
 
-__global__ void __launch_bounds__(256) dec_keys(const float *__restrict__ hm, int64_t hm_gs, const float *__restrict__ reg, int64_t reg_gs,
-                                                const float *__restrict__ height, int64_t h_gs, DecCfg c, unsigned *__restrict__ keys) {
+__global__ void __launch_bounds__(256) dec_keys(MapView hm, MapView reg, MapView height, DecCfg c, unsigned *__restrict__ keys) {
     const int g = blockIdx.y;
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= c.HW) return;
-    const float logit = hm[g * hm_gs + cell];
+    const float logit = ld(hm, g, 0, cell);
     const float score = 1.0f / (1.0f + expf(-logit));
     float x, y;
-    cell_center(c, reg + g * reg_gs, cell, x, y);
-    const float z = height[g * h_gs + cell];
+    cell_center(c, reg, g, cell, x, y);
+    const float z = ld(height, g, 0, cell);
     const bool ok = score > c.thr && x >= c.rng[0] && y >= c.rng[1] && z >= c.rng[2] && x <= c.rng[3] && y <= c.rng[4] && z <= c.rng[5];
     keys[(int64_t)g * c.HW + cell] = ok ? __float_as_uint(score) : 0u;
 }
@@ -257,9 +271,8 @@ __device__ inline void find_bin(const int *hist, int nbins, int need, int *sm_sc
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(kSelThreads) dec_select(const unsigned *__restrict__ keys_all, const float *__restrict__ reg, int64_t reg_gs,
-                                                          const float *__restrict__ height, int64_t h_gs, const float *__restrict__ dim,
-                                                          int64_t dim_gs, const float *__restrict__ rot, int64_t rot_gs, DecCfg c, int npad,
+__global__ void __launch_bounds__(kSelThreads) dec_select(const unsigned *__restrict__ keys_all, MapView reg, MapView height, MapView dim, MapView rot,
+                                                          DecCfg c, int npad,
                                                           float *__restrict__ sel_boxes /*[G,pre,7] output layout*/,
                                                           float *__restrict__ nms_boxes /*[G,pre,7] pcdet layout*/,
                                                           float *__restrict__ sel_scores, int *__restrict__ sel_cell,
@@ -359,12 +372,10 @@ __global__ void __launch_bounds__(kSelThreads) dec_select(const unsigned *__rest
         const int cell = (int)(0xffffffffu - (unsigned)(e & 0xffffffffull));
         const float score = __uint_as_float((unsigned)(e >> 32));
         float x, y;
-        cell_center(c, reg + g * reg_gs, cell, x, y);
-        const float z = height[g * h_gs + cell];
-        const float *dm = dim + g * dim_gs;
-        const float d0 = expf(dm[cell]), d1 = expf(dm[c.HW + cell]), d2 = expf(dm[2 * c.HW + cell]);
-        const float *rt = rot + g * rot_gs;
-        const float yaw = atan2f(rt[cell], rt[c.HW + cell]);
+        cell_center(c, reg, g, cell, x, y);
+        const float z = ld(height, g, 0, cell);
+        const float d0 = expf(ld(dim, g, 0, cell)), d1 = expf(ld(dim, g, 1, cell)), d2 = expf(ld(dim, g, 2, cell));
+        const float yaw = atan2f(ld(rot, g, 0, cell), ld(rot, g, 1, cell));
         const int64_t o = ((int64_t)g * c.pre_max + i);
         float *sb = sel_boxes + o * 7;
         sb[0] = x; sb[1] = y; sb[2] = z; sb[3] = d0; sb[4] = d1; sb[5] = d2; sb[6] = yaw;
@@ -499,16 +510,49 @@ DecWs dec_layout(int G, int HW, int pre_max, int post_max) {
 
 }  // namespace
 
+// Final assembly of predict's output (center_head.py:559-570,606-607,672-697): output step s takes the boxes of group
+// step_group[s], its two velocity channels vel_channel[s], vel_channel[s] + 1 of that group's velocity map at the kept cells, and the
+// label offset label_of[s].  One packed row per kept box: x y z w l h vx vy yaw score label; rows k >= count are zero.
+struct AsmSteps {
+    int S;
+    int group[kMaxSteps], vel_channel[kMaxSteps], label[kMaxSteps];
+};
+__global__ void __launch_bounds__(128) assemble_kernel(const float *__restrict__ boxes7, const float *__restrict__ scores, const int *__restrict__ cell,
+                                                       const int *__restrict__ count, MapView vel, AsmSteps st, int B, int post,
+                                                       float *__restrict__ packed, int *__restrict__ counts_out) {
+    const int b = blockIdx.x / st.S, s = blockIdx.x - b * st.S, k = threadIdx.x;
+    const int g = st.group[s];
+    const int64_t src = (int64_t)g * B + b;  // decode groups are group-major: [G][B]
+    const int n = count[src];
+    if (k == 0) counts_out[b * st.S + s] = n;
+    if (k >= post) return;
+    float *o = packed + (((int64_t)b * st.S + s) * post + k) * 11;
+    if (k < n) {
+        const float *bx = boxes7 + (src * post + k) * 7;
+        const int c = cell[src * post + k];
+        // the velocity map of group g, sample b: group index of the view = g * B + b
+        const float vx = ld(vel, (int)src, st.vel_channel[s], c), vy = ld(vel, (int)src, st.vel_channel[s] + 1, c);
+        o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2]; o[3] = bx[3]; o[4] = bx[4]; o[5] = bx[5];
+        o[6] = vx; o[7] = vy; o[8] = bx[6];
+        o[9] = scores[src * post + k];
+        o[10] = (float)st.label[s];
+    } else {
+#pragma unroll
+        for (int d = 0; d < 11; ++d) o[d] = 0.0f;
+    }
+}
+
 extern "C" size_t fd_decode_workspace_bytes(int G, const fd_decode_cfg *cfg) {
     if (!cfg || G <= 0) return 0;
     return dec_layout(G, cfg->H * cfg->W, cfg->nms_pre_max, cfg->nms_post_max).total;
 }
 
-extern "C" int fd_centerpoint_decode(const float *hm, int64_t hm_gs, const float *reg, int64_t reg_gs, const float *height, int64_t h_gs,
-                                     const float *dim, int64_t dim_gs, const float *rot, int64_t rot_gs, int G, const fd_decode_cfg *cfg,
-                                     float *out_boxes7, float *out_scores, int32_t *out_cell, int32_t *out_count, void *workspace,
-                                     size_t workspace_bytes, fd_stream_t stream_) {
+extern "C" int fd_centerpoint_decode_maps(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view *height, const fd_map_view *dim,
+                                          const fd_map_view *rot, int G, const fd_decode_cfg *cfg, float *out_boxes7, float *out_scores, int32_t *out_cell,
+                                          int32_t *out_count, void *workspace, size_t workspace_bytes, fd_stream_t stream_) {
     FD_REQUIRE(hm && reg && height && dim && rot && cfg && out_boxes7 && out_scores && out_cell && out_count, "fd_centerpoint_decode: null argument");
+    FD_REQUIRE(hm->data && reg->data && height->data && dim->data && rot->data, "fd_centerpoint_decode: null map");
+    for (const fd_map_view *v : {hm, reg, height, dim, rot}) FD_REQUIRE(v->dtype == 0 || v->dtype == 1, "fd_centerpoint_decode: map dtype must be 0 (f32) or 1 (bf16)");
     FD_REQUIRE(G > 0 && cfg->H > 0 && cfg->W > 0, "fd_centerpoint_decode: bad shape");
     FD_REQUIRE(cfg->nms_pre_max >= 1 && cfg->nms_pre_max <= kMaxPre, "fd_centerpoint_decode: nms_pre_max must be in [1,%d]", kMaxPre);
     FD_REQUIRE(cfg->nms_post_max >= 1 && cfg->nms_post_max <= 128, "fd_centerpoint_decode: nms_post_max must be in [1,128]");
@@ -530,10 +574,11 @@ extern "C" int fd_centerpoint_decode(const float *hm, int64_t hm_gs, const float
     float *sel_boxes = (float *)(ws + w.sel_boxes), *nms_boxes = (float *)(ws + w.nms_boxes), *sel_scores = (float *)(ws + w.sel_scores);
     int *sel_cell = (int *)(ws + w.sel_cell), *sel_count = (int *)(ws + w.sel_count), *keep = (int *)(ws + w.keep);
     unsigned long long *mask = (unsigned long long *)(ws + w.mask);
-    hipLaunchKernelGGL(dec_keys, dim3((c.HW + 255) / 256, G), dim3(256), 0, stream, hm, hm_gs, reg, reg_gs, height, h_gs, c, keys);
+    const MapView vh = as_view(*hm), vr = as_view(*reg), vz = as_view(*height), vd = as_view(*dim), vt = as_view(*rot);
+    hipLaunchKernelGGL(dec_keys, dim3((c.HW + 255) / 256, G), dim3(256), 0, stream, vh, vr, vz, c, keys);
     const size_t lds = (size_t)w.npad * 8 + 4096 * 4 + 32 * 4;
-    hipLaunchKernelGGL(dec_select, dim3(G), dim3(kSelThreads), lds, stream, keys, reg, reg_gs, height, h_gs, dim, dim_gs, rot, rot_gs, c, w.npad,
-                       sel_boxes, nms_boxes, sel_scores, sel_cell, sel_count);
+    hipLaunchKernelGGL(dec_select, dim3(G), dim3(kSelThreads), lds, stream, keys, vr, vz, vd, vt, c, w.npad, sel_boxes, nms_boxes, sel_scores, sel_cell,
+                       sel_count);
     float4 *foot = (float4 *)(ws + w.foot);
     const int64_t n_total = (int64_t)G * c.pre_max;
     hipLaunchKernelGGL(footprint_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, stream, nms_boxes, sel_count, c.pre_max, G, foot);
@@ -543,6 +588,36 @@ extern "C" int fd_centerpoint_decode(const float *hm, int64_t hm_gs, const float
     hipLaunchKernelGGL(dec_gather, dim3(G), dim3(128), 0, stream, keep, out_count, c.post_max, c.pre_max, sel_boxes, sel_scores, sel_cell,
                        out_boxes7, out_scores, out_cell);
     return fd::check_launch("fd_centerpoint_decode");
+}
+
+// the round-1 signature: five [G, C, H, W] float32 tensors with their group strides (NCHW planes)
+extern "C" int fd_centerpoint_decode(const float *hm, int64_t hm_gs, const float *reg, int64_t reg_gs, const float *height, int64_t h_gs,
+                                     const float *dim, int64_t dim_gs, const float *rot, int64_t rot_gs, int G, const fd_decode_cfg *cfg,
+                                     float *out_boxes7, float *out_scores, int32_t *out_cell, int32_t *out_count, void *workspace,
+                                     size_t workspace_bytes, fd_stream_t stream_) {
+    FD_REQUIRE(cfg, "fd_centerpoint_decode: null argument");
+    const int64_t hw = (int64_t)cfg->H * cfg->W;
+    const fd_map_view v[5] = {{hm, hm_gs, hw, 1, 0}, {reg, reg_gs, hw, 1, 0}, {height, h_gs, hw, 1, 0}, {dim, dim_gs, hw, 1, 0}, {rot, rot_gs, hw, 1, 0}};
+    return fd_centerpoint_decode_maps(&v[0], &v[1], &v[2], &v[3], &v[4], G, cfg, out_boxes7, out_scores, out_cell, out_count, workspace, workspace_bytes,
+                                      stream_);
+}
+
+extern "C" int fd_assemble_detections(const float *boxes7, const float *scores, const int32_t *cell, const int32_t *count, const fd_map_view *vel, int B,
+                                      int post_max, int S, const int32_t *step_group, const int32_t *step_vel_channel, const int32_t *step_label,
+                                      float *packed, int32_t *counts_out, fd_stream_t stream) {
+    FD_REQUIRE(boxes7 && scores && cell && count && vel && vel->data && step_group && step_vel_channel && step_label && packed && counts_out,
+               "fd_assemble_detections: null argument");
+    FD_REQUIRE(B >= 1 && S >= 1 && S <= kMaxSteps && post_max >= 1 && post_max <= 128, "fd_assemble_detections: need 1 <= S <= %d, 1 <= post_max <= 128", kMaxSteps);
+    FD_REQUIRE(vel->dtype == 0 || vel->dtype == 1, "fd_assemble_detections: map dtype must be 0 (f32) or 1 (bf16)");
+    AsmSteps st;
+    st.S = S;
+    for (int s = 0; s < S; ++s) {
+        FD_REQUIRE(step_group[s] >= 0 && step_vel_channel[s] >= 0, "fd_assemble_detections: negative step entry");
+        st.group[s] = step_group[s]; st.vel_channel[s] = step_vel_channel[s]; st.label[s] = step_label[s];
+    }
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(B * S)), dim3(128), 0, fd::as_stream(stream), boxes7, scores, cell, count, as_view(*vel), st, B, post_max,
+                       packed, counts_out);
+    return fd::check_launch("fd_assemble_detections");
 }
 
 extern "C" size_t fd_nms_workspace_bytes(int n) {

@@ -92,7 +92,35 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
             const int r = t % TM;
             if (t < K * TM) s_list[t] = r < n_rows ? pre[i] : -1;
         }
-        for (int t = tid; t < TS * (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // tile copy 0 starts from bias + residual (see fd_spconv_v2.hip: no dependent global loads left in the epilogue)
+        {
+            constexpr int C4i = COUT / 4, NINIT = TM * C4i / 256;
+            static_assert(TM * C4i % 256 == 0, "whole passes");
+            float4 iv[NINIT];
+#pragma unroll
+            for (int i = 0; i < NINIT; ++i) {
+                const int t = tid + i * 256, c4 = t % C4i;
+                iv[i] = bias ? reinterpret_cast<const float4 *>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (residual) {
+                float4 rv[NINIT];
+#pragma unroll
+                for (int i = 0; i < NINIT; ++i) {
+                    const int t = tid + i * 256, r = t / C4i, c4 = t - r * C4i;
+                    const int rr = r < n_rows ? r : n_rows - 1;
+                    rv[i] = reinterpret_cast<const float4 *>(residual + (int64_t)(row0 + rr) * COUT)[c4];
+                }
+#pragma unroll
+                for (int i = 0; i < NINIT; ++i) { iv[i].x += rv[i].x; iv[i].y += rv[i].y; iv[i].z += rv[i].z; iv[i].w += rv[i].w; }
+            }
+#pragma unroll
+            for (int i = 0; i < NINIT; ++i) {
+                const int t = tid + i * 256, r = t / C4i, c4 = t - r * C4i;
+                const int ts4 = r * C4i + (c4 ^ (int)(((unsigned)r >> 1) & 7u));
+                reinterpret_cast<float4 *>(s_acc)[ts4] = r < n_rows ? iv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            for (int t = TM * C4i + tid; t < TS * (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if (tid < 32) s_pad[tid] = kPad;
         __syncthreads();
         // ---- in-place compaction per (tap, row half): wave w takes taps w, w + 4, ...; tails are filled with kPad
@@ -234,14 +262,6 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
             for (int q = 1; q < TS; ++q) {
                 const float4 v2 = reinterpret_cast<const float4 *>(s_acc + q * (TM + 1) * COUT)[ts4];
                 v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
-            }
-            if (bias) {
-                const float4 bv = reinterpret_cast<const float4 *>(bias)[c4];
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            }
-            if (residual) {
-                const float4 rv = reinterpret_cast<const float4 *>(residual + (int64_t)row * COUT)[c4];
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             reinterpret_cast<float4 *>(out + (int64_t)row * COUT)[c4] = v;

@@ -143,7 +143,43 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
         const int r = t % TM;
         if (t < K * TM) s_list[t] = r < n_rows ? pre[i] : -1;
     }
-    for (int t = tid; t < TS * (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Accumulator tile.  For COUT <= 64 the tile starts from bias + residual instead of zero: the epilogue then has no global
+    // load left (it used to issue one dependent residual load per 256 rows x 4 channels -- 4 to 8 exposed memory round trips per
+    // chunk, as long as the chunk's whole MFMA loop on the 32-channel layers: the "unexplained" 47 % dependency stall of round 2).
+    // All loads of a chunk go out back to back here and land during the list staging.  (128 columns: 64 registers per thread
+    // would be needed; that layer is MFMA-bound and keeps the epilogue form.)
+    constexpr bool kInitAcc = COUT <= 64;
+    if constexpr (kInitAcc) {
+        constexpr int C4i = COUT / 4, NINIT = TM * C4i / 256;
+        static_assert(TM * C4i % 256 == 0, "whole passes");
+        float4 iv[NINIT];
+#pragma unroll
+        for (int i = 0; i < NINIT; ++i) {
+            const int t = tid + i * 256, c4 = t % C4i;
+            iv[i] = bias ? reinterpret_cast<const float4 *>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (residual) {
+            float4 rv[NINIT];
+#pragma unroll
+            for (int i = 0; i < NINIT; ++i) {
+                const int t = tid + i * 256, r = t / C4i, c4 = t - r * C4i;
+                const int rr = r < n_rows ? r : n_rows - 1;  // (clamped address, selected on use)
+                rv[i] = reinterpret_cast<const float4 *>(residual + (int64_t)(row0 + rr) * COUT)[c4];
+            }
+#pragma unroll
+            for (int i = 0; i < NINIT; ++i) { iv[i].x += rv[i].x; iv[i].y += rv[i].y; iv[i].z += rv[i].z; iv[i].w += rv[i].w; }
+        }
+#pragma unroll
+        for (int i = 0; i < NINIT; ++i) {
+            const int t = tid + i * 256, r = t / C4i, c4 = t - r * C4i;
+            const int ts4 = r * C4i + (c4 ^ (int)(((unsigned)r >> kSwzShift) & kSwzMask));
+            reinterpret_cast<float4 *>(s_acc)[ts4] = r < n_rows ? iv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // the scratch row of copy 0 and the other tile copies start from zero
+        for (int t = TM * C4i + tid; t < TS * (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (int t = tid; t < TS * (TM + 1) * COUT / 4; t += 256) reinterpret_cast<float4 *>(s_acc)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (tid < 16) s_pad[tid] = kPad;
     __syncthreads();
     if (chunk == 0) FD_T(1);
@@ -367,13 +403,15 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
             const float4 v2 = reinterpret_cast<const float4 *>(s_acc + q * (TM + 1) * COUT)[ts4];
             v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w;
         }
-        if (bias) {
-            const float4 bv = reinterpret_cast<const float4 *>(bias)[c4];
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        }
-        if (residual) {
-            const float4 rv = reinterpret_cast<const float4 *>(residual + (int64_t)row * COUT)[c4];
-            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        if constexpr (!kInitAcc) {
+            if (bias) {
+                const float4 bv = reinterpret_cast<const float4 *>(bias)[c4];
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            }
+            if (residual) {
+                const float4 rv = reinterpret_cast<const float4 *>(residual + (int64_t)row * COUT)[c4];
+                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            }
         }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         reinterpret_cast<float4 *>(out + (int64_t)row * COUT)[c4] = v;

@@ -92,8 +92,8 @@ class _GroupedConv(object):
     def __init__(self, wpk, bias, counts, cin_g):
         self.wpk, self.bias, self.counts, self.cin_g = wpk, bias, counts, cin_g
 
-    def __call__(self, x):
-        return hip_ops.conv2d_grouped_nhwc_f32(x, self.wpk, self.bias, self.counts, self.cin_g, relu=False)
+    def __call__(self, x, out=None):
+        return hip_ops.conv2d_grouped_nhwc_f32(x, self.wpk, self.bias, self.counts, self.cin_g, relu=False, out=out)
 
 
 def _convs_from_stack(modules, dtype):
@@ -165,6 +165,13 @@ class RPNPlan(object):
         return ups
 
 
+class HeadMaps(dict):
+    """One task's head maps (NCHW-shaped VIEWS of the plan's NHWC output buffer, in the plan's dtype) plus ``raw`` =
+    (buffer [T, B, H, W, C_total], task index, {name: (first channel, channels)}): CenterHead.predict_padded hands the buffer to the
+    decode kernels as it is (fd_map_view), without .float() / .contiguous() passes per map."""
+    raw = None
+
+
 class HeadPlan(object):
     """CenterHead without bev_map: shared conv, then per task one fused first conv and one block-diagonal final conv.
     With forecast_feature (n3dtf, center_head.py:119-124,383-386) each task first runs its two forecast convs; task
@@ -233,17 +240,25 @@ class HeadPlan(object):
         else:
             x = last(x)
         rets = []
+        zbuf = None
         for ti, (c1, c2, names, couts) in enumerate(self.tasks):
-            d = {}
+            d = HeadMaps()
             if self.ff:
                 p0, p1 = self.pre[ti]
                 x = p1(p0(cat[ti & 1]))                             # feats_i, contiguous for this task's heads
                 cat[(ti + 1) & 1][..., hc:].copy_(x)                # and behind x for the next task's concat
                 d["feats"] = x.permute(0, 3, 1, 2)
-            z = c2(c1(x)).permute(0, 3, 1, 2).float()  # [B, sum(couts), H, W]
-            o = 0
+            y1 = c1(x)
+            if zbuf is None:  # all tasks of a head have the same branches: one [T, B, H, W, C_total] buffer takes every task's final convs
+                Bz, Hz, Wz, _ = y1.shape
+                zbuf = torch.empty((len(self.tasks), Bz, Hz, Wz, int(sum(couts))), dtype=self.dtype, device=y1.device)
+            c2(y1, out=zbuf[ti])
+            z = zbuf[ti].permute(0, 3, 1, 2)  # [B, sum(couts), H, W] view
+            o, where = 0, {}
             for name, cn in zip(names, couts):
                 d[name] = z[:, o:o + cn]
+                where[name] = (o, cn)
                 o += cn
+            d.raw = (zbuf, ti, where)
             rets.append(d)
         return rets

@@ -223,7 +223,12 @@ class VoxelNet(SingleStageDetector):
             mark_stage("rpn")
             preds = self.bbox_head(x, bev_map)
             mark_stage("head")
-        if padded:
+        if padded == "packed":  # (packed [B,S,post,11], counts [B,S]): what the multi-GPU gather and the bench move
+            out = self.bbox_head.predict_packed(preds, self.test_cfg)
+            if out is None:
+                from .dist_infer import pack_results
+                out = pack_results(*self.bbox_head.predict_padded(preds, self.test_cfg))
+        elif padded:
             out = self.bbox_head.predict_padded(preds, self.test_cfg)
         else:
             out = self.bbox_head.predict({"metadata": [None] * B}, preds, self.test_cfg)
@@ -243,8 +248,9 @@ class StaticStep(object):
                                                                    # static tensors (valid until the next call on this stream)
     One StaticStep belongs to one stream (the one current at capture); sweeps in flight on several streams use one each."""
 
-    def __init__(self, model, voxel_cfg, capacity, batch_size=1, ndim=5):
+    def __init__(self, model, voxel_cfg, capacity, batch_size=1, ndim=5, packed=False):
         self.model, self.voxel_cfg = model, voxel_cfg
+        self.padded = "packed" if packed else True  # packed: outputs = (packed [B,S,post,11], counts [B,S]) instead of four tensors
         self.B, self.capacity, self.ndim = int(batch_size), int(capacity), int(ndim)
         dev = next(model.parameters()).device
         self.points = torch.zeros((self.B, self.capacity, self.ndim), dtype=torch.float32, device=dev)
@@ -278,10 +284,10 @@ class StaticStep(object):
         m = self.model
         if static:  # the captured sweep keeps scratch buffers of its own (not those of whatever stream it is captured on)
             with hip_ops.workspace.scope(id(self)):
-                return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg,
+                return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, padded=self.padded,
                                         counts=[self.counts[b:b + 1] for b in range(self.B)], static=True, expected=self.expected)
-        return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, counts=[self.counts[b:b + 1] for b in range(self.B)],
-                                static=static, expected=self.expected)
+        return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, padded=self.padded,
+                                counts=[self.counts[b:b + 1] for b in range(self.B)], static=static, expected=self.expected)
 
     def warm_up(self, clouds, n=2):
         """Eager sweeps on representative clouds: lets the dense-conv plan time its variants and records the level counts that
@@ -407,7 +413,12 @@ class PointPillars(SingleStageDetector):
         mark_stage("rpn")
         preds = self.bbox_head(x, bev_map)
         mark_stage("head")
-        if padded:
+        if padded == "packed":  # (packed [B,S,post,11], counts [B,S]): what the multi-GPU gather and the bench move
+            out = self.bbox_head.predict_packed(preds, self.test_cfg)
+            if out is None:
+                from .dist_infer import pack_results
+                out = pack_results(*self.bbox_head.predict_padded(preds, self.test_cfg))
+        elif padded:
             out = self.bbox_head.predict_padded(preds, self.test_cfg)
         else:
             out = self.bbox_head.predict({"metadata": [None] * B}, preds, self.test_cfg)

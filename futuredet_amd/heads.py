@@ -255,9 +255,54 @@ class CenterHead(nn.Module):
         return list(preds_dicts), vels, list(range(len(preds_dicts))), list(self.num_classes)
 
     @torch.no_grad()
+    def predict_packed(self, preds_dicts, test_cfg):
+        """Device-only decode straight from the convolution plan's NHWC output buffer: (packed [B,S,post,11] float32 rows
+        x y z w l h vx vy yaw score label, counts [B,S] int32) -- seven launches (keys, select, footprints, IoU mask, sweep, gather,
+        assembly), no torch kernel in between.  None when the maps did not come from the plan (torch path, bev_map head)."""
+        raws = [getattr(pd, "raw", None) for pd in preds_dicts]
+        if any(r is None for r in raws) or any(r[0] is not raws[0][0] or r[2] != raws[0][2] for r in raws):
+            return None
+        if test_cfg.get("per_class_nms", False) or test_cfg.get("circular_nms", False):
+            raise NotImplementedError("only rotated NMS is configured in the shipped test_cfg")
+        zbuf, _, where = raws[0]
+        T, B, H, W, C = zbuf.shape
+        assert where["hm"][1] == 1, "single-class heat-maps (every shipped task has one class)"
+        if self.standard:  # center_head.py:559-570: one task, step s = its boxes + velocity channels 2s, 2s+1 (all steps share them when timesteps == 1)
+            G = 1
+            S = self.target_timesteps
+            step_group = [0] * S
+            step_vel = [2 * s if self.timesteps > 1 else 0 for s in range(S)]
+            num_classes = [1] * S
+        else:              # :606-607: one task per step
+            G = T
+            S = T
+            step_group = list(range(T))
+            step_vel = [0] * T
+            num_classes = list(self.num_classes)
+        labels, acc = [], 0
+        for ncls in num_classes:
+            labels.append(acc)
+            acc += ncls
+        cache = self.__dict__.setdefault("_lab_cache", {})
+        ck = (zbuf.device, B, S, int(test_cfg["nms"]["nms_post_max_size"]))
+        if ck not in cache:  # labels do not depend on the data (built in the eager set-up pass, before any graph capture)
+            cache[ck] = torch.as_tensor(labels, dtype=torch.int64, device=zbuf.device).view(1, S, 1).expand(B, S, ck[3]).contiguous()
+        flat = zbuf[:G].reshape(G * B, H, W, C)
+        cfg = hip_ops.make_decode_cfg(H, W, test_cfg)
+        views = [hip_ops.nhwc_channel_view(flat, where[k][0]) for k in ("hm", "reg", "height", "dim", "rot")]
+        boxes7, scores, cell, count = hip_ops.centerpoint_decode_views(views, G * B, cfg, zbuf.device)
+        return hip_ops.assemble_detections(boxes7, scores, cell, count, hip_ops.nhwc_channel_view(flat, where["vel"][0]), B, cfg.nms_post_max,
+                                           step_group, step_vel, labels)
+
+    @torch.no_grad()
     def predict_padded(self, preds_dicts, test_cfg):
         """Device-only decode: (boxes [B,S,post,9], scores [B,S,post], labels [B,S,post] int64, counts [B,S] int32)
         with S output steps; entries k >= counts[b,s] are padding.  No host synchronisation."""
+        fused = self.predict_packed(preds_dicts, test_cfg)
+        if fused is not None:
+            packed, counts = fused
+            B, S, post, _ = packed.shape
+            return packed[..., :9], packed[..., 9], self._lab_cache[(packed.device, B, S, post)], counts
         if test_cfg.get("per_class_nms", False) or test_cfg.get("circular_nms", False):
             raise NotImplementedError("only rotated NMS is configured in the shipped test_cfg")
         srcs, vels, step_group, num_classes = self._groups(preds_dicts)

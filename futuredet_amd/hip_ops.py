@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import lib as _lib
-from .lib import DecodeCfg, FutureDetHipError, check
+from .lib import DecodeCfg, FutureDetHipError, MapView, check
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -541,6 +541,41 @@ def centerpoint_decode(hm, reg, height, dim, rot, cfg):
     check(L.fd_centerpoint_decode(*args, G, ctypes.byref(cfg), _p(boxes), _p(scores), _p(cell), _p(count), _p(ws),
                                   ws.numel(), _stream()), "fd_centerpoint_decode")
     return boxes, scores, cell, count
+
+
+def nhwc_channel_view(buf, c0):
+    """fd_map_view of channels [c0, ...) of an NHWC buffer [G, H, W, C] (float32 or bf16): the decode reads a head output in place"""
+    assert buf.is_cuda and buf.is_contiguous() and buf.dim() == 4 and buf.dtype in (torch.float32, torch.bfloat16)
+    G, H, W, C = buf.shape
+    return MapView(buf.data_ptr() + int(c0) * buf.element_size(), H * W * C, 1, C, 0 if buf.dtype == torch.float32 else 1)
+
+
+def centerpoint_decode_views(views, G, cfg, device):
+    """fd_centerpoint_decode_maps on five fd_map_view (hm, reg, height, dim, rot); G = groups x samples.  Returns
+    (boxes7 [G,post,7], scores [G,post], cell [G,post] int32, count [G] int32)."""
+    L = _lib.load()
+    post = cfg.nms_post_max
+    boxes = torch.empty((G, post, 7), dtype=torch.float32, device=device)
+    scores = torch.empty((G, post), dtype=torch.float32, device=device)
+    cell = torch.empty((G, post), dtype=torch.int32, device=device)
+    count = torch.empty((G,), dtype=torch.int32, device=device)
+    ws = workspace.get("decode", L.fd_decode_workspace_bytes(G, ctypes.byref(cfg)), device)
+    check(L.fd_centerpoint_decode_maps(*[ctypes.byref(v) for v in views], G, ctypes.byref(cfg), _p(boxes), _p(scores), _p(cell), _p(count), _p(ws),
+                                       ws.numel(), _stream()), "fd_centerpoint_decode_maps")
+    return boxes, scores, cell, count
+
+
+def assemble_detections(boxes7, scores, cell, count, vel_view, B, post, step_group, step_vel_channel, step_label):
+    """fd_assemble_detections: -> (packed [B, S, post, 11] float32 rows x y z w l h vx vy yaw score label, counts [B, S] int32)"""
+    L = _lib.load()
+    S = len(step_group)
+    dev = boxes7.device
+    packed = torch.empty((B, S, post, 11), dtype=torch.float32, device=dev)
+    counts = torch.empty((B, S), dtype=torch.int32, device=dev)
+    arr = lambda v: (ctypes.c_int32 * S)(*[int(x) for x in v])  # noqa: E731
+    check(L.fd_assemble_detections(_p(boxes7), _p(scores), _p(cell), _p(count), ctypes.byref(vel_view), int(B), int(post), S, arr(step_group),
+                                   arr(step_vel_channel), arr(step_label), _p(packed), _p(counts), _stream()), "fd_assemble_detections")
+    return packed, counts
 
 
 def rotated_nms(boxes7, thresh):

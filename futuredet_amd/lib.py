@@ -17,6 +17,12 @@ c_size_t = ctypes.c_size_t
 c_float = ctypes.c_float
 
 
+class MapView(ctypes.Structure):
+    """fd_map_view (include/futuredet_hip.h): element (g, ch, cell) at data[g * group_stride + ch * channel_stride + cell * cell_stride]"""
+    _fields_ = [("data", ctypes.c_void_p), ("group_stride", ctypes.c_int64), ("channel_stride", ctypes.c_int64), ("cell_stride", ctypes.c_int64),
+                ("dtype", ctypes.c_int)]
+
+
 class DecodeCfg(ctypes.Structure):
     _fields_ = [("H", c_int), ("W", c_int), ("out_size_factor", c_float), ("voxel_x", c_float), ("voxel_y", c_float),
                 ("pc_x", c_float), ("pc_y", c_float), ("score_threshold", c_float), ("center_range", c_float * 6),
@@ -79,6 +85,10 @@ SIGNATURES = {
     "fd_centerpoint_decode": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
                                       c_int, ctypes.POINTER(DecodeCfg), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    "fd_centerpoint_decode_maps": (c_int, [ctypes.POINTER(MapView)] * 5 + [c_int, ctypes.POINTER(DecodeCfg), c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_size_t, c_void_p]),
+    "fd_assemble_detections": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(MapView), c_int, c_int, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_nms_workspace_bytes": (c_size_t, [c_int]),
     "fd_rotated_nms": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fd_boxes_iou_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),

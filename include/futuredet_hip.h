@@ -215,7 +215,29 @@ typedef struct fd_decode_cfg {
     int nms_pre_max, nms_post_max;
 } fd_decode_cfg;
 
+/* A head map as the decode reads it: element (group g, channel ch, BEV cell) of a float32 (dtype 0) or bf16 (dtype 1) tensor at
+ * data[g * group_stride + ch * channel_stride + cell * cell_stride] (strides in elements).  NCHW planes: channel_stride = H*W,
+ * cell_stride = 1.  A channel slice of an NHWC convolution output: channel_stride = 1, cell_stride = C_total, data = base + c0 --
+ * the decode then reads the head's output in place (center_head.py:559-697 works on the permuted NHWC tensors the same way). */
+typedef struct fd_map_view {
+    const void *data;
+    int64_t group_stride, channel_stride, cell_stride;
+    int dtype;
+} fd_map_view;
+
 size_t fd_decode_workspace_bytes(int G, const fd_decode_cfg *cfg);
+/* fd_centerpoint_decode on map views (any layout / float32 or bf16); the group index of a view is g = group * B + sample */
+int fd_centerpoint_decode_maps(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view *height, const fd_map_view *dim,
+                               const fd_map_view *rot, int G, const fd_decode_cfg *cfg_host, float *out_boxes7, float *out_scores,
+                               int32_t *out_cell, int32_t *out_count, void *workspace, size_t workspace_bytes, fd_stream_t stream);
+/* Final assembly of CenterHead.predict's output (center_head.py:559-570 standard head: step s = the shared boxes + velocity
+ * channels 2s, 2s+1; :606-607 dense head: step s = task s; :672-697 label offsets and concatenation): for sample b and output step s
+ * the kept boxes of decode group step_group[s] * B + b with the velocity read from ``vel`` (a map view whose group index is
+ * group * B + sample) at channels step_vel_channel[s], +1 and the label step_label[s], as packed rows
+ * [B, S, post_max, 11] = x y z w l h vx vy yaw score label (rows >= count zero) and counts_out [B, S].  step_* are HOST arrays (S <= 16). */
+int fd_assemble_detections(const float *boxes7, const float *scores, const int32_t *cell, const int32_t *count, const fd_map_view *vel,
+                           int B, int post_max, int S, const int32_t *step_group, const int32_t *step_vel_channel,
+                           const int32_t *step_label, float *packed, int32_t *counts_out, fd_stream_t stream);
 int fd_centerpoint_decode(const float *hm, int64_t hm_gstride, const float *reg, int64_t reg_gstride,
                           const float *height, int64_t height_gstride, const float *dim, int64_t dim_gstride,
                           const float *rot, int64_t rot_gstride, int G, const fd_decode_cfg *cfg_host,

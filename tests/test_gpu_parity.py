@@ -1954,3 +1954,34 @@ def test_eight_ranks_on_one_gpu_config4_strong_scaling(hip, tmp_path):
             want = net.forward_points([_dev(synthetic_cloud(seed=sid, target_points=15000))], cfg.voxel_generator, padded=False)[0]
             a, b = _rows(got[sid]), _rows(want)
             assert a.shape == b.shape and np.array_equal(a, b), "sample %d of the 8-rank run differs from the single-process bf16 run" % sid
+
+
+@pytest.mark.parametrize("variant,precision", [("forecast_n0", "fp32"), ("forecast_n3", "bf16"), ("forecast_n3dtf", "fp32"), ("forecast_n3dtf", "bf16")])
+def test_decode_reads_the_head_output_in_place(hip, variant, precision):
+    """predict_packed (the decode kernels read the conv plan's NHWC output through fd_map_view, velocities / labels / counts are
+    assembled by fd_assemble_detections: seven launches, no torch kernel) against the generic path on the same maps (NCHW float
+    copies per map + torch index_select / gather / cat): identical detections, bit for bit, for the standard head (one task,
+    velocity channels per step) and the dense forecast_feature head (one task per step), fp32 and bf16."""
+    from futuredet_amd.dist_infer import pack_results
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, _ = _build_pair(variant)
+    if precision == "bf16":
+        net.set_precision(torch.bfloat16)
+    clouds = [synthetic_cloud(seed=s, target_points=25000) for s in (21, 22)]
+    with torch.no_grad():
+        for B in (1, 2):
+            exs = [_bf16_example(cfg, cl) for cl in clouds[:B]]
+            maps = []
+            for v, c, n, _ in exs:
+                maps.append(_hip_maps(net, cfg, v, c, n)[1])
+            x = torch.cat(maps, 0)
+            preds = net.bbox_head(x)
+            assert getattr(preds[0], "raw", None) is not None, "the plan's head output must carry its buffer"
+            packed, counts = net.bbox_head.predict_packed(preds, cfg.test_cfg)
+            plain = [dict(pd) for pd in preds]  # plain dicts: no buffer attached -> the generic path
+            assert net.bbox_head.predict_packed(plain, cfg.test_cfg) is None
+            want_p, want_c = pack_results(*net.bbox_head.predict_padded(plain, cfg.test_cfg))
+            assert torch.equal(counts, want_c) and int(counts.sum()) > 0
+            assert torch.equal(packed, want_p), "%s %s B=%d: fused decode output differs from the generic path" % (variant, precision, B)
+    report("%s %s: decode on the in-place head output == generic path (B = 1, 2)" % (variant, precision), 0.0, 0.0)
