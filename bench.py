@@ -301,15 +301,20 @@ def main():
     # whole-sweep graphs: one StaticStep per stream (VoxelNet without a bev_map input).  Instrumented steps (per-launch HIP
     # events around the sparse convs) cannot run inside a graph and take the eager path.
     use_graph = (args.graph == 1 or (args.graph < 0 and B < 8)) and bev is None
-    if use_graph and not is_pp and args.dtype == "fp32" and B * args.max_voxels * 8 >= (1 << 23):
-        use_graph = False  # row capacities beyond the fp32 kernel's 2^23 input rows (StaticStep.capture refuses them)
+    # (the sparse levels of a captured step are sized by 1.5 x the warm-up cloud's row counts, not by the data-free bounds: the
+    #  fp32 kernel's 2^23-row packing limit and the ~2 GB of scratch per stream of round 2 are gone; a sweep that needs more rows is
+    #  detected from its level counts and re-run on the eager path -- counted in config.graph_overflows)
     static_steps = {}
+    last_static = [None]   # the StaticStep the last forward() went through (None: eager launches)
+    n_overflow = [0]       # sweeps whose row counts exceeded the captured capacities and were re-run on the eager path
     capacity = (max(len(host[s]) for s in uniq) + 4095) // 4096 * 4096
 
     def forward(clouds):
         step = static_steps.get(torch.cuda.current_stream(dev).cuda_stream) if (use_graph and not prof.enabled) else None
         if step is not None:
+            last_static[0] = step
             return step(clouds)  # (packed [B,S,post,11], counts [B,S]) written by the decode's last kernel
+        last_static[0] = None
         return net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded="packed")
 
     def sync_all():
@@ -336,8 +341,18 @@ def main():
                 clouds = [resident[s] for s in seeds[mb]] if from_host is None else from_host(si, mb, st)
                 prof.begin(mb)
                 p, c = forward(clouds)
+                chk = None
+                stp = last_static[0]
+                if stp is not None and stp.caps is not None:  # capacities from a high-water mark: the level counts travel with the result
+                    lslot = ("lc", n_fwd[0] % ring)
+                    if lslot not in pinned:
+                        pinned[lslot] = torch.empty((len(stp.caps),), dtype=torch.int32, pin_memory=True)
+                    pinned[lslot].copy_(stp.level_counts, non_blocking=True)
+                    chk = (stp, pinned[lslot], clouds)
                 if per_step_gather and not one_dev:
-                    parts.append((p, c, None, st))
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    parts.append((p, c, None, st, chk, ev))
                 else:
                     slot = n_fwd[0] % ring
                     if slot not in pinned or pinned[slot][0].shape != p.shape:
@@ -347,17 +362,27 @@ def main():
                     hc.copy_(c, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(st)
-                    parts.append((hp, hc, ev, st))
+                    parts.append((hp, hc, ev, st, chk, ev))
         return parts
 
     def retire_step(parts):
         """Detections of one step on the host (and, with several ranks, gathered to every rank by one fixed-shape all_gather)."""
         ps, cs = [], []
-        for p, c, ev, st in parts:
+        for p, c, ev, st, chk, ev_chk in parts:
             if ev is not None:
                 ev.synchronize()
             else:
                 torch.cuda.current_stream(dev).wait_stream(st)
+            if chk is not None:
+                ev_chk.synchronize()
+                stp, lc, clouds = chk
+                if stp.overflowed(lc.tolist()):  # rare: this sweep needs more rows than the captured step holds -> eager launches
+                    n_overflow[0] += 1
+                    with torch.cuda.stream(st):
+                        p, c = net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded="packed")
+                        if ev is not None:
+                            p, c = p.cpu(), c.cpu()
+                    st.synchronize()
             ps.append(p)
             cs.append(c)
         p = torch.cat(ps, 0) if len(ps) > 1 else ps[0]
@@ -424,7 +449,8 @@ def main():
                 if use_graph:
                     from futuredet_amd.detectors import StaticStep
                     try:
-                        step = StaticStep(net, cfg.voxel_generator, capacity, batch_size=B, ndim=host[uniq[0]].shape[1], packed=True)
+                        step = StaticStep(net, cfg.voxel_generator, capacity, batch_size=B, ndim=host[uniq[0]].shape[1], packed=True,
+                                          row_caps="datafree" if is_pp else "auto")
                         step.warm_up([resident[s] for s in seeds[0]])
                         step.capture()
                         static_steps[st.cuda_stream] = step
@@ -520,6 +546,7 @@ def main():
                    "parallelism": "sample-sharded x%d (no data-path collective; one fixed-shape all_gather of the detections %s)"
                                   % (world, "per step" if per_step_gather or world == 1 else "after the last step, as the reference's eval loop does"),
                    "detections_last_step": int(host_c.sum()),
+                   "graph_overflows": n_overflow[0],
                    "replicas": "rank 0's weights broadcast to all ranks, checksum %.6e equal on all %d rank(s)" % (replica_checksum, world),
                    "host": "%s logical CPUs pinned per rank; pinned host memory per rank: %.1f MB of clouds + result ring"
                            % (len(cpus) if cpus else "all", sum(h.numel() * 4 for h in host.values()) / 1e6)},

@@ -103,7 +103,7 @@ class SpMiddleResNetFHD(nn.Module):
                 (self.conv4[0], self.conv4[1], [self.conv4[3], self.conv4[4]], False),
                 (self.extra_conv[0], self.extra_conv[1], [], False)]
 
-    def build_indexes(self, mark_fn, batch_size, input_shape, device, voxels=None, static=False, expected=None):
+    def build_indexes(self, mark_fn, batch_size, input_shape, device, voxels=None, static=False, expected=None, row_caps=None):
         """Builds the five sparse indexes.  ``mark_fn(index0)`` marks the input voxels.  One host read.  With
         ``voxels = (coors [B*n_max,4], nvox [B], n_max)`` the whole pyramid is built by two library calls; with
         ``static=True`` there is no host read at all: every level is sized by its row capacity and the counts stay on the
@@ -112,7 +112,7 @@ class SpMiddleResNetFHD(nn.Module):
         if voxels is not None:
             geoms = [self._stages()[lvl][0].geometry() for lvl in range(1, 5)]
             return hip_ops.build_pyramid(voxels[0], voxels[1], voxels[2], batch_size, (D, H, W), geoms, device, static=static,
-                                         expected=expected)
+                                         expected=expected, row_caps=row_caps)
         assert not static, "static indexes are built from the voxelizer's device output (voxels=...)"
         counts = torch.zeros((5,), dtype=torch.int32, device=device)
         idx = [hip_ops.SparseIndex(batch_size, D, H, W, device)]

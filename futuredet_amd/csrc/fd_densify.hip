@@ -15,7 +15,7 @@ __device__ inline unsigned short f2bf(float v) {
 template <bool IN_BF16, bool OUT_BF16>
 __global__ void __launch_bounds__(256) densify_kernel(const void *__restrict__ feats, int C, const unsigned long long *__restrict__ words,
                                                       const int *__restrict__ prefix, fd::IndexGeom g, void *__restrict__ out,
-                                                      int64_t sb, int64_t sc, int64_t sy, int64_t sx) {
+                                                      int64_t sb, int64_t sc, int64_t sy, int64_t sx, int64_t n_rows) {
     // thread -> (cell, channel): channel index fastest so channels-last stores coalesce; for NCHW the x index
     // of neighbouring cells is 8 apart in the tiled column order, writes go through L2 either way.
     const int CD = C * g.D;
@@ -31,8 +31,10 @@ __global__ void __launch_bounds__(256) densify_kernel(const void *__restrict__ f
     float v = 0.0f;
     if ((w >> d) & 1ull) {
         const int row = prefix[cell] + __popcll(w & ((1ull << d) - 1ull));
-        if (IN_BF16) v = __uint_as_float(((unsigned)reinterpret_cast<const unsigned short *>(feats)[(int64_t)row * C + c]) << 16);
-        else v = reinterpret_cast<const float *>(feats)[(int64_t)row * C + c];
+        if (row < n_rows) {  // (a capacity-sized level whose count overflowed: rows past the feature matrix read as zero)
+            if (IN_BF16) v = __uint_as_float(((unsigned)reinterpret_cast<const unsigned short *>(feats)[(int64_t)row * C + c]) << 16);
+            else v = reinterpret_cast<const float *>(feats)[(int64_t)row * C + c];
+        }
     }
     const int64_t o = b * sb + ch * sc + y * sy + x * sx;
     if (OUT_BF16) reinterpret_cast<unsigned short *>(out)[o] = f2bf(v);
@@ -45,7 +47,7 @@ __global__ void __launch_bounds__(256) densify_kernel(const void *__restrict__ f
 template <bool IN_BF16>
 __global__ void __launch_bounds__(256) densify_nchw_tile(const void *__restrict__ feats, int C, const unsigned long long *__restrict__ words,
                                                          const int *__restrict__ prefix, fd::IndexGeom g, float *__restrict__ out,
-                                                         int64_t sb, int64_t sc, int64_t sy, int64_t sx) {
+                                                         int64_t sb, int64_t sc, int64_t sy, int64_t sx, int64_t n_rows) {
     extern __shared__ float s_tile[];  // [64 cells][CH + 1], CH = channels of this workgroup (blockIdx.y selects the chunk)
     const int CD = C * g.D, CH = CD / gridDim.y, ch0 = blockIdx.y * CH, ld = CH + 1;
     const int64_t cell0 = (int64_t)blockIdx.x * 64;
@@ -65,8 +67,10 @@ __global__ void __launch_bounds__(256) densify_nchw_tile(const void *__restrict_
         float v = 0.0f;
         if ((w >> d) & 1ull) {
             const int row = s_p[cell] + __popcll(w & ((1ull << d) - 1ull));
-            if (IN_BF16) v = __uint_as_float(((unsigned)reinterpret_cast<const unsigned short *>(feats)[(int64_t)row * C + c]) << 16);
-            else v = reinterpret_cast<const float *>(feats)[(int64_t)row * C + c];
+            if (row < n_rows) {
+                if (IN_BF16) v = __uint_as_float(((unsigned)reinterpret_cast<const unsigned short *>(feats)[(int64_t)row * C + c]) << 16);
+                else v = reinterpret_cast<const float *>(feats)[(int64_t)row * C + c];
+            }
         }
         s_tile[cell * ld + (c - c0) * g.D + d] = v;
     }
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(256) densify_nchw_tile(const void *__restrict_
 }  // namespace
 
 extern "C" int fd_densify(const void *feats, int c, int dtype, const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W,
-                          void *out, int out_dtype, int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x,
+                          void *out, int out_dtype, int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x, int64_t n_rows,
                           fd_stream_t stream) {
     FD_REQUIRE(words && prefix && out, "fd_densify: null argument");  // feats may be null when no cell is active
     FD_REQUIRE(c > 0 && D > 0 && D <= 64, "fd_densify: bad shape");
@@ -97,19 +101,19 @@ extern "C" int fd_densify(const void *feats, int c, int dtype, const uint64_t *w
     if (out_dtype == 0 && stride_x == 1 && tile_lds <= 60 * 1024) {  // NCHW float32: tile kernel with wider stores
         const dim3 tgrid((unsigned)(g.num_cols() / 64), (unsigned)chunks);
         if (dtype == 0)
-            hipLaunchKernelGGL((densify_nchw_tile<false>), tgrid, dim3(256), tile_lds, s, feats, c, wd, prefix, g, (float *)out, stride_b, stride_c, stride_y, stride_x);
+            hipLaunchKernelGGL((densify_nchw_tile<false>), tgrid, dim3(256), tile_lds, s, feats, c, wd, prefix, g, (float *)out, stride_b, stride_c, stride_y, stride_x, n_rows);
         else
-            hipLaunchKernelGGL((densify_nchw_tile<true>), tgrid, dim3(256), tile_lds, s, feats, c, wd, prefix, g, (float *)out, stride_b, stride_c, stride_y, stride_x);
+            hipLaunchKernelGGL((densify_nchw_tile<true>), tgrid, dim3(256), tile_lds, s, feats, c, wd, prefix, g, (float *)out, stride_b, stride_c, stride_y, stride_x, n_rows);
         return fd::check_launch("fd_densify(tile)");
     }
     if (dtype == 0 && out_dtype == 0)
-        hipLaunchKernelGGL((densify_kernel<false, false>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x);
+        hipLaunchKernelGGL((densify_kernel<false, false>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x, n_rows);
     else if (dtype == 0 && out_dtype == 1)
-        hipLaunchKernelGGL((densify_kernel<false, true>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x);
+        hipLaunchKernelGGL((densify_kernel<false, true>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x, n_rows);
     else if (dtype == 1 && out_dtype == 0)
-        hipLaunchKernelGGL((densify_kernel<true, false>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x);
+        hipLaunchKernelGGL((densify_kernel<true, false>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x, n_rows);
     else if (dtype == 1 && out_dtype == 1)
-        hipLaunchKernelGGL((densify_kernel<true, true>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x);
+        hipLaunchKernelGGL((densify_kernel<true, true>), grid, dim3(256), 0, s, feats, c, wd, prefix, g, out, stride_b, stride_c, stride_y, stride_x, n_rows);
     else {
         fd::set_error("fd_densify: bad dtype");
         return FD_EINVAL;

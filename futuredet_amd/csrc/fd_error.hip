@@ -90,7 +90,7 @@ int fd::fill_words(void *p, uint32_t value, size_t n_words, hipStream_t stream) 
 }
 
 extern "C" const char *fd_last_error(void) { return fd::g_err; }
-extern "C" int fd_abi_version(void) { return 3; }
+extern "C" int fd_abi_version(void) { return 4; }
 
 extern "C" int fd_tuning_set(const char *name, int value) {
     FD_REQUIRE(name, "fd_tuning_set: null name");

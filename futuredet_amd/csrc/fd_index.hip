@@ -162,6 +162,7 @@ struct PyramidLevels {
     const unsigned long long *words[kMaxLevels];
     int *prefix[kMaxLevels];
     int *coords[kMaxLevels];
+    long long coords_rows[kMaxLevels];  // rows of coords[l] (0 = unbounded)
     IndexGeom geom[kMaxLevels];
 };
 
@@ -241,10 +242,12 @@ __global__ void __launch_bounds__(256) idx_coords_ml(PyramidLevels L) {
     int b, y, x;
     fd::col_to_byx(g, col, b, y, x);
     int row = L.prefix[l][col];
+    const long long cap = L.coords_rows[l] > 0 ? L.coords_rows[l] : 0x7fffffffll;
     while (w) {
         int z = __builtin_ctzll(w);
         w &= w - 1;
-        reinterpret_cast<int4 *>(coords)[row++] = make_int4(b, z, y, x);
+        if (row < cap) reinterpret_cast<int4 *>(coords)[row] = make_int4(b, z, y, x);  // (an overflowing capacity-sized level stays inside its table)
+        ++row;
     }
 }
 
@@ -257,6 +260,7 @@ bool fill_levels(PyramidLevels &L, int B, int n_levels, const fd_index_level *le
         L.words[l] = (const unsigned long long *)lv.words;
         L.prefix[l] = lv.prefix;
         L.coords[l] = lv.coords;
+        L.coords_rows[l] = lv.coords_rows;
         L.blk0[l] = (int)blk;
         L.cblk0[l] = (int)cblk;
         const int64_t nc = L.geom[l].num_cols();

@@ -158,14 +158,15 @@ class VoxelNet(SingleStageDetector):
 
     # ------------------------------------------------------------------------------------------------ fast path
     @torch.no_grad()
-    def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True, counts=None, static=False, expected=None):
+    def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True, counts=None, static=False, expected=None, row_caps=None):
         """clouds: list of device float32 [N_i, 5] tensors (one merged multi-sweep cloud per sample);
         voxel_cfg: the config's ``voxel_generator`` dict (range, voxel_size, max_points_in_voxel, max_voxel_num).
         Returns predict_padded()'s tuple (padded=True) or the list of per-sample dicts.
         ``counts``: per cloud a device int32[1] with its number of valid rows (fixed-capacity buffers, loading.assemble_device).
         ``static=True``: no host read-back anywhere -- sparse levels are sized by their row capacities and every kernel takes
         its count from the device, so the call can be captured into one hipGraph (StaticStep); ``expected`` = typical row
-        counts per level (launch heuristics only).  Results are identical to the default mode."""
+        counts per level (launch heuristics only).  Results are identical to the default mode.  ``row_caps``: per-level row
+        capacities below the data-free bounds (static mode; see hip_ops.build_pyramid -- the caller checks for overflow)."""
         assert not self.training
         assert not (static and not padded), "the static step returns the padded device tuple"
         mark_stage = getattr(self, "stage_hook", None) or (lambda name: None)
@@ -195,7 +196,7 @@ class VoxelNet(SingleStageDetector):
 
         mark_stage("voxelize")
         bb = self.backbone
-        idx = bb.build_indexes(mark, B, list(grid), dev, voxels=(coors, nvox, max_voxels), static=static, expected=expected)
+        idx = bb.build_indexes(mark, B, list(grid), dev, voxels=(coors, nvox, max_voxels), static=static, expected=expected, row_caps=row_caps)
         # (static: idx[l].n is the level's capacity; the counts are read by whoever wants them from level_counts, later)
         self.__dict__["last_level_counts"] = torch.cat([ix.n_dev for ix in idx]) if static else [ix.n for ix in idx]
         mark_stage("index")
@@ -248,9 +249,15 @@ class StaticStep(object):
                                                                    # static tensors (valid until the next call on this stream)
     One StaticStep belongs to one stream (the one current at capture); sweeps in flight on several streams use one each."""
 
-    def __init__(self, model, voxel_cfg, capacity, batch_size=1, ndim=5, packed=False):
+    def __init__(self, model, voxel_cfg, capacity, batch_size=1, ndim=5, packed=False, row_caps="datafree", headroom=1.5):
+        """``row_caps``: "datafree" sizes the sparse levels by bounds that hold for ANY cloud (no overflow possible; ~2 GB of
+        scratch per step at the bench configuration, 1.28 M / 1.43 M rows for levels 1 / 2 where a 300k-point cloud has 0.27 M /
+        0.16 M); "auto" sizes them by ``headroom`` x the counts of the warm-up clouds (+ 4096 rows): a sweep that needs more rows
+        than that is detected -- ``overflowed()`` / ``run_checked()`` -- and must be re-run on the eager path."""
         self.model, self.voxel_cfg = model, voxel_cfg
         self.padded = "packed" if packed else True  # packed: outputs = (packed [B,S,post,11], counts [B,S]) instead of four tensors
+        self.row_caps_mode, self.headroom = row_caps, float(headroom)
+        self.caps = None  # per-level row capacities of the captured step (None: data-free bounds)
         self.B, self.capacity, self.ndim = int(batch_size), int(capacity), int(ndim)
         dev = next(model.parameters()).device
         self.points = torch.zeros((self.B, self.capacity, self.ndim), dtype=torch.float32, device=dev)
@@ -285,7 +292,7 @@ class StaticStep(object):
         if static:  # the captured sweep keeps scratch buffers of its own (not those of whatever stream it is captured on)
             with hip_ops.workspace.scope(id(self)):
                 return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, padded=self.padded,
-                                        counts=[self.counts[b:b + 1] for b in range(self.B)], static=True, expected=self.expected)
+                                        counts=[self.counts[b:b + 1] for b in range(self.B)], static=True, expected=self.expected, row_caps=self.caps)
         return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, padded=self.padded,
                                 counts=[self.counts[b:b + 1] for b in range(self.B)], static=static, expected=self.expected)
 
@@ -305,7 +312,14 @@ class StaticStep(object):
             raise RuntimeError("StaticStep.warm_up(clouds) must run before the capture")
         mv = self.voxel_cfg["max_voxel_num"]
         cap0 = self.B * int(mv[1] if isinstance(mv, (list, tuple)) else mv)
-        if getattr(m.backbone, "compute_dtype", None) == torch.float32 and isinstance(m, VoxelNet) and cap0 * 8 >= (1 << 23):
+        self.caps = None
+        if self.row_caps_mode != "datafree" and isinstance(m, VoxelNet) and self.expected:
+            if self.row_caps_mode == "auto":
+                self.caps = [cap0] + [int(self.headroom * e) + 4096 for e in self.expected[1:]]  # (level 0 is capped by the voxelizer itself)
+            else:
+                self.caps = [int(c) for c in self.row_caps_mode]
+        worst = max(self.caps[1:]) if self.caps else cap0 * 8
+        if getattr(m.backbone, "compute_dtype", None) == torch.float32 and isinstance(m, VoxelNet) and worst >= (1 << 23):
             # the pair-compacting fp32 kernel packs (input row, local row) into 32 bits: 2^23 input rows at most; a capacity
             # beyond that would send every launch to the slower register kernel
             raise NotImplementedError("StaticStep: %d x max_voxels gives sparse levels a row capacity >= 2^23 (fp32 kernel limit); "
@@ -333,6 +347,22 @@ class StaticStep(object):
         self._load(clouds)
         self.graph.replay()
         return self.outputs
+
+    def overflowed(self, level_counts_host=None):
+        """True when the last replay needed more rows on some level than the captured capacities (row_caps="auto"): its outputs
+        are then wrong and the sweep has to be re-run eagerly.  Synchronises unless the counts are passed in (host copy of
+        ``level_counts`` taken after the replay)."""
+        if self.caps is None or self.level_counts is None or not len(self.caps):
+            return False
+        lc = self.level_counts.cpu().tolist() if level_counts_host is None else [int(v) for v in level_counts_host]
+        return any(n > c for n, c in zip(lc, self.caps))
+
+    def run_checked(self, clouds):
+        """replay + overflow check (one synchronisation) + eager re-run of an overflowing sweep: always-correct results"""
+        out = self(clouds)
+        if self.overflowed():
+            return self.model.forward_points(clouds, self.voxel_cfg, padded=self.padded)
+        return out
 
 
 @DETECTORS.register_module
@@ -372,7 +402,7 @@ class PointPillars(SingleStageDetector):
         return self.bbox_head.predict(example, preds, self.test_cfg)
 
     @torch.no_grad()
-    def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True, counts=None, static=False, expected=None):
+    def forward_points(self, clouds, voxel_cfg, bev_map=None, padded=True, counts=None, static=False, expected=None, row_caps=None):
         """Same contract as VoxelNet.forward_points.  This path never reads anything back (pillar count and point counts stay on
         the device), so ``static`` changes nothing here; ``counts`` = device row counts of fixed-capacity cloud buffers."""
         assert not self.training

@@ -226,12 +226,15 @@ class _PyramidPlan(object):
 _pyramid_plans = {}
 
 
-def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device, static=False, expected=None):
+def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device, static=False, expected=None, row_caps=None):
     """All sparse indexes of the backbone with two library calls and ONE host read: level 0 (D,H,W = shape0) marked
     from the voxelizer output ``coors`` [B*n_max, 4] / ``nvox`` [B]; level l from level l-1 by geoms[l-1] =
     (ksize, stride, pad).  Returns the list of finalised SparseIndex (coords materialised).
     ``static=True``: NO host read -- every level gets its row capacity (_PyramidPlan.row_caps) as ``n``, the counts stay in
-    ``n_dev`` and ``expected`` (typical counts, e.g. of an earlier sweep) only steers launch heuristics."""
+    ``n_dev`` and ``expected`` (typical counts, e.g. of an earlier sweep) only steers launch heuristics.  ``row_caps`` (one
+    per level) replaces the data-free capacities by smaller ones (a high-water mark with head room): every kernel then works on
+    min(capacity, count) rows, and a sweep whose count exceeds a capacity is DETECTABLE -- counts[l] > capacity -- but not
+    computed correctly; the caller re-runs it on the eager path (detectors.StaticStep does)."""
     L = _lib.load()
     key = (int(B), tuple(int(v) for v in shape0), tuple((tuple(k), tuple(s), tuple(p)) for k, s, p in geoms), str(device))
     plan = _pyramid_plans.get(key)
@@ -264,6 +267,8 @@ def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device, static=False, ex
           "fd_index_pyramid")
     if static:
         host = plan.row_caps(int(B) * int(n_max))
+        if row_caps is not None:
+            host = [min(int(a), int(b)) for a, b in zip(host, row_caps)]
         for l, ix in enumerate(idx):
             ix.static = True
             ix.n_expected = int(expected[l]) if expected is not None else 0
@@ -276,6 +281,7 @@ def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device, static=False, ex
         ix.n = int(host[l])
         ix.coords = coords_all[o:o + ix.n]
         levels[l].coords = (coords_all.data_ptr() + 16 * o) if ix.n else None
+        levels[l].coords_rows = ix.n
         o += ix.n
     check(L.fd_index_pyramid_coords(plan.B, len(shapes), levels, _stream()), "fd_index_pyramid_coords")
     return idx
@@ -375,7 +381,7 @@ def densify(feats, index, out_dtype=None, channels_last=False, out=None):
         out_dtype = out.dtype
     sb, sc, sy, sx = out.stride()
     check(L.fd_densify(_p(feats), C, _DT[feats.dtype], _p(index.words), _p(index.prefix), index.B, index.D, index.H,
-                       index.W, _p(out), _DT[out_dtype], sb, sc, sy, sx, _stream()), "fd_densify")
+                       index.W, _p(out), _DT[out_dtype], sb, sc, sy, sx, int(feats.shape[0]), _stream()), "fd_densify")
     return out
 
 

@@ -32,7 +32,7 @@ class DecodeCfg(ctypes.Structure):
 class IndexLevel(ctypes.Structure):  # struct fd_index_level
     _fields_ = [("D", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("ksize", ctypes.c_int32 * 3),
                 ("stride", ctypes.c_int32 * 3), ("pad", ctypes.c_int32 * 3), ("words", c_void_p), ("prefix", c_void_p),
-                ("coords", c_void_p)]
+                ("coords", c_void_p), ("coords_rows", ctypes.c_int64)]
 
 
 # name -> (restype, argtypes); this table is checked against include/futuredet_hip.h by the tests
@@ -62,7 +62,7 @@ SIGNATURES = {
     "fd_spconv_ranges_workspace_bytes": (c_size_t, [c_i64]),
     "fd_spconv_ranges": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fd_densify": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_i64,
-                           c_i64, c_i64, c_i64, c_void_p]),
+                           c_i64, c_i64, c_i64, c_i64, c_void_p]),
     "fd_conv2d_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fd_conv2d_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "fd_conv2d_nhwc_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -149,7 +149,8 @@ int fd_spconv_ranges(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_ou
  * ------------------------------------------------------------------------------------------------- */
 int fd_densify(const void *feats, int c, int dtype, const uint64_t *words, const int32_t *prefix, int B, int D,
                int H, int W, void *out, int out_dtype, int64_t stride_b, int64_t stride_c, int64_t stride_y,
-               int64_t stride_x, fd_stream_t stream);
+               int64_t stride_x, int64_t n_rows /* rows of feats: an index row >= n_rows (a capacity-sized level that overflowed) reads as zero */,
+               fd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Dense 2-D convolution, bf16 NHWC, fp32 accumulate, fused bias + ReLU (hand-written MFMA implicit GEMM).
@@ -356,6 +357,8 @@ typedef struct fd_index_level {
     uint64_t *words;
     int32_t *prefix;
     int32_t *coords; /* [n_l, 4] or NULL */
+    int64_t coords_rows; /* rows of ``coords``: an active voxel whose row index is >= coords_rows is not written (capacity-sized
+                          * levels of the sync-free step; 0 = unbounded, the caller sized coords from the counts) */
 } fd_index_level;
 int fd_index_pyramid(const int32_t *coords, const int32_t *n_dev, int64_t n_max_per_sample, int B, int n_levels,
                      const fd_index_level *levels_host, int32_t *counts_dev, void *workspace, size_t workspace_bytes,

@@ -1985,3 +1985,55 @@ def test_decode_reads_the_head_output_in_place(hip, variant, precision):
             assert torch.equal(counts, want_c) and int(counts.sum()) > 0
             assert torch.equal(packed, want_p), "%s %s B=%d: fused decode output differs from the generic path" % (variant, precision, B)
     report("%s %s: decode on the in-place head output == generic path (B = 1, 2)" % (variant, precision), 0.0, 0.0)
+
+
+def test_static_step_high_water_mark_capacities_and_overflow(hip):
+    """sparse levels of a captured sweep sized from a high-water mark (1.5 x the warm-up cloud's row counts) instead
+    of the data-free bounds.  A sweep within the capacities is bit-identical to the eager path; a cloud that needs MORE rows is
+    detected from the level counts (overflowed()), run_checked() returns the eager result for it, nothing is written outside the
+    tables (the next small sweep through the same graph is still exact); and an fp32 batch of 8 -- whose data-free capacities
+    exceed the fp32 kernel's 2^23-row packing limit, so round 2 refused to capture it -- is captured and exact."""
+    from futuredet_amd.detectors import StaticStep
+    from futuredet_amd.synth import synthetic_cloud
+
+    cfg, net, _ = _build_pair("forecast_n0")
+    vg = cfg.voxel_generator
+    small, big = _dev(synthetic_cloud(seed=1, target_points=15000)), _dev(synthetic_cloud(seed=2, target_points=85000))
+
+    def same(a, b):
+        k = int(a[3].max())
+        return torch.equal(a[3], b[3]) and torch.equal(a[0][:, :, :k], b[0][:, :, :k]) and torch.equal(a[1][:, :, :k], b[1][:, :, :k])
+
+    with torch.no_grad():
+        step = StaticStep(net, vg, capacity=90112, row_caps="auto", headroom=1.5)
+        step.warm_up([small])
+        got = [t.clone() for t in step([small])]
+        torch.cuda.synchronize()
+        free = StaticStep(net, vg, capacity=90112)  # data-free capacities, for the comparison of sizes
+        free.expected = step.expected
+        free.capture()
+        assert free.caps is None and step.caps is not None and step.caps[1] < 0.2 * 8 * 160000, step.caps
+        assert not step.overflowed()
+        want_small = net.forward_points([small], vg)
+        assert same(want_small, got)
+        step([big])
+        torch.cuda.synchronize()
+        assert step.overflowed(), (step.level_counts.cpu().tolist(), step.caps)
+        want_big = net.forward_points([big], vg)
+        assert same(want_big, step.run_checked([big]))
+        again = step([small])
+        torch.cuda.synchronize()
+        assert not step.overflowed() and same(want_small, again), "an overflowing sweep must not damage the captured step"
+        # fp32, 8 clouds per sweep
+        clouds = [_dev(synthetic_cloud(seed=30 + i, target_points=12000 + 1500 * i)) for i in range(8)]
+        with pytest.raises(NotImplementedError):
+            s8 = StaticStep(net, vg, capacity=24576, batch_size=8)
+            s8.warm_up(clouds)
+            s8.capture()
+        s8 = StaticStep(net, vg, capacity=24576, batch_size=8, row_caps="auto")
+        s8.warm_up(clouds)
+        got8 = s8(clouds)
+        torch.cuda.synchronize()
+        assert not s8.overflowed() and same(net.forward_points(clouds, vg), got8)
+    report("static step with high-water-mark capacities: exact within, detected + eager beyond, fp32 batch of 8 captured", 0.0, 0.0,
+           "(caps %s)" % step.caps)
