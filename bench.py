@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.json configs[] preset (1-based as in VERDICT)")
-    ap.add_argument("--variant", default="forecast_n0", choices=["forecast_n0", "forecast_n3", "forecast_n3dtf", "pp_n3dtf"])
+    ap.add_argument("--variant", default="forecast_n0", choices=["forecast_n0", "forecast_n3", "forecast_n3dtf", "forecast_n3dtfm", "pp_n3dtf"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--points", type=int, default=300000)
     ap.add_argument("--batch", type=int, default=1, help="clouds per rank per forward pass")
@@ -300,7 +300,7 @@ def main():
 
     # whole-sweep graphs: one StaticStep per stream (VoxelNet without a bev_map input).  Instrumented steps (per-launch HIP
     # events around the sparse convs) cannot run inside a graph and take the eager path.
-    use_graph = (args.graph == 1 or (args.graph < 0 and B < 8)) and bev is None
+    use_graph = args.graph == 1 or (args.graph < 0 and B < 8)
     # (the sparse levels of a captured step are sized by 1.5 x the warm-up cloud's row counts, not by the data-free bounds: the
     #  fp32 kernel's 2^23-row packing limit and the ~2 GB of scratch per stream of round 2 are gone; a sweep that needs more rows is
     #  detected from its level counts and re-run on the eager path -- counted in config.graph_overflows)
@@ -313,7 +313,7 @@ def main():
         step = static_steps.get(torch.cuda.current_stream(dev).cuda_stream) if (use_graph and not prof.enabled) else None
         if step is not None:
             last_static[0] = step
-            return step(clouds)  # (packed [B,S,post,11], counts [B,S]) written by the decode's last kernel
+            return step(clouds, bev_map=bev)  # (packed [B,S,post,11], counts [B,S]) written by the decode's last kernel
         last_static[0] = None
         return net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded="packed")
 
@@ -451,7 +451,7 @@ def main():
                     try:
                         step = StaticStep(net, cfg.voxel_generator, capacity, batch_size=B, ndim=host[uniq[0]].shape[1], packed=True,
                                           row_caps="datafree" if is_pp else "auto")
-                        step.warm_up([resident[s] for s in seeds[0]])
+                        step.warm_up([resident[s] for s in seeds[0]], bev_map=bev)
                         step.capture()
                         static_steps[st.cuda_stream] = step
                     except Exception as e:  # the eager launches are always available (the line then says so)

@@ -179,9 +179,18 @@ class HeadPlan(object):
     [0,c) and receive the previous task's feats in [c,2c) (task 0 reads the same buffer through zero weights)."""
 
     def __init__(self, head, dtype=torch.bfloat16):
-        assert not head.bev_map
         self.dtype = dtype
         self.shared = _convs_from_stack(head.shared_conv, dtype)
+        # bev_map branch (center_head.py:336-341,380-381: x = shared_conv(x) + bev_conv(bev_map)): three 3x3 convs from 6 map
+        # channels; the 6 channels are padded to the kernel's input granule with zero weights
+        self.bev = None
+        if head.bev_map:
+            st = fold_stack(head.bev_conv, torch.float32, False)
+            g = granule(dtype)
+            w0 = st[0].weight
+            self.bev_cin = w0.shape[1]
+            w0 = torch.cat([w0, torch.zeros((w0.shape[0], (-w0.shape[1]) % g) + tuple(w0.shape[2:]), dtype=w0.dtype, device=w0.device)], dim=1)
+            self.bev = [_Conv(w0, st[0].bias, 1, True, dtype)] + [_Conv(f.weight, f.bias, f.stride, f.relu, dtype) for f in st[1:]]
         self.ff = bool(head.forecast_feature)
         self.tasks = []
         self.pre = []
@@ -222,7 +231,18 @@ class HeadPlan(object):
                 c2 = _Conv(w2, b2, 1, False, dtype)
             self.tasks.append((_Conv(w1, b1, 1, True, dtype), c2, names, couts))
 
-    def __call__(self, x):  # x [B,H,W,C] of the plan's dtype -> list of dicts of NCHW float32 tensors
+    def __call__(self, x, bev_map=None):  # x [B,H,W,C] of the plan's dtype (bev_map [B,6,H,W]) -> list of HeadMaps
+        if self.bev is not None:
+            assert bev_map is not None, "this head has a bev_map branch"
+            for conv in self.shared:
+                x = conv(x)
+            B, H, W, _ = x.shape
+            y = torch.zeros((B, H, W, self.bev[0].cin), dtype=self.dtype, device=x.device)
+            y[..., : self.bev_cin] = bev_map.permute(0, 2, 3, 1)
+            for conv in self.bev:
+                y = conv(y)
+            x = x + y
+            return self._tasks(x, None)
         for conv in self.shared[:-1]:
             x = conv(x)
         last = self.shared[-1]
@@ -239,6 +259,17 @@ class HeadPlan(object):
             cat[1][..., :hc].copy_(cat[0][..., :hc])
         else:
             x = last(x)
+            cat = None
+        return self._tasks(x, cat)
+
+    def _tasks(self, x, cat):
+        hc = self.shared[-1].cout
+        if self.ff and cat is None:  # (bev_map head: x is already complete; lay the concat buffers out from it)
+            B, H, W, _ = x.shape
+            cat = [torch.empty((B, H, W, 2 * hc), dtype=self.dtype, device=x.device) for _ in range(2)]
+            cat[0][..., hc:].zero_()
+            cat[0][..., :hc].copy_(x)
+            cat[1][..., :hc].copy_(x)
         rets = []
         zbuf = None
         for ti, (c1, c2, names, couts) in enumerate(self.tasks):

@@ -258,6 +258,7 @@ class StaticStep(object):
         self.padded = "packed" if packed else True  # packed: outputs = (packed [B,S,post,11], counts [B,S]) instead of four tensors
         self.row_caps_mode, self.headroom = row_caps, float(headroom)
         self.caps = None  # per-level row capacities of the captured step (None: data-free bounds)
+        self.bev = None   # static [B, 6, H, W] input of a bev_map head (n3dtfm), allocated by the first call that passes one
         self.B, self.capacity, self.ndim = int(batch_size), int(capacity), int(ndim)
         dev = next(model.parameters()).device
         self.points = torch.zeros((self.B, self.capacity, self.ndim), dtype=torch.float32, device=dev)
@@ -287,18 +288,27 @@ class StaticStep(object):
         except Exception:
             pass
 
+    def _set_bev(self, bev_map):
+        if bev_map is None:
+            return
+        if self.bev is None:
+            self.bev = torch.zeros_like(bev_map)
+            self.graph = None
+        self.bev.copy_(bev_map, non_blocking=True)
+
     def _run(self, static):
         m = self.model
         if static:  # the captured sweep keeps scratch buffers of its own (not those of whatever stream it is captured on)
             with hip_ops.workspace.scope(id(self)):
-                return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, padded=self.padded,
+                return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, padded=self.padded, bev_map=self.bev,
                                         counts=[self.counts[b:b + 1] for b in range(self.B)], static=True, expected=self.expected, row_caps=self.caps)
-        return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, padded=self.padded,
+        return m.forward_points([self.points[b] for b in range(self.B)], self.voxel_cfg, padded=self.padded, bev_map=self.bev,
                                 counts=[self.counts[b:b + 1] for b in range(self.B)], static=static, expected=self.expected)
 
-    def warm_up(self, clouds, n=2):
+    def warm_up(self, clouds, n=2, bev_map=None):
         """Eager sweeps on representative clouds: lets the dense-conv plan time its variants and records the level counts that
         steer the sparse-conv launch shapes of the captured step."""
+        self._set_bev(bev_map)
         self._load(clouds)
         for _ in range(n):
             self._run(False)
@@ -339,7 +349,8 @@ class StaticStep(object):
         self.graph = g
         self.version = self._version_key()
 
-    def __call__(self, clouds):
+    def __call__(self, clouds, bev_map=None):
+        self._set_bev(bev_map)
         if self.graph is None or self.version != self._version_key():
             if self.expected is None:
                 self.warm_up(clouds)
@@ -361,7 +372,7 @@ class StaticStep(object):
         """replay + overflow check (one synchronisation) + eager re-run of an overflowing sweep: always-correct results"""
         out = self(clouds)
         if self.overflowed():
-            return self.model.forward_points(clouds, self.voxel_cfg, padded=self.padded)
+            return self.model.forward_points(clouds, self.voxel_cfg, padded=self.padded, bev_map=self.bev)
         return out
 
 

@@ -205,7 +205,7 @@ class CenterHead(nn.Module):
     def forward(self, x, bev_map=None, *kwargs):
         if self.training:
             return self.forward_modules(x, bev_map)
-        if x.is_cuda and self.use_hip_conv and not self.bev_map and self.compute_dtype in (torch.bfloat16, torch.float32):
+        if x.is_cuda and self.use_hip_conv and self.compute_dtype in (torch.bfloat16, torch.float32):
             ver = (weights_version(self), self.compute_dtype)
             if self._plan is None or self._plan[0] != ver:
                 from .dense_bf16 import HeadPlan
@@ -215,7 +215,7 @@ class CenterHead(nn.Module):
                 except ValueError:
                     self._plan = (ver, None)
             if self._plan[1] is not None:
-                return self._plan[1](x.to(self.compute_dtype).permute(0, 2, 3, 1).contiguous())
+                return self._plan[1](x.to(self.compute_dtype).permute(0, 2, 3, 1).contiguous(), bev_map)
         dt, cl = self.compute_dtype, self.channels_last
         key = (dt, cl, next(self.parameters()).device, weights_version(self.shared_conv) + (weights_version(self.bev_conv) if self.bev_map else 0))
         if self._folded is None or self._folded[0] != key:
