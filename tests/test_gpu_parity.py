@@ -2066,3 +2066,46 @@ def test_static_step_with_bev_map_head(hip):
         torch.cuda.synchronize()
         assert not torch.equal(other[1], outs[2]), "the bev_map input must reach the head"
     report("static step with a bev_map head (n3dtfm): 3 clouds x 3 maps bit-identical to eager", 0.0, 0.0)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_street_scene_with_few_detections(hip, precision):
+    """a scene of typical nuScenes sparsity next to the saturated one -- synthetic_cloud(profile="street"): 300k points
+    in ~65k voxels (motion-compensated static scene), heat-map head tamed (synth.tame_scores) so that a few hundred cells pass the
+    score threshold and a few dozen boxes survive: neither the 160k-voxel cap, nor the top-1000 cut, nor the 83-per-step cut is
+    active.  fp32: maps 1e-3 and detections attributed against the oracle; bf16: against the bf16 oracle (distribution +
+    attribution).  The cloud also goes through a whole-sweep graph that was warmed up on a DENSE cloud (launch grids sized by
+    typical counts of another density) and must equal the eager sweep bit for bit."""
+    from futuredet_amd.detectors import StaticStep
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims, tame_scores
+
+    cfg, net, onet = _build_pair("forecast_n3")
+    sd = tame_scores(tame_box_dims(seeded_state_dict(net, 7)))
+    net.load_state_dict(sd, strict=False)
+    onet.load_state_dict(sd, strict=False)
+    cloud = synthetic_cloud(seed=0, target_points=300000, profile="street")
+    if precision == "bf16":
+        net.set_precision(torch.bfloat16)
+    with torch.no_grad():
+        got = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
+    n_det = len(got["scores"])
+    assert 8 <= n_det < 300, n_det
+    if precision == "fp32":
+        v, c, n, obb, obev, want = _oracle_run(cfg, onet, cloud)
+        assert 40000 < len(n) < 90000 and want["topk_cut"] is None
+        bb, x = _hip_maps(net, cfg, v, c, n)
+        assert_close("street scene (n3 fp32, %d voxels) backbone BEV" % len(n), bb.float().cpu().numpy(), obb.numpy(), 1e-3)
+        assert_close("street scene (n3 fp32) neck output", x.float().cpu().numpy(), obev.numpy(), 1e-3)
+        _attribute("street scene (n3 fp32, %d detections)" % n_det, _rows(got), _rows(want), cfg.test_cfg)
+    else:
+        _check_bf16("street scene (n3 bf16, %d detections)" % n_det, cfg, net, onet, cloud, got, min_rows=8)
+    dense = _dev(synthetic_cloud(seed=1, target_points=300000))
+    step = StaticStep(net, cfg.voxel_generator, capacity=330000, row_caps="auto")
+    with torch.no_grad():
+        step.warm_up([dense])
+        want_p = net.forward_points([_dev(cloud)], cfg.voxel_generator)
+        got_p = step([_dev(cloud)])
+        torch.cuda.synchronize()
+    assert not step.overflowed()
+    k = int(want_p[3].max())
+    assert torch.equal(want_p[3], got_p[3]) and torch.equal(want_p[0][:, :, :k], got_p[0][:, :, :k]) and torch.equal(want_p[1][:, :, :k], got_p[1][:, :, :k])
