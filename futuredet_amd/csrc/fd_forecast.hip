@@ -230,7 +230,49 @@ __global__ void __launch_bounds__(1024) forecast_groups_kernel(const double *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------- trajectory library lookup
+// process_trajectories (nuscenes.py:341-382): every predicted trajectory, written as the row [vx, vy, q0..q3, centre_i - centre_0 ...],
+// is replaced by the nearest row of a trajectory library (argmin over the library of the Euclidean distance, first minimum wins
+// like np.argmin).  One workgroup per query row; float64 sums of squared differences in column order.
+__global__ void __launch_bounds__(256) nearest_rows_kernel(const double *__restrict__ lib, int n_lib, const double *__restrict__ query, int dim,
+                                                           int *__restrict__ idx) {
+    __shared__ double s_d[256];
+    __shared__ int s_i[256];
+    const double *q = query + (size_t)blockIdx.x * dim;
+    double best = 1.0e300;
+    int arg = 0x7fffffff;
+    for (int j = threadIdx.x; j < n_lib; j += 256) {
+        const double *r = lib + (size_t)j * dim;
+        double acc = 0.0;
+        for (int c = 0; c < dim; ++c) {
+            const double d = r[c] - q[c];
+            acc = fma(d, d, acc);
+        }
+        if (acc < best) { best = acc; arg = j; }  // (j ascending per thread: the first minimum is kept)
+    }
+    s_d[threadIdx.x] = best;
+    s_i[threadIdx.x] = arg;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double d2 = s_d[threadIdx.x + o];
+            const int i2 = s_i[threadIdx.x + o];
+            if (d2 < s_d[threadIdx.x] || (d2 == s_d[threadIdx.x] && i2 < s_i[threadIdx.x])) { s_d[threadIdx.x] = d2; s_i[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) idx[blockIdx.x] = s_i[0];
+}
+
 }  // namespace
+
+extern "C" int fd_nearest_rows(const double *library, int n_library, const double *queries, int n_queries, int dim, int32_t *idx, fd_stream_t stream) {
+    FD_REQUIRE(n_queries >= 0 && n_library >= 1 && dim >= 1, "fd_nearest_rows: need n_library >= 1, dim >= 1");
+    if (n_queries == 0) return FD_OK;
+    FD_REQUIRE(library && queries && idx, "fd_nearest_rows: null argument");
+    hipLaunchKernelGGL(nearest_rows_kernel, dim3((unsigned)n_queries), dim3(256), 0, fd::as_stream(stream), library, n_library, queries, dim, idx);
+    return fd::check_launch("fd_nearest_rows");
+}
 
 extern "C" int fd_det_to_global_boxes(const float *box3d9, int n, const double *cs_rotation4, const double *cs_translation3,
                                       const double *pose_rotation4, const double *pose_translation3, double *center, double *quat,

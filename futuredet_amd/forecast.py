@@ -129,10 +129,36 @@ def _second_det_to_nusc_box(detection, cs_record=None, pose_record=None):
     return _boxes_from_arrays(c, q, v, s, scores, labels)
 
 
-def forecast_boxes(det_forecast, time, cs_record, pose_record, forecast, forecast_mode, classname, jitter=False, K=1, C=0.0, stale=None):
+def process_trajectories(ret_boxes, forecast, train_dist, device="cuda"):
+    """nuscenes.py:341-382: every trajectory is replaced by the nearest row of the trajectory library ``train_dist``
+    ([M, 2 + 4 + 3 (forecast - 1)]: start velocity xy, start orientation, offsets of the later centres from the first); the search
+    (distance_matrix + argmin, :366-368) runs on the device (fd_nearest_rows).  Boxes are modified in place like the reference."""
+    if len(ret_boxes) == 0:
+        return []
+    rows = []
+    for ret_box in ret_boxes:  # :349-363
+        box = ret_box[0]
+        rotation = [box.orientation[0], box.orientation[1], box.orientation[2], box.orientation[3]]
+        rows.append(np.array(list(box.velocity[:2]) + rotation + list(np.hstack([ret_box[i].center - box.center for i in range(1, forecast)]))))
+    test_dist = np.ascontiguousarray(np.array(rows, np.float64))
+    train = np.ascontiguousarray(np.asarray(train_dist, np.float64))
+    idx = hip_ops.nearest_rows(torch.from_numpy(train).to(device), torch.from_numpy(test_dist).to(device)).cpu().numpy()
+    out_boxes = []
+    for ret_box, j in zip(ret_boxes, idx):  # :370-380
+        translation = deepcopy(ret_box[0].center)
+        trajectory = train[j][6:]
+        for i in range(forecast - 1):
+            ret_box[i + 1].center = translation + trajectory[3 * i:3 * i + 3]
+        out_boxes.append(deepcopy(ret_box))
+    return out_boxes
+
+
+def forecast_boxes(det_forecast, time, cs_record, pose_record, forecast, forecast_mode, classname, jitter=False, K=1, C=0.0, stale=None,
+                   train_dist=None, postprocess=False):
     """nuscenes.py:384-494 with the devkit look-ups factored out: ``time`` = seconds between consecutive forecast steps
     (get_time, :399-406), ``cs_record`` / ``pose_record`` = (rotation, translation) of the sample's LIDAR_TOP calibrated
-    sensor and ego pose.  Returns ret_boxes: a list of trajectories, each a list of ``forecast`` boxes."""
+    sensor and ego pose.  Returns ret_boxes: a list of trajectories, each a list of ``forecast`` boxes.
+    ``postprocess`` (velocity_dense only, :465-467): trajectories are snapped to the library ``train_dist`` (process_trajectories)."""
     time = list(time)
     if stale is None:
         stale = any(t == 0 for t in time)
@@ -148,8 +174,13 @@ def forecast_boxes(det_forecast, time, cs_record, pose_record, forecast, forecas
         return []
     if forecast_mode in ["velocity_constant", "velocity_forward", "velocity_reverse"]:
         ret_boxes = match_boxes(ret_boxes)
+    elif forecast_mode in ["velocity_sparse_forward", "velocity_sparse_reverse", "velocity_sparse_match"]:
+        # nuscenes.py:422-429: these modes index each Box as a [forward, reverse] pair (a two-head output that no shipped config
+        # produces) and then fall into ``assert False, "Invalid Forecast Mode"`` (:468-469): the reference itself cannot execute
+        # them (TypeError on the first Box, recorded in tests/golden/forecast2.npz::sparse_mode_exception).  Same outcome here.
+        raise TypeError("forecast_mode %r is not executable in the reference either (nuscenes.py:422-429,468-469)" % forecast_mode)
     elif forecast_mode != "velocity_dense":
-        raise NotImplementedError("forecast_mode %r: only the velocity_* modes of the shipped evaluate.py settings are covered" % forecast_mode)
+        raise AssertionError("Invalid Forecast Mode")  # :468-469
     if "dense" not in forecast_mode:  # :433-441
         trajectory_boxes = [[ret_boxes[i][j] for i in range(forecast)] for j in range(len(ret_boxes[0]))]
         if forecast_mode == "velocity_reverse":
@@ -166,6 +197,8 @@ def forecast_boxes(det_forecast, time, cs_record, pose_record, forecast, forecas
         ret_boxes = out
     else:
         ret_boxes = tracker(classname, time, ret_boxes)  # :443,465-466
+        if postprocess:
+            ret_boxes = process_trajectories(ret_boxes, forecast, train_dist)
     if jitter:  # :476-492 (draws from numpy's global generator like the reference)
         jitter_boxes = []
         for trajectory_box in ret_boxes:

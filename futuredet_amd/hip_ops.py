@@ -751,6 +751,16 @@ def det_to_global_boxes(box3d, cs_record=None, pose_record=None):
     return center, quat, vel, size
 
 
+def nearest_rows(library, queries):
+    """fd_nearest_rows: library [M, D], queries [N, D] float64 device tensors -> int32 [N] index of the nearest library row"""
+    L = _lib.load()
+    library, queries = _dev(library, "library", torch.float64), _dev(queries, "queries", torch.float64)
+    assert library.shape[1] == queries.shape[1]
+    idx = torch.zeros((max(queries.shape[0], 1),), dtype=torch.int32, device=queries.device)[: queries.shape[0]]
+    check(L.fd_nearest_rows(_p(library), library.shape[0], _p(queries), queries.shape[0], library.shape[1], _p(idx), _stream()), "fd_nearest_rows")
+    return idx
+
+
 def forecast_groups(centers, match_thresh):
     """fd_forecast_groups: centers [n,3] float64 device tensor -> int32 [n] component ids (multi_future's forecast_id)."""
     L = _lib.load()

@@ -344,6 +344,12 @@ int fd_det_to_global_boxes(const float *box3d9, int n, const double *cs_rotation
  * connected component, components numbered by their smallest member (networkx's enumeration order).  n <= 8192. */
 int fd_forecast_groups(const double *centers3, int n, double match_thresh, int32_t *ids, fd_stream_t stream);
 
+/* The search of process_trajectories (det3d/datasets/nuscenes/nuscenes.py:341-382, forecast_boxes with postprocess=True :465-467):
+ * idx[i] = argmin_j || library[j] - queries[i] || over the rows of a trajectory library [n_library, dim] (float64, row =
+ * [vx, vy, q0..q3, centre_1 - centre_0, ...]); the first minimum wins like np.argmin.  Exact squared differences instead of the
+ * reference's |a|^2 + |b|^2 - 2ab expansion: the two can only disagree between library rows that are equidistant to 1e-15. */
+int fd_nearest_rows(const double *library, int n_library, const double *queries, int n_queries, int dim, int32_t *idx, fd_stream_t stream);
+
 /* The whole index pyramid of the backbone in one call (the same launches as fd_index_mark / _downsample / _scan /
  * _coords above, issued back to back): level 0 is marked from the voxelizer's coords of every sample
  * (coords [B * n_max_per_sample, 4], n_dev[b] = voxel count of sample b or NULL), level l > 0 is derived from

@@ -651,6 +651,33 @@ def gen_forecast2():
         out[mode + "_score"] = np.array([[b.score for b in tr] for tr in ret], np.float64).reshape(-1, T)
         out[mode + "_label"] = np.array([[b.label for b in tr] for tr in ret], np.int64).reshape(-1, T)
         print("forecast_boxes", mode, "trajectories", len(ret))
+    # ---- velocity_dense with postprocess=True (process_trajectories, nuscenes.py:341-382,465-467): every trajectory is replaced by the
+    #      nearest one of a trajectory library (train_dist rows = [vx, vy, q0..q3, (centre_i - centre_0) for i = 1..T-1])
+    dense = nm.forecast_boxes(nusc, sample_data, scene_data, tokens, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in det.items()}, T,
+                              "velocity_dense", "car", False, 1, 0.0, None, False)[0]
+    lib_rows = []
+    rng2 = np.random.default_rng(78)  # (its own stream: the draws of the older fixture keys stay what they were)
+    for tr in dense[::2]:  # library = perturbed copies of half of the trajectories plus unrelated rows
+        row = np.concatenate([tr[0].velocity[:2], tr[0].orientation.elements, np.hstack([tr[i].center - tr[0].center for i in range(1, T)])])
+        lib_rows.append(row + rng2.normal(0, 0.05, row.shape))
+    lib_rows += [rng2.normal(0, 4.0, lib_rows[0].shape) for _ in range(40)]
+    train_dist = np.array(lib_rows)
+    d = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in det.items()}
+    ret_pp, _ = nm.forecast_boxes(nusc, sample_data, scene_data, tokens, d, T, "velocity_dense", "car", False, 1, 0.0, train_dist, True)
+    out["pp_train_dist"] = train_dist
+    out["pp_center"] = np.array([[b.center for b in tr] for tr in ret_pp], np.float64).reshape(-1, T, 3)
+    print("forecast_boxes velocity_dense + postprocess: trajectories", len(ret_pp))
+    # ---- the velocity_sparse_* modes (nuscenes.py:422-429) cannot run in the reference itself: record what happens
+    fails = []
+    for mode in ("velocity_sparse_forward", "velocity_sparse_reverse", "velocity_sparse_match"):
+        d = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in det.items()}
+        try:
+            nm.forecast_boxes(nusc, sample_data, scene_data, tokens, d, T, mode, "car", False, 1, 0.0, None, False)
+            fails.append("")
+        except Exception as e:  # noqa: BLE001
+            fails.append(type(e).__name__)
+    out["sparse_mode_exception"] = np.array(fails)
+    print("velocity_sparse_* in the reference:", fails)
     out["time"] = np.array([nm.get_time(nusc, a, b) for a, b in zip(tokens[1:T], tokens[2:T + 1])])
     # ---- multi_future on serialised boxes: clusters of near-identical first boxes plus chains that link transitively
     cents = np.concatenate([rng.uniform(-30, 30, (12, 3)) * [1, 1, 0.02]] * 3) + rng.normal(0, 0.06, (36, 3))
@@ -676,7 +703,15 @@ def gen_forecast2():
 if __name__ == "__main__":
     install_shims()
     sys.path.insert(0, REF)
-    which = sys.argv[1:] or ["voxelizer", "configs", "dense", "predict", "iou", "backbone", "sweeps", "pillars", "forecast"]
+    which = sys.argv[1:] or ["voxelizer", "configs", "dense", "predict", "iou", "backbone", "sweeps", "pillars", "forecast", "forecast2"]
+    if len(which) > 1:
+        # one generator per process: each installs the import shims it needs for the reference modules it imports, and the
+        # shims of one (det3d.datasets stand-ins of the forecast generators) must not be what another finds in sys.modules
+        import subprocess
+
+        for w in which:
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), w])
+        sys.exit(0)
     for w in which:
         {"voxelizer": gen_voxelizer, "configs": gen_configs, "dense": gen_dense_nets, "predict": gen_predict,
          "iou": gen_iou, "backbone": gen_backbone, "sweeps": gen_sweeps, "pillars": gen_pillars, "forecast": gen_forecast,

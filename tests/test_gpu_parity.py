@@ -987,6 +987,36 @@ def test_forecast_boxes_match_reference_golden(hip, golden, mode):
     assert forecast.forecast_boxes(det, [0.5, 0.0, 0.5, 0.5, 0.5, 0.5], cs, pose, 7, mode, "car") == []  # a stale step (:402-403,419-420)
 
 
+def test_forecast_postprocess_and_sparse_modes_match_reference_golden(hip, golden):
+    """The rest of forecast_boxes (VERDICT r2 missing #3): velocity_dense with postprocess=True -- process_trajectories
+    (nuscenes.py:341-382), the nearest-library-trajectory search on the device (fd_nearest_rows) -- gives the reference's centres
+    (1e-9), and the three velocity_sparse_* modes end the way they end in the reference (the fixture records the reference's own
+    exception: they are dead code there, nuscenes.py:422-429,468-469)."""
+    from futuredet_amd import forecast
+
+    g = golden("forecast2.npz")
+    det = {"box3d_lidar": torch.from_numpy(g["box3d"]).cuda(), "scores": torch.from_numpy(g["scores"]).cuda(),
+           "label_preds": torch.from_numpy(g["labels"]).cuda()}
+    cs, pose = (g["cs_rotation"], g["cs_translation"]), (g["pose_rotation"], g["pose_translation"])
+    ret = forecast.forecast_boxes(det, list(g["time"]), cs, pose, 7, "velocity_dense", "car", train_dist=g["pp_train_dist"], postprocess=True)
+    assert len(ret) == len(g["pp_center"])
+    assert_close("forecast_boxes velocity_dense + postprocess centres", np.array([[b.center for b in tr] for tr in ret], np.float64), g["pp_center"], 1e-9)
+    # the search itself against numpy on a larger library, duplicates included (first minimum wins)
+    rng = np.random.default_rng(5)
+    lib = rng.normal(0, 3, (5000, 24))
+    lib[1234] = lib[77]
+    q = np.concatenate([lib[[77, 4999, 0]] + 1e-3, rng.normal(0, 3, (200, 24))])
+    got = hip.nearest_rows(torch.from_numpy(lib).cuda(), torch.from_numpy(q).cuda()).cpu().numpy()
+    want = np.argmin(((lib[None] - q[:, None]) ** 2).sum(-1), axis=1)
+    assert np.array_equal(got, want) and got[0] == 77
+    assert list(g["sparse_mode_exception"]) == ["TypeError"] * 3
+    for mode in ("velocity_sparse_forward", "velocity_sparse_reverse", "velocity_sparse_match"):
+        with pytest.raises(TypeError):
+            forecast.forecast_boxes(det, list(g["time"]), cs, pose, 7, mode, "car")
+    with pytest.raises(AssertionError):
+        forecast.forecast_boxes(det, list(g["time"]), cs, pose, 7, "no_such_mode", "car")
+
+
 def test_multi_future_matches_reference_golden(hip, golden):
     """forecast ids (connected components of the < 0.25 m graph, numbered like networkx enumerates them) and the copied
     scores vs the reference's multi_future; a 0.2 m chain must end up in one component, other classes are dropped."""
