@@ -196,45 +196,95 @@ __global__ void __launch_bounds__(NW * 64) spconv_bf16_ws(const unsigned short *
         };
         u32x4 a_r[DEPTH][RG][NCU];
         int e_next[RG];
+        if constexpr (!RING) {
+            // ---- RESIDENT: steps without a single pair in this wave's rows are skipped (no gather instruction, no MFMA): an
+            // out-of-range lane costs the gather path as much as a loaded one (tools/probes/gather_probe.hip), and 65 % of the
+            // (16 rows, tap) items of the first stage are empty, most of them in the down-sampling convolutions.  The step
+            // mask is the OR over the lanes' entries of the slice; the walk over its set bits is scalar work.
+            unsigned mine = 0u;
 #pragma unroll
-        for (int d = 0; d < DEPTH - 1; ++d) {
-            fetch_idx(d, e_next);
-            issue(a_r[d], e_next);
-        }
-        fetch_idx(DEPTH - 1, e_next);
-        u32x4 wr[NWR];
-        if constexpr (RING) {
+            for (int i = 0; i < NPRE; ++i) {
+                const int t = lane + i * 64;
+                if (i * 64 < K * ROWS && t < K * ROWS) {
+                    const int tap = t / ROWS, r = t - tap * ROWS;
+                    if (sl[t] >= 0 && row0 + r < row_end) mine |= 1u << (PAIR ? tap >> 1 : tap);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mine |= (unsigned)__shfl_xor((int)mine, o);
+            unsigned rem = (unsigned)__builtin_amdgcn_readfirstlane((int)mine);
+            const int n_steps = __builtin_popcount(rem);
+            auto next_step = [&]() -> int {
+                const int t = rem ? __builtin_ctz(rem) : T;  // T = 'no step': its entries are the 'no neighbour' row
+                rem &= rem - 1u;
+                return t;
+            };
+            int t_r[DEPTH];
+#pragma unroll
+            for (int d = 0; d < DEPTH - 1; ++d) {
+                t_r[d] = next_step();
+                fetch_idx(t_r[d], e_next);
+                issue(a_r[d], e_next);
+            }
+            int t_n = next_step();
+            fetch_idx(t_n, e_next);
+            for (int i0 = 0; i0 < n_steps; i0 += DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    const int t = t_r[d];
+                    issue(a_r[(d + DEPTH - 1) % DEPTH], e_next);
+                    t_r[(d + DEPTH - 1) % DEPTH] = t_n;
+                    t_n = next_step();
+                    fetch_idx(t_n, e_next);
+                    const int tw = t < T ? t : T - 1;
+                    const u32x4 *wsrc = s_w + (tw * FR) * 64 + lane;
+#pragma unroll
+                    for (int c = 0; c < NCU; ++c) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const bf16x8 wf = __builtin_bit_cast(bf16x8, wsrc[(c * NB + nb) * 64]);
+#pragma unroll
+                            for (int g = 0; g < RG; ++g)
+                                acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, a_r[d][g][c]), acc[g][nb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < DEPTH - 1; ++d) {
+                fetch_idx(d, e_next);
+                issue(a_r[d], e_next);
+            }
+            fetch_idx(DEPTH - 1, e_next);
+            u32x4 wr[NWR];
             wload(0, wr);
             wstore(0, wr);
             wload(1, wr);
             __syncthreads();
-        }
-
-        for (int t0 = 0; t0 < T; t0 += DEPTH) {
+            for (int t0 = 0; t0 < T; t0 += DEPTH) {
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                const int t = t0 + d;
-                if constexpr (RING) {
+                for (int d = 0; d < DEPTH; ++d) {
+                    const int t = t0 + d;
                     wstore((d + 1) & 1, wr);  // W[t + 1], requested one step ago, for the step after the coming barrier
                     wload(t + 2, wr);
-                }
-                // the slot freed by step t - 1 takes the gather of step t + DEPTH - 1; the entries of step t + DEPTH are read
-                // now and used one iteration later (no LDS round trip in front of a gather)
-                issue(a_r[(d + DEPTH - 1) % DEPTH], e_next);
-                fetch_idx(t + DEPTH, e_next);
-                const int tw = t < T ? t : T - 1;
-                const u32x4 *wsrc = RING ? s_w + ((d & 1) * FR) * 64 + lane : s_w + (tw * FR) * 64 + lane;
+                    // the slot freed by step t - 1 takes the gather of step t + DEPTH - 1; the entries of step t + DEPTH are read
+                    // now and used one iteration later (no LDS round trip in front of a gather)
+                    issue(a_r[(d + DEPTH - 1) % DEPTH], e_next);
+                    fetch_idx(t + DEPTH, e_next);
+                    const u32x4 *wsrc = s_w + ((d & 1) * FR) * 64 + lane;
 #pragma unroll
-                for (int c = 0; c < NCU; ++c) {
+                    for (int c = 0; c < NCU; ++c) {
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const bf16x8 wf = __builtin_bit_cast(bf16x8, wsrc[(c * NB + nb) * 64]);
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const bf16x8 wf = __builtin_bit_cast(bf16x8, wsrc[(c * NB + nb) * 64]);
 #pragma unroll
-                        for (int g = 0; g < RG; ++g)
-                            acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, a_r[d][g][c]), acc[g][nb], 0, 0, 0);
+                            for (int g = 0; g < RG; ++g)
+                                acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, a_r[d][g][c]), acc[g][nb], 0, 0, 0);
+                        }
                     }
+                    __syncthreads();
                 }
-                if constexpr (RING) __syncthreads();
             }
         }
 
@@ -343,11 +393,13 @@ bool launch_resident(const WsArgs &a, int rg, int depth) {
     if constexpr (COUT <= 32) {
         if (rg >= 4) return WsKernel<CIN, COUT, 4, 2, 16, false>::launch(a);
     }
-    if (rg >= 2) {
-        if constexpr (COUT <= 32) {
-            if (depth >= 4) return WsKernel<CIN, COUT, 2, 4, 16, false>::launch(a);
+    if constexpr (COUT <= 32) {  // (two row groups x 64 columns do not fit the 128 registers of a 1024-thread workgroup)
+        if (rg >= 2) {
+            if constexpr (CIN == 16) {
+                if (depth >= 4) return WsKernel<CIN, COUT, 2, 4, 16, false>::launch(a);
+            }
+            return WsKernel<CIN, COUT, 2, 2, 16, false>::launch(a);
         }
-        return WsKernel<CIN, COUT, 2, 2, 16, false>::launch(a);
     }
     return depth >= 4 ? WsKernel<CIN, COUT, 1, 4, 16, false>::launch(a) : WsKernel<CIN, COUT, 1, 2, 16, false>::launch(a);
 }

@@ -8,6 +8,7 @@
 //   4 mfma_half  as 2, odd rows out of range (bounds-checked zeros)
 //   5 quad_half  as 1, odd rows out of range
 //   6 mfma256    lane p+16q -> row(p) * 256 + 16 q (256-byte rows, first 64 B piece), random rows
+//   8 all_oob    every lane out of range;  9 one_lane: lane 0 loads, the other 63 are out of range
 //   7 blocked    lane p+16q -> (r0 + p) * 16 + q * 256 within a 1 KB block: chunk-major blocked layout, consecutive rows
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/gather_probe tools/probes/gather_probe.hip
 #include <hip/hip_runtime.h>
@@ -62,11 +63,11 @@ int main(int argc, char **argv) {
     hipMalloc(&cyc, n_waves * 8);
     std::vector<unsigned> h(n_off);
     std::vector<long long> hc(n_waves);
-    const char *names[] = {"linear", "quadrow", "mfma", "mfma_seq", "mfma_half", "quad_half", "mfma256", "blocked"};
+    const char *names[] = {"linear", "quadrow", "mfma", "mfma_seq", "mfma_half", "quad_half", "mfma256", "blocked", "all_oob", "one_lane"};
     const size_t windows[] = {16u << 10, 2u << 20, 24u << 20, 400u << 20};
     printf("%d CUs, %d waves per CU, %d loads of 1 KB per wave\n", n_cu, waves_per_cu, reps * UNROLL);
     for (size_t win : windows) {
-        for (int pat = 0; pat < 8; ++pat) {
+        for (int pat = 0; pat < 10; ++pat) {
             // each CU's waves work in their own window slice when the window is small (L1 case), else share the whole window
             srand(1234 + pat);
             for (int w = 0; w < n_waves; ++w) {
@@ -86,6 +87,8 @@ int main(int argc, char **argv) {
                             case 4: off = (l & 1) ? 0xffffff00u : (unsigned)base + rows[l & 15] * 64 + 16 * (l >> 4); break;
                             case 5: off = ((l >> 2) & 1) ? 0xffffff00u : (unsigned)base + rows[l >> 2] * 64 + 16 * (l & 3); break;
                             case 6: off = (unsigned)base + rows[l & 15] * 256 + 16 * (l >> 4); break;
+                            case 8: off = 0xffffff00u; break;                                                         // every lane out of range
+                            case 9: off = l == 0 ? (unsigned)base + rows[0] * 64 : 0xffffff00u; break;               // one lane loads, 63 out of range
                             default: off = (unsigned)base + (r0 >> 4) * 1024 + ((r0 & 15) + (l & 15)) * 16 + (l >> 4) * 256; break;  // may run into the next block: still contiguous per chunk
                         }
                         h[((size_t)w * reps * UNROLL + i) * 64 + l] = off;
@@ -109,7 +112,7 @@ int main(int argc, char **argv) {
             for (int w = 0; w < n_waves; ++w) mean += (double)hc[w];
             mean /= n_waves;
             const double kb = (double)reps * UNROLL;  // KB per wave
-            const double frac = (pat == 4 || pat == 5) ? 0.5 : 1.0;
+            const double frac = (pat == 4 || pat == 5) ? 0.5 : (pat == 8 ? 0.0 : (pat == 9 ? 1.0 / 64 : 1.0));
             printf("window %7.1f MB  %-10s  %7.1f cycles per 1-KB load per wave  -> %6.1f B/clk/CU (requested %s)  kernel %.1f us  %.2f TB/s\n", win / 1048576.0, names[pat],
                    mean / kb, 1024.0 * frac * waves_per_cu / (mean / kb), frac < 1 ? "half" : "all", ms * 1e3,
                    (double)n_waves * kb * 1024 * frac / (ms * 1e-3) / 1e12);
