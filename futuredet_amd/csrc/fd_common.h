@@ -18,6 +18,10 @@ int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bi
 int spconv_bf16_ws_dispatch(const void *in, const void *wp, const float *bias, const void *residual, int relu, const int *nbr, int64_t nbr_stride, int K,
                             int64_t n_in_bound, int n_out, const int *n_out_dev, int64_t n_expected, int cin, int cout, void *out, hipStream_t stream);
 
+// fd_conv2d_wino_pc.hip: 0 = launched, 1 = shape not supported by the variant, -1 = dynamic LDS refused
+int wino_pc_launch(const float *x, const void *wp, const float *bias, float *y, int B, int H, int W, int cin, int cout, int relu, int cout_total,
+                   int co_off, hipStream_t stream);
+
 int spconv_f32_c32_dispatch(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
                             int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, const int *n_out_dev, int cin, int cout, float *out,
                             const int *ranges, int n_ranges, hipStream_t stream);

@@ -276,7 +276,7 @@ bool launch_wino(const float *x, const void *wp, const float *bias, float *y, Wi
     return true;
 }
 
-constexpr int kNumWinoTiles = 6;
+constexpr int kNumWinoTiles = 7;
 
 }  // namespace
 
@@ -342,6 +342,15 @@ extern "C" int fd_conv2d_wino_nhwc_f32(const float *x, int B, int H, int W, int 
         case 3: ok = launch_wino<4, 8, 1>(x, wpacked, bias, y, p, s); break;   // 8 x 16 pixels x 64 channels, 128
         case 4: ok = launch_wino<8, 8, 1>(x, wpacked, bias, y, p, s); break;   // 16 x 16 pixels x 64 channels, 256
         case 5: ok = launch_wino<4, 4, 2>(x, wpacked, bias, y, p, s); break;   // 8 x 8 pixels x 128 channels, 128 (two workgroups per CU)
+        case 7: {  // strips of 32 tiles x 64 channels, producer + consumer waves (fd_conv2d_wino_pc.hip); needs W >= 63
+            const int rc = fd::wino_pc_launch(x, wpacked, bias, y, B, H, W, cin, cout, relu, cout_total, co_off, s);
+            if (rc == 1) {
+                fd::set_error("fd_conv2d_wino_nhwc_f32: tile 7 needs W >= 63 and an input below 2 GB (got W = %d)", W);
+                return FD_EINVAL;
+            }
+            ok = rc == 0;
+            break;
+        }
         default: ok = launch_wino<4, 4, 1>(x, wpacked, bias, y, p, s); break;  // 8 x 8 pixels x 64 channels, 64 (three per CU)
     }
     if (!ok) {

@@ -189,7 +189,9 @@ int fd_conv2d_grouped_nhwc_f32(const float *x, int B, int H, int W, int groups, 
                                const int *counts_host, int relu, float *y, int cout_total, int co_off, int tile, fd_stream_t stream);
 /* 3x3 stride-1 pad-1 only: Winograd F(2x2,3x3) with the 16 element-wise products as MFMA GEMMs over the input channels
  * (2.25x fewer multiplies than the direct form).  Weights are transformed (U = G g G^T) and packed by
- * fd_conv2d_wino_f32_pack_weight; cin must be a multiple of 16; output placement: channel offset only. */
+ * fd_conv2d_wino_f32_pack_weight; cin must be a multiple of 16; output placement: channel offset only.  Every tile gives the
+ * same bits; the last one (strips of 32 Winograd tiles, producer + consumer waves) needs W >= 63 and tensors below 2 GB and
+ * fails with FD_EINVAL otherwise. */
 int fd_conv2d_wino_f32_num_tiles(void);
 size_t fd_conv2d_wino_f32_packed_weight_bytes(int cout, int cin);
 int fd_conv2d_wino_f32_pack_weight(const float *w_oihw_host, int cout, int cin, void *wpacked_host);

@@ -547,10 +547,13 @@ def test_conv2d_nhwc_f32_vs_torch(hip, cfg):
 
 
 @pytest.mark.parametrize("cfg", [(64, 128, 37, 45, 1), (128, 128, 20, 20, 2), (96, 11, 19, 35, 3), (256, 256, 16, 16, 4), (48, 70, 29, 31, 0),
-                                 (16, 384, 8, 50, 1), (32, 64, 33, 6, 4), (128, 128, 21, 20, 5), (64, 70, 18, 23, 6)], ids=lambda c: "%d-%d_%dx%d_t%d" % c)
+                                 (16, 384, 8, 50, 1), (32, 64, 33, 6, 4), (128, 128, 21, 20, 5), (64, 70, 18, 23, 6),
+                                 (64, 128, 37, 77, 7), (96, 11, 19, 67, 7), (256, 256, 9, 63, 7), (48, 70, 29, 90, 7), (16, 384, 8, 65, 7),
+                                 (128, 128, 45, 180, 7)], ids=lambda c: "%d-%d_%dx%d_t%d" % c)
 def test_conv2d_wino_f32_vs_torch(hip, cfg):
     """Winograd F(2x2,3x3) on MFMA vs torch conv2d in float64: odd sizes (partial 2x2 tiles and partial workgroup tiles), Cout
-    not a multiple of 16 / 64, channel-offset writes, every workgroup tile.  The transforms add a few roundings to an fp32
+    not a multiple of 16 / 64, channel-offset writes, every workgroup tile (tile 7 = strips of 32 tiles that wrap to the next
+    tile row, cross into the next image of the batch and end beyond the last tile).  The transforms add a few roundings to an fp32
     chain of <= 256 terms per product: |d| <= 2e-4 * max(1, |ref|)."""
     cin, cout, H, W, tile = cfg
     rng = np.random.default_rng(cin + cout + H + tile)
@@ -1872,7 +1875,7 @@ def test_dense_conv_tiles_bit_identical(hip):
     the direct kernel, and every tile shape of the Winograd kernel, must give the same bits (the per-element summation order
     does not depend on the tile), so a timing-dependent tile choice cannot change results between runs or ranks."""
     rng = np.random.default_rng(3)
-    for (ks, stride, cin, cout, H, W) in ((3, 1, 64, 128, 37, 45), (3, 2, 32, 128, 40, 33), (1, 1, 128, 256, 23, 18), (3, 1, 128, 70, 30, 26)):
+    for (ks, stride, cin, cout, H, W) in ((3, 1, 64, 128, 37, 77), (3, 2, 32, 128, 40, 33), (1, 1, 128, 256, 23, 18), (3, 1, 128, 70, 30, 26), (3, 1, 32, 200, 9, 63)):
         x = torch.from_numpy(rng.standard_normal((2, H, W, cin)).astype(np.float32)).cuda()
         w = torch.from_numpy((rng.standard_normal((cout, cin, ks, ks)) * (2.0 / (cin * ks * ks)) ** 0.5).astype(np.float32))
         b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).cuda()
@@ -1891,7 +1894,11 @@ def test_dense_conv_tiles_bit_identical(hip):
             wpw = hip.pack_conv2d_weight_wino(w).cuda()
             ref = None
             for tile in range(0, hip.conv2d_wino_f32_num_tiles() + 1):
-                y = hip.conv2d_wino_nhwc_f32(x, wpw, b, cout, True, tile=tile)
+                try:
+                    y = hip.conv2d_wino_nhwc_f32(x, wpw, b, cout, True, tile=tile)
+                except hip.FutureDetHipError:
+                    assert tile == 7 and W < 63, (tile, W)  # the strip variant refuses images narrower than one strip of 32 tiles
+                    continue
                 ref = y if ref is None else ref
                 assert torch.equal(ref, y), "winograd %d->%d: tile %d changes the result" % (cin, cout, tile)
     report("dense fp32 convs: all tile shapes of one formulation bit-identical", 0.0, 0.0)

@@ -3,7 +3,7 @@
 # Use with FD_LIB_PATH=tools/probes/libfd_trace.so python tools/spconv_trace.py
 set -e
 cd "$(dirname "$0")/../.."
-srcs="fd_error fd_voxelize fd_index fd_spconv fd_spconv_v2 fd_densify fd_conv2d fd_conv2d_f32 fd_conv2d_wino fd_decode fd_sweeps fd_pillars fd_forecast"
+srcs="fd_error fd_voxelize fd_index fd_spconv fd_spconv_v2 fd_spconv_c32 fd_spconv_bf16 fd_densify fd_conv2d fd_conv2d_f32 fd_conv2d_wino fd_conv2d_wino_pc fd_decode fd_sweeps fd_pillars fd_forecast"
 objs=""
 mkdir -p tools/probes/_obj
 for s in $srcs; do
