@@ -59,6 +59,8 @@ inline hipStream_t as_stream(fd_stream_t s) { return reinterpret_cast<hipStream_
 // call may be captured into a hipGraph: measured on ROCm 7.2 / MI355X, a captured graph whose memset nodes reset the
 // voxelizer's hash table hangs on its second replay (the table is not reset, the probe loop never finds a free slot).
 int fill_words(void *p, uint32_t value, size_t n_words, hipStream_t stream);
+// the same for up to three regions in one launch (a null pointer = no region)
+int fill_words3(void *p0, uint32_t v0, size_t n0, void *p1, uint32_t v1, size_t n1, void *p2, uint32_t v2, size_t n2, hipStream_t stream);
 
 // ---- per-process state (fd_error.hip).  The library keeps NO per-call mutable state; what it caches is
 //      keyed by device ordinal and published with atomics, so calls from several threads / for several

@@ -75,18 +75,57 @@ int tuning(TuneKey key) { return tune_table().v[key].load(std::memory_order_rela
 }  // namespace fd
 
 namespace {
-__global__ void __launch_bounds__(256) fill_words_kernel(uint32_t *__restrict__ p, uint32_t v, size_t n) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+// up to three regions per launch, 16-byte stores (region starts are 16-byte aligned in every caller's layout; a tail or a
+// misaligned head of < 4 words goes out as single words)
+struct FillJob {
+    uint32_t *p[3];
+    uint32_t v[3];
+    size_t n[3];
+    unsigned first_block[4];  // region r owns blocks [first_block[r], first_block[r + 1])
+};
+__global__ void __launch_bounds__(256) fill_words_kernel(FillJob j) {
+    const int r = blockIdx.x >= j.first_block[2] ? 2 : (blockIdx.x >= j.first_block[1] ? 1 : 0);
+    uint32_t *__restrict__ p = j.p[r];
+    const uint32_t v = j.v[r];
+    const size_t n = j.n[r];
+    const size_t nb = j.first_block[r + 1] - j.first_block[r], b = blockIdx.x - j.first_block[r];
+    const size_t head = ((16 - ((uintptr_t)p & 15)) & 15) / 4 < n ? ((16 - ((uintptr_t)p & 15)) & 15) / 4 : n;
+    const size_t n4 = (n - head) / 4;
+    uint4 *p4 = reinterpret_cast<uint4 *>(p + head);
+    const uint4 v4 = make_uint4(v, v, v, v);
+    for (size_t i = b * 256 + threadIdx.x; i < n4; i += nb * 256) p4[i] = v4;
+    if (b == 0) {
+        if (threadIdx.x < head) p[threadIdx.x] = v;
+        const size_t tail0 = head + n4 * 4;
+        if (tail0 + threadIdx.x < n && threadIdx.x < 4) p[tail0 + threadIdx.x] = v;
+    }
 }
 }  // namespace
 
-int fd::fill_words(void *p, uint32_t value, size_t n_words, hipStream_t stream) {
-    if (!n_words) return 0;
-    size_t blocks = (n_words + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t *)p, value, n_words);
+int fd::fill_words3(void *p0, uint32_t v0, size_t n0, void *p1, uint32_t v1, size_t n1, void *p2, uint32_t v2, size_t n2, hipStream_t stream) {
+    FillJob j;
+    void *ps[3] = {p0, p1, p2};
+    const uint32_t vs[3] = {v0, v1, v2};
+    const size_t ns[3] = {n0, n1, n2};
+    unsigned total = 0;
+    for (int r = 0; r < 3; ++r) {
+        j.p[r] = (uint32_t *)ps[r];
+        j.v[r] = vs[r];
+        j.n[r] = ps[r] ? ns[r] : 0;
+        j.first_block[r] = total;
+        size_t blocks = j.n[r] ? (j.n[r] / 4 + 1023) / 1024 : 0;  // four 16-byte stores per thread
+        if (j.n[r] && blocks == 0) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        total += (unsigned)blocks;
+    }
+    j.first_block[3] = total;
+    if (!total) return 0;
+    hipLaunchKernelGGL(fill_words_kernel, dim3(total), dim3(256), 0, stream, j);
     return 0;
+}
+
+int fd::fill_words(void *p, uint32_t value, size_t n_words, hipStream_t stream) {
+    return fd::fill_words3(p, value, n_words, nullptr, 0u, 0, nullptr, 0u, 0, stream);
 }
 
 extern "C" const char *fd_last_error(void) { return fd::g_err; }

@@ -313,9 +313,8 @@ extern "C" int fd_voxelize(const float *points, int64_t n_points, const int32_t 
     int *bsum = (int *)(ws + w.bsum), *boff = (int *)(ws + w.boff), *vslot = (int *)(ws + w.vslot);
     int *bucket = (int *)(ws + w.bucket);
     const int n = (int)n_points;
-    fd::fill_words(keys, 0xffffffffu, w.table, stream);   // (kernels, not hipMemsetAsync: see fd::fill_words)
-    fd::fill_words(first, 0x7f7f7f7fu, w.table, stream);
-    fd::fill_words(cnt, 0u, (w.vid - w.cnt) / sizeof(int), stream);  // cnt + cursor are adjacent
+    // (a kernel, not hipMemsetAsync: see fd::fill_words; one launch for the three regions -- cnt + cursor are adjacent)
+    fd::fill_words3(keys, 0xffffffffu, w.table, first, 0x7f7f7f7fu, w.table, cnt, 0u, (w.vid - w.cnt) / sizeof(int), stream);
     const int nb = (n + 255) / 256;
     const int nsb = (n + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(vox_hash, dim3(nb), dim3(256), 0, stream, points, n, n_points_dev, p, keys, first, cnt, pslot);

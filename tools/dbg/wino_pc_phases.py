@@ -1,4 +1,4 @@
-"""Knock-out timing of the producer/consumer Winograd kernel (debug build with FD_WPC_DBG: 1 = producers idle, 2 = consumers idle)."""
+"""Graph-timed (no host time between launches) comparison of the producer/consumer Winograd tile (7) with the best one-role tile (6)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from futuredet_amd import hip_ops
@@ -17,7 +17,6 @@ for cin, cout, hw in [(128,128,180),(256,128,180),(256,256,90),(64,384,180),(512
     wp = hip_ops.pack_conv2d_weight_wino(w).cuda(); out = torch.empty(1, hw, hw, cout, device="cuda")
     line = "%d->%d@%d" % (cin, cout, hw)
     for dbg in (0,):
-        pass
-        line += " | dbg%d %.1f" % (dbg, timeit(lambda: hip_ops.conv2d_wino_nhwc_f32(x, wp, b, cout, True, out=out, tile=7)))
+        line += " | tile7 %.1f" % (timeit(lambda: hip_ops.conv2d_wino_nhwc_f32(x, wp, b, cout, True, out=out, tile=7)))
     line += " | w6 %.1f" % timeit(lambda: hip_ops.conv2d_wino_nhwc_f32(x, wp, b, cout, True, out=out, tile=6))
     print(line, flush=True)
