@@ -332,6 +332,10 @@ __global__ void __launch_bounds__(512) conv2d_wino_pc_f32(const float *__restric
         float *const y1 = y + (((int64_t)b1 * p.H + 2 * ty1) * p.W + 2 * tx1) * p.cout_total + p.co_off;  // pixel of run 1's first tile
         float *const y2 = y + (((int64_t)b2 * p.H + 2 * ty2) * p.W) * p.cout_total + p.co_off;
         const float4 bv = *reinterpret_cast<const float4 *>(s_bias + co);
+        // straight-line stores when nothing of the item can fall outside (every tile of the strip exists, no partial tile at the
+        // right / bottom edge, the 64 channels exist, 16-byte aligned channel runs): true for all but the last strip of the RPN /
+        // head layers.  The general form below has one exec-masked branch per store.
+        const bool interior = wide && n1 + n2 == NTILE && !((p.H | p.W) & 1) && (item / p.n_strips) * 64 + 64 <= p.Cout_real;
 #pragma unroll
         for (int i = 0; i < NTB; ++i) {
             const int j = i * 16 + lm;
@@ -351,6 +355,17 @@ __global__ void __launch_bounds__(512) conv2d_wino_pc_f32(const float *__restric
             yv[0][1] = sub4(sub4(r0[1], r0[2]), r0[3]);
             yv[1][0] = r1[0] + r1[1] + r1[2];
             yv[1][1] = sub4(sub4(r1[1], r1[2]), r1[3]);
+            if (interior) {  // (wave-uniform)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        f32x4 v = yv[dy][dx] + f32x4{bv.x, bv.y, bv.z, bv.w};
+                        if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                        *reinterpret_cast<f32x4 *>(yb + (dy * p.W + dx) * p.cout_total) = v;
+                    }
+                continue;
+            }
             if (!live) continue;
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
