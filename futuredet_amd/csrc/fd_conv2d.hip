@@ -24,6 +24,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int TH = 8, TW = 16;  // output pixels per workgroup (M = 128)
 
+// tuning builds (tools/probes/build_trace.sh): thread 0 of every workgroup accumulates cycles per phase:
+// [0] prologue (first patch in LDS), [1] step loops, [2] slice hand-over (store + next loads), [3] barrier, [4] epilogue, [5] whole
+#ifdef FD_V2_TRACE
+__device__ unsigned long long *g_ctrace;
+#define FD_CT(var) const unsigned long long var = __builtin_readcyclecounter()
+#define FD_CADD(i, v) cacc[i] += (v)
+#else
+#define FD_CT(var)
+#define FD_CADD(i, v)
+#endif
+
 __device__ inline unsigned short f2bf(float v) {
     unsigned u = __float_as_uint(v);
     u += 0x7fffu + ((u >> 16) & 1u);
@@ -34,6 +45,7 @@ struct ConvParams {
     int B, H, W, Cin, Ho, Wo, Cout_pad, Cout_real, cout_total, co_off, pad, relu;
     int osy, osx, ooy, oox;  // output pixel mapping
     int tiles_x, tiles_y;
+    unsigned w_bytes;
 };
 
 // WMT x WNT MFMA tiles (32 x 32) per wave, waves arranged WAVES_M x WAVES_N (product 4); M tile = 128 pixels
@@ -48,6 +60,10 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x PP x 64 bytes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef FD_V2_TRACE
+    unsigned long long cacc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    FD_CT(c_start);
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
     int t = blockIdx.x;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -113,49 +129,77 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
     constexpr int ITERS = KS * KS * 2;
     constexpr int RING = (ITERS % 6 == 0) ? 6 : 2;
     const int total_iters = nslices * ITERS;
-    const bf16x8 *wb[WNT];
-#pragma unroll
-    for (int j = 0; j < WNT; ++j) wb[j] = wp + ((n0 >> 5) + j) * w_nt_stride + lane;
+    // fragment loads: buffer loads with the wave-uniform part of the address in the scalar offset (no vector instruction per load)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(wp), 0, (int)p.w_bytes, 0x00020000);
+    const unsigned lane16 = lane * 16;
+    auto wfrag = [&](int j, int it) {
+        const int soff = __builtin_amdgcn_readfirstlane((int)((((n0 >> 5) + j) * w_nt_stride + (int64_t)it * 64) * 16));
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, soff, 0));
+    };
     bf16x8 bw[RING][WNT];
 #pragma unroll
     for (int r = 0; r < RING; ++r)
 #pragma unroll
-        for (int j = 0; j < WNT; ++j) bw[r][j] = wb[j][(int64_t)(r < total_iters ? r : 0) * 64];
-    if (nslices > 1) load_slice(1);  // registers hold slice s+1 while slice s is computed
-    for (int s = 0; s < nslices; ++s) {
-        const unsigned char *src = smem + (s & 1) * (PP * 64);
-        // A fragments are read one step ahead of their MFMAs (LDS latency ~130 cycles vs 128 cycles of MFMA per step)
-        auto read_a = [&](int it, bf16x8(&a)[WMT]) {
-            const int tap = it >> 1, ks = it & 1;
-            const int ky = tap / KS, kx = tap % KS;
+        for (int j = 0; j < WNT; ++j) bw[r][j] = wfrag(j, r < total_iters ? r : 0);
+    // per-lane LDS offsets of the A fragments of every step (tap, k-half), relative to the slice buffer
+    unsigned aoff[ITERS][WMT];
 #pragma unroll
-            for (int i = 0; i < WMT; ++i) {
-                const int pix = (prow[i] + ky) * PW + pcol[i] + kx;
-                const int q = ks * 2 + lk;
-                a[i] = *reinterpret_cast<const bf16x8 *>(src + pix * 64 + ((q ^ ((pix >> 2) & 3)) << 4));
-            }
+    for (int it = 0; it < ITERS; ++it) {
+        const int tap = it >> 1, ks = it & 1;
+        const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) {
+            const int pix = (prow[i] + ky) * PW + pcol[i] + kx;
+            const int q = ks * 2 + lk;
+            aoff[it][i] = (unsigned)(pix * 64 + ((q ^ ((pix >> 2) & 3)) << 4));
+        }
+    }
+    if (nslices > 1) load_slice(1);  // registers hold slice s+1 while slice s is computed
+    FD_CT(c_pro);
+    FD_CADD(0, c_pro - c_start);
+    for (int s = 0; s < nslices; ++s) {
+        FD_CT(c0);
+        // A fragments are read ahead of their MFMAs (LDS latency ~130 cycles, a step has 128 cycles of MFMA).  Their LDS
+        // offsets (tap, k-half and swizzle applied) are per-lane constants computed once (aoff): no address arithmetic in the loop --
+        // every VALU instruction here is a slot the MFMAs do not get.  The reads and the weight requests sit BETWEEN the MFMA groups
+        // of a step (fences): an MFMA occupies the pipe for 32 cycles but issues in 4, what is issued in its shadow is free; lumped
+        // after the step's MFMAs the same instructions cost ~100 cycles per 128-cycle step (tools/conv_bf16_trace.py: 4870 cycles
+        // per slice for 2304 of MFMA before).
+        const unsigned sbase = (unsigned)((s & 1) * (PP * 64));
+        auto read_a = [&](int it, bf16x8(&a)[WMT]) {
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + sbase + aoff[it][i]);
         };
-        bf16x8 a[2][WMT];
+        bf16x8 a[3][WMT];  // ring of three: the fragments of step it + 2 are requested in the middle of step it (1.5 steps = 190 cycles of lead)
         read_a(0, a[0]);
+        if (ITERS > 1) read_a(1, a[1]);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int slot = it % RING;  // ITERS % RING == 0, so the slot sequence is the same in every slice
-            if (it + 1 < ITERS) read_a(it + 1, a[(it + 1) & 1]);
-#pragma unroll
-            for (int i = 0; i < WMT; ++i)
-#pragma unroll
-                for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it & 1][i], bw[slot][j], acc[i][j], 0, 0, 0);
             const int nxt = s * ITERS + it + RING;
+            const int nsel = nxt < total_iters ? nxt : 0;
 #pragma unroll
-            for (int j = 0; j < WNT; ++j) bw[slot][j] = wb[j][(int64_t)(nxt < total_iters ? nxt : 0) * 64];
+            for (int j = 0; j < WNT; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < WMT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it % 3][i], bw[slot][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0 && it + 2 < ITERS) read_a(it + 2, a[(it + 2) % 3]);
+                bw[slot][j] = wfrag(j, nsel);  // the slot just consumed takes the fragment of RING steps ahead
+            }
         }
         // Patch loads go at the END of a slice: vector-memory loads return in order, so a patch load issued at the top
         // would sit in front of this slice's weight-ring loads and stall them for its whole latency; issued here it has a
         // full slice of MFMAs to land and only the ring loads of the next slice's first steps queue behind it.
+        FD_CT(c1);
         if (s + 1 < nslices) store_slice((s + 1) & 1);
         if (s + 2 < nslices) load_slice(s + 2);
+        FD_CT(c2);
         __syncthreads();
+        FD_CT(c3);
+        FD_CADD(1, c1 - c0); FD_CADD(2, c2 - c1); FD_CADD(3, c3 - c2);
     }
+    FD_CT(c_epi);
     // epilogue.  C/D layout of 32x32: col (channel) = lane & 31, row (pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
     const bool wide = ((p.cout_total | p.co_off) & 7) == 0 && (p.Cout_real & 7) == 0;  // 16-byte aligned channel runs
@@ -163,29 +207,37 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
         // A lane owns one channel of 16 pixels, i.e. 2-byte stores if written directly (64 store instructions per
         // wave, issue-bound).  Transpose the tile through LDS instead and store 16 bytes (8 channels) per lane.
         unsigned short *s_out = reinterpret_cast<unsigned short *>(smem);  // [128 pixels][NT channels] bf16
+        // Lanes l and l ^ 1 hold adjacent channels of the same 16 pixels.  Per pixel pair (r, r + 1): bias, ReLU, one packed
+        // convert (round to nearest even, v_cvt_pk_bf16_f32), the neighbour's pair by a DPP quad permute, one byte permute ->
+        // the even lane owns the (channel pair, pixel r) dword, the odd lane (channel pair, pixel r + 1): 4-byte LDS writes at
+        // compile-time offsets from a per-lane base.  (The older form rounded by hand and exchanged through ds_bpermute: 5.1 k
+        // cycles for this phase, tools/conv_bf16_trace.py.)
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bool odd = lm & 1;
+        const unsigned sel = odd ? 0x03020706u : 0x05040100u;  // v_perm_b32(nb, mine), low half first: odd -> {nb.hi16, mine.hi16}, even -> {mine.lo16, nb.lo16}
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
             const int cl = (wn * WNT + j) * 32 + lm;  // channel inside the block
             const int co = blockIdx.y * NT + cl;
             const float bv = (bias && co < p.Cout_real) ? bias[co] : 0.0f;
-            const bool odd = lm & 1;
 #pragma unroll
-            for (int i = 0; i < WMT; ++i)
+            for (int i = 0; i < WMT; ++i) {
+                unsigned char *dst = reinterpret_cast<unsigned char *>(s_out) + ((((wm * WMT + i) * 32 + (odd ? 1 : 0) + 4 * lk) * NT + (cl & ~1)) << 1);
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    // lanes l and l^1 hold adjacent channels of the same 16 pixels: swap one value so that each lane owns
-                    // a (channel pair, pixel) dword -> 4-byte LDS writes, half as many, no sub-dword bank sharing
-                    float v0 = acc[i][j][r] + bv, v1 = acc[i][j][r + 1] + bv;
-                    if (p.relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
-                    const unsigned mine0 = f2bf(v0), mine1 = f2bf(v1);
-                    const unsigned got = (unsigned)__shfl_xor((int)(odd ? mine0 : mine1), 1);
-                    const int rr = odd ? r + 1 : r;
-                    const int m = (wm * WMT + i) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lk;
-                    const unsigned packed = odd ? (got | (mine1 << 16)) : (mine0 | (got << 16));
-                    *reinterpret_cast<unsigned *>(s_out + m * NT + (cl & ~1)) = packed;
+                    f32x2_t v = {acc[i][j][r] + bv, acc[i][j][r + 1] + bv};
+                    if (p.relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); }
+                    const unsigned mine = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+                    const unsigned packed = __builtin_amdgcn_perm(nb, mine, sel);
+                    // pixel of this dword: (r & 3) + 8 (r >> 2) + 4 lk (+ 1 on the odd lane: inside `dst`)
+                    *reinterpret_cast<unsigned *>(dst + ((((r & 3) + 8 * (r >> 2)) * NT) << 1)) = packed;
                 }
+            }
         }
         __syncthreads();
+        FD_CT(c_mid);
         constexpr int C8 = NT / 8;
         for (int id = tid; id < TH * TW * C8; id += 256) {
             const int m = id / C8, c8 = id - m * C8;
@@ -197,6 +249,13 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
                     *reinterpret_cast<const uint4 *>(s_out + m * NT + c8 * 8);
             }
         }
+#ifdef FD_V2_TRACE
+        if (tid == 0 && g_ctrace) {
+            const unsigned long long c_end = __builtin_readcyclecounter();
+            unsigned long long *o = g_ctrace + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+            o[0] = cacc[0]; o[1] = cacc[1]; o[2] = cacc[2]; o[3] = cacc[3]; o[4] = c_end - c_epi; o[5] = c_end - c_start; o[6] = c_mid - c_epi; o[7] = c_end;
+        }
+#endif
         return;
     }
 #pragma unroll
@@ -243,6 +302,10 @@ int dispatch_nt(const void *x, const void *wp, const float *bias, void *y, const
 }
 
 }  // namespace
+
+#ifdef FD_V2_TRACE
+extern "C" int fd_debug_set_conv_trace(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_ctrace), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#endif
 
 extern "C" size_t fd_conv2d_packed_weight_bytes(int cout, int cin, int ks) {
     if (cout <= 0 || cin <= 0 || cin % 32 || (ks != 1 && ks != 3)) return 0;
@@ -293,6 +356,11 @@ extern "C" int fd_conv2d_nhwc_bf16(const void *x, int B, int H, int W, int cin, 
     p.Cout_pad = (cout + 31) / 32 * 32;
     p.cout_total = cout_total; p.co_off = co_off; p.pad = pad; p.relu = relu;
     p.osy = osy; p.osx = osx; p.ooy = ooy; p.oox = oox;
+    {
+        const size_t wb_ = fd_conv2d_packed_weight_bytes(cout, cin, ks);
+        FD_REQUIRE(wb_ < (1ull << 31), "fd_conv2d_nhwc_bf16: packed weights of 2 GB and more are not supported");
+        p.w_bytes = (unsigned)wb_;
+    }
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
     hipStream_t s = fd::as_stream(stream);
