@@ -12,7 +12,9 @@ def timeit(fn, iters=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return 1e3 * e0.elapsed_time(e1) / iters
-line = ""
+nt = int(sys.argv[1]) if len(sys.argv) > 1 else 0  # conv_nt override: 0 = heuristic, 64 / 32 = narrower channel blocks
+hip_ops.set_tuning("conv_nt", nt)
+line = "conv_nt=%d: " % nt
 for cin, cout, hw, ks, st in [(128,128,180,3,1),(256,128,180,3,1),(256,256,90,3,1),(512,64,180,3,1),(64,384,180,3,1),(128,256,180,3,2),(128,256,180,1,1)]:
     x = torch.randn(1, hw, hw, cin, device="cuda").bfloat16(); w = torch.randn(cout, cin, ks, ks) * 0.02; b = torch.randn(cout, device="cuda")
     wp = hip_ops.pack_conv2d_weight(w).cuda()
