@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of two builds of the library on the same box: rocprofv3 kernel durations of the sparse conv kernels over a short bench run.
-# usage: tools/dbg/ab_kernels.sh libA.so libB.so
+# usage: tools/ab_kernels.sh libA.so libB.so
 cd /tmp && export TMPDIR=/tmp
 for lib in "$@"; do
   tag=$(basename $lib .so)

@@ -1,6 +1,6 @@
 """Graph-timed bf16 3x3 / 1x1 conv layers of the RPN / head (use FD_LIB_PATH to compare two builds on one box)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from futuredet_amd import hip_ops
 def timeit(fn, iters=20):
     for _ in range(3): fn()

@@ -1,6 +1,6 @@
 """Graph-timed (no host time between launches) comparison of the producer/consumer Winograd tile (7) with the best one-role tile (6)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from futuredet_amd import hip_ops
 def timeit(fn, iters=20):
     for _ in range(3): fn()
