@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the FutureDet LiDAR hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the second timed loop (host -> host)")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage GPU times to stderr")
+    ap.add_argument("--fp32-arith", default="native", choices=["native", "split"], help="fp32 only: 'split' runs the sparse levels with >= --split-min-channels "
+                    "channels on the bf16 matrix pipe with three-piece (3 x bf16) operands, fp32 accumulate (fd_spconv_split.hip)")
+    ap.add_argument("--split-min-channels", type=int, default=128)
     ap.add_argument("--torch-dense", action="store_true", help="A/B: run RPN + head through PyTorch-ROCm (MIOpen) instead of the hand-written MFMA convolutions")
     ap.add_argument("--dump", default="", help="rank 0 saves the last step's gathered detections (npz: packed, counts) here (tests)")
     pre, _ = ap.parse_known_args()
@@ -228,8 +231,33 @@ def cpu_baseline(cfg, sd, cloud, gpu_rows):
                          "so) vs the CPU oracle, rows matched within 1e-3*max(1,|ref|) per component"}
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` started WITHOUT a launcher (no WORLD_SIZE in the environment): re-execute under
+    ``python -m torch.distributed.run --nproc-per-node N`` on a free port, one rank per GPU, as tools/dist_test.py is started in
+    the reference (tools/dist_test.py:125-135).  Refuses instead of printing ``n_gpus: 1`` when the box has fewer devices (unless
+    FD_BENCH_ONE_DEVICE=1, the 1-GPU test hook that puts every rank on cuda:0)."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < args.gpus and not os.environ.get("FD_BENCH_ONE_DEVICE"):
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) are visible\n" % (args.gpus, have))
+        sys.exit(2)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # (does not return)
     from futuredet_amd import build as fbuild
     from futuredet_amd import build_detector, dist_infer, lib
     from futuredet_amd.configs import centerpoint_config
@@ -239,7 +267,8 @@ def main():
     # world > 1 logic (sharded seeds, barriers, MAX over ranks, result gather, rank-0 print) can be exercised anywhere
     one_dev = bool(os.environ.get("FD_BENCH_ONE_DEVICE"))
     rank, world, local = dist_infer.init_from_env("gloo" if one_dev else "nccl")
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d (or plain `python bench.py --gpus %d`)" % (
+        world, args.gpus, args.gpus, args.gpus)
     if one_dev:
         local = 0
     torch.cuda.set_device(local)
@@ -267,7 +296,9 @@ def main():
     dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
     if args.torch_dense:
         net.neck.use_hip_conv = net.bbox_head.use_hip_conv = False
-    net.set_precision(dtype, None if args.channels_last < 0 else bool(args.channels_last))
+    net.set_precision(dtype, None if args.channels_last < 0 else bool(args.channels_last), fp32_arith=args.fp32_arith if hasattr(net.backbone, "fp32_arith") else None)
+    if hasattr(net.backbone, "split_min_channels"):
+        net.backbone.split_min_channels = args.split_min_channels
     prof = SpconvProfiler()
     net.backbone.profile_hook = prof
 

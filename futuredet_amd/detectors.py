@@ -79,10 +79,17 @@ class VoxelNet(SingleStageDetector):
         self.__dict__.pop("_graphs", None)
         return super()._apply(fn, *a, **kw)
 
-    def set_precision(self, dtype=torch.float32, channels_last=None):
+    def set_precision(self, dtype=torch.float32, channels_last=None, fp32_arith=None):
         """fp32 (default) or bf16 conv features/weights with fp32 accumulation; voxelizer, indexes, decode and
-        NMS always stay fp32/int."""
+        NMS always stay fp32/int.  ``fp32_arith`` ("native" | "split", fp32 only): "split" computes the wide convolutions on the
+        bf16 matrix pipe with three-piece (3 x bf16) operands and fp32 accumulation -- fp32 storage and fp32-class error at 6/16 of
+        the fp32 MFMA time (sparse: fd_spconv_split.hip; dense Winograd GEMMs: fd_conv2d_wino_pc.hip)."""
         self.__dict__.pop("_graphs", None)
+        if fp32_arith is not None:
+            assert fp32_arith in ("native", "split"), fp32_arith
+            for m in (self.backbone, self.neck, self.bbox_head):
+                if hasattr(m, "fp32_arith") or m is self.backbone:
+                    m.fp32_arith = fp32_arith
         if channels_last is None:
             channels_last = False  # measured on MI355X: MIOpen is as fast or faster on NCHW for these shapes
         self.backbone.compute_dtype = dtype
@@ -271,7 +278,8 @@ class StaticStep(object):
 
     def _version_key(self):
         m = self.model
-        return (weights_version(m), getattr(m.backbone, "compute_dtype", None), m.neck.compute_dtype, getattr(m.neck, "use_hip_conv", None))
+        return (weights_version(m), getattr(m.backbone, "compute_dtype", None), m.neck.compute_dtype, getattr(m.neck, "use_hip_conv", None),
+                getattr(m.backbone, "fp32_arith", None), getattr(m.backbone, "split_min_channels", None))
 
     def _load(self, clouds):
         assert len(clouds) == self.B

@@ -109,6 +109,8 @@ SIGNATURES = {
     "fd_rows_place": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p,
                               c_int, c_int, c_void_p]),
     "fd_shuffle_bias_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
+    "fd_rows_to_planes": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
+    "fd_planes_to_rows": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "fd_sweep_assemble_workspace_bytes": (c_size_t, [c_i64]),
     "fd_sweep_assemble": (c_int, [c_void_p, c_int, c_int, c_i64, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

@@ -119,7 +119,16 @@ int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int D
  *   in_feats  [n_in, cin]  float32 (dtype 0) or bfloat16 (dtype 1);  cin, cout in {16,32,64,128}
  *   wpacked   weights in MFMA fragment order, produced by fd_spconv_pack_weight from [K,cin,cout] float32
  *   bias      [cout] float32 or NULL; residual [n_out,cout] same dtype as out or NULL; relu 0/1
+ * Split-operand fp32 arithmetic (dtype 2 / 3 / 4; no reference counterpart -- spconv 1.0 multiplies fp32 by fp32): an fp32
+ * value is stored as the exact sum of three bf16 pieces, row = [h[C] | m[C] | l[C]] bfloat16 ("planes", 6 C bytes per row),
+ * and a product is six bf16 MFMAs with fp32 accumulate (fd_spconv_split.hip; cin, cout in {32,64,128}):
+ *   dtype 2   in_feats planes, out_feats planes, residual planes       (weights packed with dtype 2)
+ *   dtype 3   in_feats planes, out_feats float32, residual float32     (weights packed with dtype 2 or 3: same layout)
+ *   dtype 4   in_feats float32, out_feats planes, no residual; NATIVE fp32 arithmetic (weights packed with dtype 0 or 4)
+ * fd_rows_to_planes / fd_planes_to_rows convert [n, c] float32 <-> planes exactly (c a multiple of 4).
  * ------------------------------------------------------------------------------------------------- */
+int fd_rows_to_planes(const float *src, int64_t n, int c, const int32_t *n_dev, void *dst_planes, fd_stream_t stream);
+int fd_planes_to_rows(const void *src_planes, int64_t n, int c, const int32_t *n_dev, float *dst, fd_stream_t stream);
 size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype);
 int fd_spconv_pack_weight(const float *w_kio_host, int K, int cin, int cout, int dtype, void *wpacked_host);
 int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *wpacked, const float *bias, const void *residual,

@@ -1993,6 +1993,29 @@ def test_eight_ranks_on_one_gpu_config4_strong_scaling(hip, tmp_path):
             assert a.shape == b.shape and np.array_equal(a, b), "sample %d of the 8-rank run differs from the single-process bf16 run" % sid
 
 
+def test_plain_bench_command_starts_its_own_ranks(hip):
+    """`python bench.py --gpus 2` WITHOUT a launcher (no WORLD_SIZE in the environment) must run two ranks -- it
+    re-executes itself under torch.distributed.run on a free port (tools/dist_test.py:125-135 is started once per GPU by the
+    launcher) -- and report n_gpus = 2; with fewer devices than ranks (and no one-device hook) it must refuse, not print n_gpus 1."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(FD_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "20000", "--no-cpu-baseline",
+           "--no-host-leg", "--inflight", "2", "--pool", "2"]
+    out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and "all 2 rank" in line["config"]["replicas"]
+    if torch.cuda.device_count() < 2:
+        env.pop("FD_BENCH_ONE_DEVICE")
+        out = subprocess.run(cmd, env=env, cwd=repo, capture_output=True, text=True, timeout=300)
+        assert out.returncode != 0 and "device(s) are visible" in out.stderr and "n_gpus" not in out.stdout
+
+
 @pytest.mark.parametrize("variant,precision", [("forecast_n0", "fp32"), ("forecast_n3", "bf16"), ("forecast_n3dtf", "fp32"), ("forecast_n3dtf", "bf16")])
 def test_decode_reads_the_head_output_in_place(hip, variant, precision):
     """predict_packed (the decode kernels read the conv plan's NHWC output through fd_map_view, velocities / labels / counts are

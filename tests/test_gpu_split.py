@@ -1,0 +1,226 @@
+"""Split-operand (3 x bf16) fp32 arithmetic: the gate the review set for making it the measured path.
+
+* per-layer error against a float64 reference must stay within 2 x the native fp32 kernel's error (same inputs, same
+  rulebook), for every channel pair the split kernels cover and for the F.conv3d arbiter geometries;
+* the error table goes to gpurun_out/split_error_table.txt (the round's copy is committed under profiles/);
+* every full-size 1e-3 criterion of the fp32 configuration holds on the split path too.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from parity_util import REPO, assert_close, rel_err, report
+
+pytestmark = pytest.mark.gpu
+TABLE = os.path.join(REPO, "gpurun_out", "split_error_table.txt")
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _table(line):
+    print("[split] " + line)
+    try:
+        os.makedirs(os.path.dirname(TABLE), exist_ok=True)
+        with open(TABLE, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+def _err_stats(got, ref64):
+    """(max, rms) of |got - ref| / max(1, |ref|) against a float64 reference"""
+    d = np.abs(got.astype(np.float64) - ref64) / np.maximum(1.0, np.abs(ref64))
+    return float(d.max()), float(np.sqrt((d * d).mean()))
+
+
+def _float64_conv(x, w, nbr, n_out, bias=None, residual=None, relu=False):
+    """sum_k x[nbr[k, o]] @ w[k] in float64 on the host, driven by the DEVICE rulebook (so both kernels and the reference
+    see the same pairs; the rulebook itself is checked against the oracle elsewhere)."""
+    x64 = x.astype(np.float64)
+    out = np.zeros((n_out, w.shape[2]), np.float64)
+    for k in range(nbr.shape[0]):
+        o = np.nonzero(nbr[k, :n_out] >= 0)[0]
+        if len(o):
+            out[o] += x64[nbr[k, o]] @ w[k].astype(np.float64)
+    if bias is not None:
+        out += bias.astype(np.float64)
+    if residual is not None:
+        out += residual.astype(np.float64)
+    return np.maximum(out, 0) if relu else out
+
+
+def _sparse_level(hip, rng, B, D, H, W, p, cin, scale=1.0):
+    occ = rng.random((B, D, H, W)) < p
+    idx = np.argwhere(occ).astype(np.int32)
+    rng.shuffle(idx)
+    feats = (rng.standard_normal((len(idx), cin)) * scale).astype(np.float32)
+    src = hip.SparseIndex(B, D, H, W, torch.device("cuda"))
+    n_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    src.mark(_dev(idx))
+    src.scan(n_dev)
+    src.finalize(int(n_dev.cpu()[0]))
+    x = hip.rows_permute(_dev(feats), src.lookup(_dev(idx)), cin, torch.float32, n_rows=src.n)
+    return src, x
+
+
+SPLIT_PAIRS = [(32, 32), (32, 64), (64, 64), (64, 128), (128, 128)]
+
+
+@pytest.mark.parametrize("cin,cout", SPLIT_PAIRS)
+@pytest.mark.parametrize("scale", [1.0, 300.0], ids=["unit", "x300"])
+def test_spconv_split_error_within_twice_the_native_kernels(hip, cin, cout, scale):
+    """Same rows, weights, rulebook: native fp32 MFMA kernel vs the split-operand kernel, each against float64.  Gate: the
+    split kernel's max and rms error <= 2 x the native kernel's (+ one fp32 ulp of slack for tiny cases), and <= the 1e-4 of
+    test_spconv_apply_vs_oracle.  Row-group variants of the split kernel agree bit for bit.  ``x300``: features of a few
+    hundred (what un-normalised stages carry) -- the split has no fixed-point range to fall out of."""
+    rng = np.random.default_rng(cin * 11 + cout)
+    src, x = _sparse_level(hip, rng, 2, 9, 40, 37, 0.2, cin, scale)
+    w = (rng.standard_normal((27, cin, cout)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    res = (rng.standard_normal((src.n, cout)) * scale).astype(np.float32)
+    nbr = src.rulebook(src, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    w_native = hip.pack_spconv_weight(torch.from_numpy(w)).cuda()
+    w_split = hip.pack_spconv_weight(torch.from_numpy(w), hip.F32_SPLIT).cuda()
+    y_native = hip.spconv_apply(x, w_native, _dev(bias), nbr, src.n, cout, residual=_dev(res), relu=True).cpu().numpy()
+    xp, resp = hip.rows_to_planes(x), hip.rows_to_planes(_dev(res))
+    assert torch.equal(hip.planes_to_rows(xp), x), "planes are a lossless re-encoding of the float32 rows"
+    ys = []
+    try:
+        for nt in (0, 1, 2, 3, 4):  # default, then 1 .. 4 tiles of 32 rows per wave (capped by the shape's register budget)
+            hip.set_tuning("split_rg", nt)
+            yp = hip.spconv_apply(xp, w_split, _dev(bias), nbr, src.n, cout, residual=resp, relu=True, mode="p2p")
+            ys.append(hip.planes_to_rows(yp).cpu().numpy())
+        hip.set_tuning("split_rg", 0)
+        y_f = hip.spconv_apply(xp, w_split, _dev(bias), nbr, src.n, cout, residual=_dev(res), relu=True, mode="p2f").cpu().numpy()
+    finally:
+        hip.set_tuning("split_rg", 0)
+    for other in ys[1:]:
+        assert np.array_equal(ys[0], other), "split kernel: tiles-per-wave variants must agree bit for bit"
+    assert np.array_equal(ys[0], y_f), "planes out and float32 out are the same numbers"
+    ref = _float64_conv(x.cpu().numpy(), w, nbr.cpu().numpy(), src.n, bias, res, True)
+    en, es = _err_stats(y_native, ref), _err_stats(ys[0], ref)
+    _table("sparse subm 3x3x3 %3d->%3d scale %-5g rows %6d  native max %.3e rms %.3e   split max %.3e rms %.3e   ratio max %.2f rms %.2f"
+           % (cin, cout, scale, src.n, en[0], en[1], es[0], es[1], es[0] / max(en[0], 1e-30), es[1] / max(en[1], 1e-30)))
+    tol = max(1e-4, 2.0 * en[0])  # (x300: the native kernel itself sits at 1.5e-4 ... 5e-4 of max(1, |ref|): fp32 resolution of sums of ~1e3)
+    report("spconv split %d->%d x%g vs float64 (native %.2e)" % (cin, cout, scale, en[0]), es[0], tol)
+    assert es[0] <= tol
+    assert es[0] <= 2.0 * en[0] + 1.2e-7 and es[1] <= 2.0 * en[1] + 1e-8, (en, es)
+
+
+CONV3D_SPLIT_CASES = [((3, 3, 3), (1, 1, 1), (1, 1, 1), True, 32, 32, 0.15), ((3, 3, 3), (1, 1, 1), (1, 1, 1), True, 64, 64, 0.25),
+                      ((3, 3, 3), (1, 1, 1), (1, 1, 1), True, 128, 128, 0.30), ((3, 3, 3), (2, 2, 2), (1, 1, 1), False, 32, 64, 0.10),
+                      ((3, 3, 3), (2, 2, 2), (0, 1, 1), False, 64, 128, 0.15), ((3, 1, 1), (2, 1, 1), (0, 0, 0), False, 128, 128, 0.30)]
+
+
+@pytest.mark.parametrize("case", CONV3D_SPLIT_CASES, ids=lambda c: "k%s_s%s_%d-%d" % ("".join(map(str, c[0])), "".join(map(str, c[1])), c[4], c[5]))
+def test_spconv_split_matches_dense_conv3d_directly(hip, case):
+    """The arbiter that is not this repo's oracle (see test_sparse_conv_matches_dense_conv3d_directly): the split kernel against a
+    float64 torch conv3d on the densified input (a 21 x 48 x 48 grid, B = 2), every geometry of the backbone; the native kernel's
+    error on the same case is the yardstick."""
+    ks, st, pd, subm, cin, cout, dens = case
+    rng = np.random.default_rng(cin * 137 + cout + ks[1])
+    B, D, H, W = 2, 21, 48, 48
+    occ = rng.random((B, D, H, W)) < dens
+    idx = np.argwhere(occ).astype(np.int32)
+    rng.shuffle(idx)
+    feats = rng.standard_normal((len(idx), cin)).astype(np.float32)
+    w = (rng.standard_normal((ks[0] * ks[1] * ks[2], cin, cout)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    src = hip.SparseIndex(B, D, H, W, torch.device("cuda"))
+    n_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    src.mark(_dev(idx))
+    src.scan(n_dev)
+    src.finalize(int(n_dev.cpu()[0]))
+    x = hip.rows_permute(_dev(feats), src.lookup(_dev(idx)), cin, torch.float32, n_rows=src.n)
+    if subm:
+        dst = src
+    else:
+        dst = src.downsample(ks, st, pd)
+        nd = torch.zeros(1, dtype=torch.int32, device="cuda")
+        dst.scan(nd)
+        dst.finalize(int(nd.cpu()[0]))
+    nbr = src.rulebook(dst, ks, st, pd)
+    y_split = hip.spconv_apply(hip.rows_to_planes(x), hip.pack_spconv_weight(torch.from_numpy(w), hip.F32_SPLIT).cuda(), None, nbr, dst.n, cout, mode="p2f")
+    y_native = hip.spconv_apply(x, hip.pack_spconv_weight(torch.from_numpy(w)).cuda(), None, nbr, dst.n, cout)
+    co = dst.coords.long().cpu()
+    dense_in = torch.zeros((B, cin, D, H, W), dtype=torch.float64)
+    ii = torch.from_numpy(idx.astype(np.int64))
+    dense_in[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]] = torch.from_numpy(feats).double()
+    w5 = torch.from_numpy(w).reshape(ks[0], ks[1], ks[2], cin, cout).permute(4, 3, 0, 1, 2).contiguous().double()
+    ref = torch.nn.functional.conv3d(dense_in, w5, None, stride=st, padding=pd)
+    ref_rows = ref[co[:, 0], :, co[:, 1], co[:, 2], co[:, 3]].numpy()
+    en, es = _err_stats(y_native.cpu().numpy(), ref_rows), _err_stats(y_split.cpu().numpy(), ref_rows)
+    _table("conv3d arbiter k%s s%s %3d->%3d rows %6d  native max %.3e rms %.3e   split max %.3e rms %.3e   ratio max %.2f rms %.2f"
+           % ("".join(map(str, ks)), "".join(map(str, st)), cin, cout, dst.n, en[0], en[1], es[0], es[1], es[0] / max(en[0], 1e-30), es[1] / max(en[1], 1e-30)))
+    report("spconv split vs float64 F.conv3d k%s s%s %d->%d (native %.2e)" % (ks, st, cin, cout, en[0]), es[0], 1e-4)
+    assert es[0] <= 1e-4 and es[0] <= 2.0 * en[0] + 1.2e-7 and es[1] <= 2.0 * en[1] + 1e-8, (en, es)
+
+
+def test_split_operand_pieces_are_exact(hip):
+    """x = h + m + l exactly for finite fp32 values (the claim the kernel header makes), checked through the kernel: a 1-tap
+    'convolution' with an identity weight must return its input bit for bit -- including denormal-range, huge and tiny values."""
+    rng = np.random.default_rng(5)
+    cin = cout = 32
+    src, x = _sparse_level(hip, rng, 1, 5, 24, 24, 0.3, cin)
+    n = src.n
+    mant = rng.standard_normal((n, cin)).astype(np.float32)
+    expo = rng.integers(-100, 100, size=(n, cin))
+    vals = np.ldexp(mant, expo).astype(np.float32)
+    vals[0, :8] = [0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.1754944e-38, 1e-40]
+    x = _dev(vals)
+    w = np.zeros((27, cin, cout), np.float32)
+    w[13] = np.eye(cin, dtype=np.float32)
+    nbr = src.rulebook(src, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    xp = hip.rows_to_planes(x)
+    back = hip.planes_to_rows(xp).cpu().numpy()
+    small = np.abs(vals) < 2.0 ** -100  # (pieces of values this small leave the normal range: not exact, documented)
+    assert np.array_equal(back[~small], vals[~small]), "float32 -> planes -> float32 must be the identity"
+    y = hip.spconv_apply(xp, hip.pack_spconv_weight(torch.from_numpy(w), hip.F32_SPLIT).cuda(), None, nbr, n, cout, mode="p2f").cpu().numpy()
+    assert np.array_equal(y[~small], vals[~small]), "identity weights through the split kernel must return the input bit for bit"
+    assert np.all(np.abs(y[small]) <= np.abs(vals[small]) * 1.0000002)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 64)])
+def test_native_kernel_planes_epilogue_is_the_split_of_its_float32_output(hip, cin, cout):
+    """mode f2p (the layer in front of a split region: native fp32 arithmetic, output written as planes) == rows_to_planes of the
+    same layer's float32 output, bit for bit."""
+    rng = np.random.default_rng(cin + cout)
+    src, x = _sparse_level(hip, rng, 2, 9, 40, 37, 0.2, cin)
+    dst = src.downsample((3, 3, 3), (2, 2, 2), (1, 1, 1))
+    nd = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dst.scan(nd)
+    dst.finalize(int(nd.cpu()[0]))
+    nbr = src.rulebook(dst, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    w = (rng.standard_normal((27, cin, cout)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    wpk = hip.pack_spconv_weight(torch.from_numpy(w)).cuda()
+    bias = _dev(rng.standard_normal(cout).astype(np.float32))
+    y = hip.spconv_apply(x, wpk, bias, nbr, dst.n, cout, relu=True)
+    yp = hip.spconv_apply(x, wpk, bias, nbr, dst.n, cout, relu=True, mode="f2p")
+    assert torch.equal(yp, hip.rows_to_planes(y))
+    assert torch.equal(hip.planes_to_rows(yp), y)
+
+
+def test_full_size_config2_fp32_split_vs_oracle(hip):
+    """BASELINE configs[1] on the split path (backbone's wide layers + Winograd GEMMs as 3 x bf16): the same 1e-3 criteria as
+    test_full_size_config2_fp32_vs_oracle, and the native path's achieved errors next to it in the table."""
+    from futuredet_amd.synth import synthetic_cloud
+    from test_gpu_parity import _attribute, _build_pair, _hip_maps, _oracle_run, _rows
+
+    cfg, net, onet = _build_pair("forecast_n0")
+    cloud = synthetic_cloud(seed=0, target_points=300000)
+    v, c, n, obb, obev, want = _oracle_run(cfg, onet, cloud)
+    bb_n, x_n = _hip_maps(net, cfg, v, c, n)
+    net.set_precision(torch.float32, fp32_arith="split")
+    bb, x = _hip_maps(net, cfg, v, c, n)
+    assert not torch.equal(bb, bb_n), "the split path must actually run (different arithmetic, different bits)"
+    e_bb = assert_close("full size config 2 SPLIT backbone BEV", bb.float().cpu().numpy(), obb.numpy(), 1e-3)
+    e_x = assert_close("full size config 2 SPLIT neck output", x.float().cpu().numpy(), obev.numpy(), 1e-3)
+    _table("full size config 2 (n0, 300k pts): backbone BEV vs oracle native %.3e split %.3e; neck output native %.3e split %.3e"
+           % (rel_err(bb_n.float().cpu().numpy(), obb.numpy()), e_bb, rel_err(x_n.float().cpu().numpy(), obev.numpy()), e_x))
+    with torch.no_grad():
+        for i in range(2):  # eager + graph replay
+            got = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
+            _attribute("full size config 2 SPLIT forward_points run %d" % i, _rows(got), _rows(want), cfg.test_cfg, topk_cut=want["topk_cut"])
