@@ -346,8 +346,10 @@ __global__ void __launch_bounds__(256) rows_place(const unsigned long long *__re
 // one thread per (output row, (ky,kx) column pair): fills the kz taps of that column from one word load
 __global__ void __launch_bounds__(256) rulebook_kernel(const unsigned long long *__restrict__ in_words, const int *__restrict__ in_prefix,
                                                        IndexGeom gi, const int *__restrict__ out_coords, const int *__restrict__ n_out_dev,
-                                                       int64_t nbr_stride, int fill_tail, DownParams dp, int *__restrict__ nbr) {
-    const int n_out = fd::device_count((int)(nbr_stride < 0x7fffffff ? nbr_stride : 0x7fffffff), n_out_dev);
+                                                       int64_t nbr_stride, int64_t out_rows, int fill_tail, DownParams dp, int *__restrict__ nbr) {
+    // rows = the device's count clamped to what the coordinate table HOLDS (out_rows), not to the padded row stride of nbr: an
+    // overflowing sweep of a capacity-sized level (count > capacity) must not read coordinates past the level's slice
+    const int n_out = fd::device_count((int)(out_rows < 0x7fffffff ? out_rows : 0x7fffffff), n_out_dev);
     // rows written: all of the table's row capacity (tail = -1), or only the device's count when the consumers clamp to it
     // themselves (capacity-sized tables of the sync-free step: the launch must not cost what the capacity suggests)
     const int64_t n_rows = fill_tail ? nbr_stride : (int64_t)n_out;
@@ -495,9 +497,10 @@ extern "C" int fd_rows_place(const uint64_t *words, const int32_t *prefix, int B
 }
 
 extern "C" int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int Din, int Hin, int Win,
-                           const int32_t *out_coords, const int32_t *n_out_dev, int64_t nbr_stride, int fill_tail, const int *ksize3,
+                           const int32_t *out_coords, int64_t out_rows, const int32_t *n_out_dev, int64_t nbr_stride, int fill_tail, const int *ksize3,
                            const int *stride3, const int *pad3, int32_t *nbr, fd_stream_t stream) {
     FD_REQUIRE(in_words && in_prefix && out_coords && n_out_dev && nbr && ksize3 && stride3 && pad3, "fd_rulebook: null argument");
+    FD_REQUIRE(out_rows >= 0 && out_rows <= nbr_stride, "fd_rulebook: out_rows (rows of out_coords) must lie in [0, nbr_stride]");
     DownParams dp;
     FD_REQUIRE(fill_dp(dp, ksize3, stride3, pad3) == 0, "fd_rulebook: unsupported kernel/stride/pad");
     if (nbr_stride <= 0) return FD_OK;
@@ -508,7 +511,7 @@ extern "C" int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, i
     const int64_t cap = ((int64_t)fd::device_cu_count() * 32 + kyx - 1) / kyx;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(rulebook_kernel, dim3((unsigned)blocks, (unsigned)kyx), dim3(256), 0, fd::as_stream(stream),
-                       (const unsigned long long *)in_words, in_prefix, gi, out_coords, n_out_dev, nbr_stride, fill_tail, dp, nbr);
+                       (const unsigned long long *)in_words, in_prefix, gi, out_coords, n_out_dev, nbr_stride, out_rows, fill_tail, dp, nbr);
     return fd::check_launch("fd_rulebook");
 }
 

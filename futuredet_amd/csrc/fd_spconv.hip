@@ -524,6 +524,12 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
         if (fd::spconv_bf16_ws_dispatch(in_feats, w, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out, n_out_dev, n_expected, cin, cout, out_feats,
                                         fd::as_stream(stream)))
             return fd::check_launch("fd_spconv_apply(bf16 ws)");
+        // "strict" (fd_tuning_set / FD_STRICT=1; tests and tuning runs): a shape the default kernel family covers must not fall
+        // through to the older kernels silently (round 3: 32 -> 64 did, because its LDS request did not fit)
+        if (fd::tuning(fd::kTuneStrict) && n_in * cin * 2 < (1ll << 31)) {
+            fd::set_error("fd_spconv_apply: strict mode: the bf16 kernel (fd_spconv_bf16.hip) did not take %d -> %d, K = %d", cin, cout, K);
+            return FD_EINVAL;
+        }
     }
     if (dtype == 1 && cin >= 32 && cout >= 64 && !fd::tuning(fd::kTuneSpconvBf16V1) && n_in * cin * 2 < (1ll << 31)) {
         // bf16, wide layers: column-split workgroups (shared gather through LDS, per-wave weight slices)

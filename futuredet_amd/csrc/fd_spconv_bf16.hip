@@ -352,15 +352,20 @@ constexpr size_t ws_lds_bytes(int K) {
 template <int CIN, int COUT, int RG, int DEPTH, int NW, bool RING>
 struct WsKernel {
     static int wgs_per_cu(int K) {
-        static std::atomic<int> cached[2] = {{0}, {0}};  // K = 27 / K = 3 differ in the RESIDENT kernels' LDS request
-        std::atomic<int> &c = cached[K == kMaxTaps ? 0 : 1];
+        // The RESIDENT kernels' LDS request grows with K (all taps' weights are staged), so the answer is cached per K; the
+        // dynamic-LDS limit of the instantiation is raised ONCE per device to the most any K can ask for (capped at the CU's
+        // 160 KB) -- a limit set for a small K and then reused for a larger one made that launch fail (advisor, round 3).
+        static std::atomic<int> cached[kMaxTaps + 1] = {};
+        K = K < 1 ? 1 : (K > kMaxTaps ? kMaxTaps : K);
+        std::atomic<int> &c = cached[K];
         int v = c.load(std::memory_order_relaxed);
         if (v) return v > 0 ? v : 0;
         const size_t lds = ws_lds_bytes<CIN, COUT, RG, NW, RING>(K);
+        const size_t lds_limit = ws_lds_bytes<CIN, COUT, RG, NW, RING>(kMaxTaps) < (size_t)160 * 1024 ? ws_lds_bytes<CIN, COUT, RG, NW, RING>(kMaxTaps) : (size_t)160 * 1024;
         auto kern = spconv_bf16_ws<CIN, COUT, RG, DEPTH, NW, RING>;
         int nb = 0;
         static std::atomic<uint64_t> lds_set{0};
-        if (lds > 160 * 1024 || (lds > 65536 && !fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_set)) ||
+        if (lds > 160 * 1024 || (lds_limit > 65536 && !fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_limit, lds_set)) ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, lds) != hipSuccess) {
             (void)hipGetLastError();
             nb = 0;
@@ -390,6 +395,12 @@ struct WsKernel {
 // 1024-thread workgroup (128 per lane) excludes 4 row groups for 64 output columns and the deep ring next to 4 groups.
 template <int CIN, int COUT>
 bool launch_resident(const WsArgs &a, int rg, int depth) {
+    if constexpr (CIN == 32 && COUT == 64) {
+        // 27 taps x 4 KB of weights = 108 KB: next to them only 8 waves' rulebook slices fit the CU's 160 KB (16 waves: 166 KB --
+        // that variant refused every K = 27 launch of round 3 and the layer silently ran the round-2 kernel).  512-thread
+        // workgroups have 256 registers per lane: two row groups x 64 columns fit.
+        if (a.K > 9) return rg >= 2 ? WsKernel<CIN, COUT, 2, 2, 8, false>::launch(a) : WsKernel<CIN, COUT, 1, 4, 8, false>::launch(a);
+    }
     if constexpr (COUT <= 32) {
         if (rg >= 4) return WsKernel<CIN, COUT, 4, 2, 16, false>::launch(a);
     }
@@ -449,7 +460,10 @@ int spconv_bf16_ws_dispatch(const void *in, const void *wp, const float *bias, c
         case 16016: for (; rg >= 1 && !(ok = launch_resident<16, 16>(a, rg, depth)); rg >>= 1) {} break;
         case 16032: for (; rg >= 1 && !(ok = launch_resident<16, 32>(a, rg, depth)); rg >>= 1) {} break;
         case 32032: for (; rg >= 1 && !(ok = launch_resident<32, 32>(a, rg, depth)); rg >>= 1) {} break;
-        case 32064: for (; rg >= 1 && !(ok = launch_resident<32, 64>(a, rg, depth)); rg >>= 1) {} break;
+        case 32064:
+            if (fd::tuning(fd::kTuneBf16RG) <= 0) rg = 2;  // (8-wave workgroups: 32 rows per wave keep 256 rows per workgroup pass)
+            for (; rg >= 1 && !(ok = launch_resident<32, 64>(a, rg, depth)); rg >>= 1) {}
+            break;
         case 64064: ok = launch_ring<64, 64>(a, rg, depth); break;
         case 64128: ok = launch_ring<64, 128>(a, rg, depth); break;
         case 128128: ok = launch_ring<128, 128>(a, rg, depth); break;

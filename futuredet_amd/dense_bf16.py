@@ -280,16 +280,24 @@ class HeadPlan(object):
                 cat[(ti + 1) & 1][..., hc:].copy_(x)                # and behind x for the next task's concat
                 d["feats"] = x.permute(0, 3, 1, 2)
             y1 = c1(x)
-            if zbuf is None:  # all tasks of a head have the same branches: one [T, B, H, W, C_total] buffer takes every task's final convs
-                Bz, Hz, Wz, _ = y1.shape
-                zbuf = torch.empty((len(self.tasks), Bz, Hz, Wz, int(sum(couts))), dtype=self.dtype, device=y1.device)
-            c2(y1, out=zbuf[ti])
-            z = zbuf[ti].permute(0, 3, 1, 2)  # [B, sum(couts), H, W] view
+            uniform = all(tuple(t[3]) == tuple(self.tasks[0][3]) for t in self.tasks)
+            if uniform:
+                if zbuf is None:  # all tasks have the same branch widths: one [T, B, H, W, C_total] buffer takes every task's final convs
+                    Bz, Hz, Wz, _ = y1.shape
+                    zbuf = torch.empty((len(self.tasks), Bz, Hz, Wz, int(sum(couts))), dtype=self.dtype, device=y1.device)
+                zt = zbuf[ti]
+                c2(y1, out=zt)
+            else:
+                # tasks of different widths (e.g. the 6-task nuScenes head with 1- and 2-class tasks): a buffer per task, and no packed
+                # decode (raw = None: CenterHead.predict takes the per-task path) -- a shared buffer sized by the first task would
+                # reject or leave stale channels for the wider ones (advisor, round 3)
+                zt = c2(y1)
+            z = zt.permute(0, 3, 1, 2)  # [B, sum(couts), H, W] view
             o, where = 0, {}
             for name, cn in zip(names, couts):
                 d[name] = z[:, o:o + cn]
                 where[name] = (o, cn)
                 o += cn
-            d.raw = (zbuf, ti, where)
+            d.raw = (zbuf, ti, where) if uniform else None
             rets.append(d)
         return rets

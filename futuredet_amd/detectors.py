@@ -50,12 +50,37 @@ class SingleStageDetector(BaseDetector):
             print("no pretrained model at {}".format(pretrained))
 
 
-def load_checkpoint(model, filename, map_location="cpu", strict=False):
-    """det3d/torchie/trainer/checkpoint.py:122-173: accepts {state_dict: ...} or a bare dict, strips "module."."""
+_REMOTE_SCHEMES = ("modelzoo://", "torchvision://", "open-mmlab://", "http://", "https://")
+
+
+def load_checkpoint(model, filename, map_location="cpu", strict=False, logger=None):
+    """The contract of det3d/torchie/trainer/checkpoint.py:122-173 for local files: ``filename`` must be an existing file (IOError
+    otherwise); the checkpoint is an OrderedDict of tensors or a dict with a "state_dict" entry (RuntimeError otherwise); a
+    leading "module." (DataParallel / DDP wrapper) is stripped from every key when the first key carries it; a wrapper model is
+    loaded through its ``.module``; returns the checkpoint object.  The reference also downloads modelzoo:// / torchvision:// /
+    open-mmlab:// / http(s):// names through torch's model zoo -- this build has no network path and says so instead."""
+    import collections
+    import os.path as osp
+
+    if isinstance(filename, str) and filename.startswith(_REMOTE_SCHEMES):
+        raise NotImplementedError("load_checkpoint: remote checkpoints (%s) are not fetched by this build; download the file and pass its path"
+                                  % filename.split("://")[0])
+    if not osp.isfile(filename):
+        raise IOError("{} is not a checkpoint file".format(filename))
     ckpt = torch.load(filename, map_location=map_location)
-    sd = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
-    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
-    model.load_state_dict(sd, strict=strict)
+    if isinstance(ckpt, collections.OrderedDict):
+        sd = ckpt
+    elif isinstance(ckpt, dict) and "state_dict" in ckpt:
+        sd = ckpt["state_dict"]
+    else:
+        raise RuntimeError("No state_dict found in checkpoint file {}".format(filename))
+    keys = list(sd.keys())
+    if keys and keys[0].startswith("module."):
+        sd = collections.OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in sd.items())
+    target = model.module if hasattr(model, "module") else model
+    res = target.load_state_dict(sd, strict=strict)
+    if logger is not None and (res.missing_keys or res.unexpected_keys):
+        logger.warning("load_checkpoint: missing keys %s, unexpected keys %s", list(res.missing_keys), list(res.unexpected_keys))
     return ckpt
 
 
@@ -256,11 +281,13 @@ class StaticStep(object):
                                                                    # static tensors (valid until the next call on this stream)
     One StaticStep belongs to one stream (the one current at capture); sweeps in flight on several streams use one each."""
 
-    def __init__(self, model, voxel_cfg, capacity, batch_size=1, ndim=5, packed=False, row_caps="datafree", headroom=1.5):
-        """``row_caps``: "datafree" sizes the sparse levels by bounds that hold for ANY cloud (no overflow possible; ~2 GB of
-        scratch per step at the bench configuration, 1.28 M / 1.43 M rows for levels 1 / 2 where a 300k-point cloud has 0.27 M /
-        0.16 M); "auto" sizes them by ``headroom`` x the counts of the warm-up clouds (+ 4096 rows): a sweep that needs more rows
-        than that is detected -- ``overflowed()`` / ``run_checked()`` -- and must be re-run on the eager path."""
+    def __init__(self, model, voxel_cfg, capacity, batch_size=1, ndim=5, packed=False, row_caps="auto", headroom=1.5):
+        """``row_caps``: "auto" (default) sizes the sparse levels by ``headroom`` x the counts of the warm-up clouds (+ 4096 rows): a
+        sweep that needs more rows than that is detected from its level counts and re-run on the eager path -- ``step(clouds)`` does
+        both (one synchronisation per call); callers that copy ``level_counts`` next to their results pass ``check=False`` and call
+        ``overflowed(counts)`` themselves, as bench.py does.  "datafree" sizes the levels by bounds that hold for ANY cloud (no
+        overflow possible, no check; ~2 GB of scratch per step at the bench configuration, 1.28 M / 1.43 M rows for levels 1 / 2 where
+        a 300k-point cloud has 0.27 M / 0.16 M, and fp32 batches of 8 exceed the fp32 kernel's 2^23-row packing)."""
         self.model, self.voxel_cfg = model, voxel_cfg
         self.padded = "packed" if packed else True  # packed: outputs = (packed [B,S,post,11], counts [B,S]) instead of four tensors
         self.row_caps_mode, self.headroom = row_caps, float(headroom)
@@ -357,7 +384,10 @@ class StaticStep(object):
         self.graph = g
         self.version = self._version_key()
 
-    def __call__(self, clouds, bev_map=None):
+    def __call__(self, clouds, bev_map=None, check=True):
+        """Replays the captured sweep.  With capacities from a high-water mark (row_caps="auto") and ``check`` the level counts are
+        read back (one synchronisation) and an overflowing sweep is re-run on the eager path: the result is always correct.
+        ``check=False``: the caller checks ``overflowed()`` itself (no synchronisation here)."""
         self._set_bev(bev_map)
         if self.graph is None or self.version != self._version_key():
             if self.expected is None:
@@ -365,6 +395,8 @@ class StaticStep(object):
             self.capture()
         self._load(clouds)
         self.graph.replay()
+        if check and self.caps is not None and self.overflowed():
+            return self.model.forward_points(clouds, self.voxel_cfg, padded=self.padded, bev_map=self.bev)
         return self.outputs
 
     def overflowed(self, level_counts_host=None):
@@ -377,11 +409,8 @@ class StaticStep(object):
         return any(n > c for n, c in zip(lc, self.caps))
 
     def run_checked(self, clouds):
-        """replay + overflow check (one synchronisation) + eager re-run of an overflowing sweep: always-correct results"""
-        out = self(clouds)
-        if self.overflowed():
-            return self.model.forward_points(clouds, self.voxel_cfg, padded=self.padded, bev_map=self.bev)
-        return out
+        """replay + overflow check (one synchronisation) + eager re-run of an overflowing sweep (what ``step(clouds)`` does by default)"""
+        return self(clouds, check=True)
 
 
 @DETECTORS.register_module

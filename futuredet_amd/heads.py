@@ -269,7 +269,10 @@ class CenterHead(nn.Module):
         assert where["hm"][1] == 1, "single-class heat-maps (every shipped task has one class)"
         if self.standard:  # center_head.py:559-570: one task, step s = its boxes + velocity channels 2s, 2s+1 (all steps share them when timesteps == 1)
             G = 1
-            S = self.target_timesteps
+            # center_head.py:559-565 emits one step per velocity pair: ``timesteps`` of them when the head forecasts, else
+            # ``target_timesteps`` copies of the single pair (the same rule as _groups above)
+            S = self.timesteps if self.timesteps > 1 else self.target_timesteps
+            assert self.timesteps <= 1 or 2 * S <= where["vel"][1], "velocity channels 2 s, 2 s + 1 must exist for every step"
             step_group = [0] * S
             step_vel = [2 * s if self.timesteps > 1 else 0 for s in range(S)]
             num_classes = [1] * S

@@ -216,7 +216,7 @@ class SparseIndex(object):
             nbr.fill_(-1)
             return nbr
         # static indexes: the table has the level's row capacity; only the device's count of rows is written (and read)
-        check(L.fd_rulebook(_p(self.words), _p(self.prefix), self.B, self.D, self.H, self.W, _p(out_index.coords),
+        check(L.fd_rulebook(_p(self.words), _p(self.prefix), self.B, self.D, self.H, self.W, _p(out_index.coords), out_index.n,
                             _p(out_index.n_dev), nstride, 0 if static else 1, (ctypes.c_int * 3)(*ksize), (ctypes.c_int * 3)(*stride),
                             (ctypes.c_int * 3)(*pad), _p(nbr), _stream()), "fd_rulebook")
         nbr.n_out = out_index.n

@@ -51,7 +51,7 @@ SIGNATURES = {
     "fd_index_coords": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "fd_index_lookup": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "fd_rows_permute": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p]),
-    "fd_rulebook": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p,
+    "fd_rulebook": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p,
                             c_void_p, c_void_p, c_void_p]),
     "fd_spconv_packed_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "fd_spconv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

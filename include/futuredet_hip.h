@@ -104,10 +104,11 @@ int fd_index_lookup(const uint64_t *words, const int32_t *prefix, int B, int D, 
 /* dst[row_of[j], 0:c_dst] = src[j, 0:c_src] (zero padded to c_dst); rows with row_of<0 skipped */
 int fd_rows_permute(const float *src, int c_src, const int32_t *row_of, const int32_t *n_dev, int64_t n_max,
                     void *dst, int c_dst, int dst_bf16, fd_stream_t stream);
-/* nbr [K, nbr_stride] int32.  fill_tail != 0: rows o >= n_out (device count) are filled with -1 up to nbr_stride;
- * fill_tail == 0: rows >= n_out are left untouched (capacity-sized tables whose consumers are given the same device count) */
+/* nbr [K, nbr_stride] int32; out_coords holds out_rows (<= nbr_stride) rows, the kernel works on min(out_rows, *n_out_dev).
+ * fill_tail != 0: rows o >= that count are filled with -1 up to nbr_stride;
+ * fill_tail == 0: rows >= the count are left untouched (capacity-sized tables whose consumers are given the same device count) */
 int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int Din, int Hin, int Win,
-                const int32_t *out_coords, const int32_t *n_out_dev, int64_t nbr_stride, int fill_tail, const int *ksize3,
+                const int32_t *out_coords, int64_t out_rows, const int32_t *n_out_dev, int64_t nbr_stride, int fill_tail, const int *ksize3,
                 const int *stride3, const int *pad3, int32_t *nbr, fd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------

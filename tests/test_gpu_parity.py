@@ -1174,14 +1174,45 @@ def _bf16_example(cfg, cloud):
     return v, c, n, ex
 
 
+# Achieved end-to-end deviation of the bf16 pipeline from the bf16 oracle, round 3 on MI355X (profiles/round3_parity_report.txt):
+# (mean, fraction of active elements beyond 2e-2) per map.  The gates are 2 x these per configuration (the flat
+# 3e-2 / 30 % of round 3 would not have noticed a 2 x regression), with floors for the maps whose achieved figure is ~0.
+_BF16_ACHIEVED = {
+    "30k n3": dict(backbone=(1.8e-3, 1.14e-2), neck=(2.94e-3, 1.68e-2), reg=(4.65e-3, 3.15e-2), height=(1.97e-3, 1.1e-3), dim=(6e-5, 0.0), rot=(3.7e-3, 2.35e-2),
+                   vel=(3.67e-3, 1.87e-2), hm=(2.77e-3, 2.08e-2)),
+    "full size config 3": dict(backbone=(4.17e-3, 3.24e-2), neck=(7.77e-3, 6.62e-2), reg=(1.224e-2, 0.123), height=(3.55e-3, 4.2e-3), dim=(3.2e-4, 0.0),
+                               rot=(9.52e-3, 8.58e-2), vel=(8.74e-3, 7.4e-2), hm=(9.09e-3, 8.84e-2)),
+    "config 4 sample 3": dict(backbone=(4.18e-3, 3.24e-2), neck=(7.91e-3, 6.87e-2), reg=(1.244e-2, 0.127), height=(3.55e-3, 4.9e-3), dim=(3.4e-4, 0.0),
+                              rot=(9.89e-3, 9.33e-2), vel=(8.87e-3, 7.64e-2), hm=(9.12e-3, 9.03e-2)),
+    "full size config 5": dict(backbone=(4.25e-3, 3.39e-2), neck=(6.99e-3, 5.84e-2), reg=(1.082e-2, 0.107), height=(3.34e-3, 4.9e-3), dim=(2.7e-4, 0.0),
+                               rot=(8.73e-3, 7.88e-2), vel=(7.96e-3, 6.54e-2), hm=(8.17e-3, 8.05e-2)),
+    "street scene": dict(backbone=(6.28e-3, 6.78e-2), neck=(7.64e-3, 8.86e-2), reg=(1.205e-2, 0.155), height=(3.39e-3, 7.1e-3), dim=(2.7e-4, 0.0),
+                         rot=(1.054e-2, 0.132), vel=(9.33e-3, 0.108), hm=(1.46e-3, 9.4e-3)),
+}
+
+
+def _bf16_gate(tag, kind):
+    """(mean, fraction) gates = 2 x the achieved figures of this configuration, floors 1e-3 / 5e-3; unknown tags: the worst
+    configuration's figures."""
+    for key, d in _BF16_ACHIEVED.items():
+        if tag.startswith(key):
+            m, f = d[kind]
+            break
+    else:
+        m = max(d[kind][0] for d in _BF16_ACHIEVED.values())
+        f = max(d[kind][1] for d in _BF16_ACHIEVED.values())
+    return max(2.0 * m, 1e-3), max(2.0 * f, 5e-3)
+
+
 def _check_bf16(tag, cfg, net, onet, cloud, got, min_rows=20):
     """The HIP bf16 path end to end against the oracle's bf16 configuration (oracle/bf16.py: weights and per-layer activations
     rounded to bf16, fp32 accumulate) on one cloud.  Element-wise equality to a tolerance cannot be asked of ~45 chained bf16
     layers: the two implementations sum in different orders, so a pre-rounding value near a rounding boundary rounds differently
     (one ulp, 2^-8 relative), and downstream layers amplify such flips (measured: 1 ulp after stage 1, 5e-2 after stage 2,
     0.3 on a few elements of the 128-channel stage, 0.8 on single elements of the neck output).  What IS asserted here: the
-    DISTRIBUTION of the deviation (mean <= 3e-2, 70 % of the active elements within 2e-2 * max(1, |ref|); achieved: mean 2e-3 .. 1.2e-2,
-    88-99 %, growing with the size of the cloud) for the backbone BEV, the neck output and every head map, and that the detections
+    DISTRIBUTION of the deviation (mean and the fraction of active elements beyond 2e-2 * max(1, |ref|), each gated at 2 x the
+    figure this configuration achieved in round 3, _BF16_ACHIEVED: mean 2e-3 .. 1.2e-2, fraction 1 .. 15 %, growing with the size
+    of the cloud) for the backbone BEV, the neck output and every head map, and that the detections
     agree except for attributed near-threshold decisions.  The element-wise bound (one ulp) is asserted per LAYER with identical
     inputs in test_bf16_every_layer_teacher_forced; the decode on identical maps in test_bf16_decode_on_identical_maps.
     The distance to the fp32 oracle is reported (it measures bf16 itself)."""
@@ -1198,21 +1229,22 @@ def _check_bf16(tag, cfg, net, onet, cloud, got, min_rows=20):
     with torch.no_grad():
         preds = net.bbox_head(x)
 
-    def dist(name, g, r):
+    def dist(name, kind, g, r):
         g, r = np.asarray(g, np.float64), np.asarray(r, np.float64)
         d = np.abs(g - r) / np.maximum(1.0, np.abs(r))
         act = (g != 0) | (r != 0)  # (the BEV map is mostly empty cells, identical zeros on both sides)
         d = d[act] if act.any() else d.reshape(-1)
         mean, frac, mx = float(d.mean()), float((d > 2e-2).mean()), float(d.max())
-        report(tag + " bf16 %s: mean" % name, mean, 3e-2, "(frac > 2e-2: %.2e, max %.3f, active elements %d)" % (frac, mx, d.size))
-        assert mean <= 3e-2 and frac <= 0.3, (name, mean, frac, mx)
+        gm, gf = _bf16_gate(tag, kind)
+        report(tag + " bf16 %s: mean" % name, mean, gm, "(frac > 2e-2: %.2e of gate %.2e, max %.3f, active elements %d)" % (frac, gf, mx, d.size))
+        assert mean <= gm and frac <= gf, (name, mean, gm, frac, gf, mx)
 
-    dist("backbone BEV vs bf16 oracle", bb.float().cpu().numpy(), obb.numpy())
-    dist("neck output vs bf16 oracle", x.float().cpu().numpy(), obev.numpy())
+    dist("backbone BEV vs bf16 oracle", "backbone", bb.float().cpu().numpy(), obb.numpy())
+    dist("neck output vs bf16 oracle", "neck", x.float().cpu().numpy(), obev.numpy())
     for ti, (pg, po) in enumerate(zip(preds, opreds)):
         for k in po:
             if k != "feats":
-                dist("head task %d %s vs bf16 oracle" % (ti, k), pg[k].float().cpu().numpy(), po[k].numpy())
+                dist("head task %d %s vs bf16 oracle" % (ti, k), k, pg[k].float().cpu().numpy(), po[k].numpy())
     scale = float(fbev.abs().max())
     report(tag + " bf16 neck output vs FP32 oracle (max, of scale; reported, not gated)", float((x.float().cpu() - fbev).abs().max()) / scale, 1.0)
     return _attribute_bf16_detections(tag, cfg, _rows(got), _rows(odet[0]), opreds, preds, min_rows)
@@ -1233,6 +1265,10 @@ def _attribute_bf16_detections(tag, cfg, g, w, opreds, dpreds, min_rows=20):
     dense = len(opreds) > 1
     cat = dict(found=0, score=0, pre_cut=0, nms=0, post_cut=0, unexplained=0)
     cache = {}
+    margins = []  # how far above the oracle's own pre-max cut the detections lost to the device's cut were
+    lost_cells = set()  # (task, cell) of the detections not found: the standard head shares ONE heat-map and one box per cell between its
+                        # 7 time steps, so a single cell that falls out of the device's top-1000 costs 7 detections -- which is why the
+                        # saturated configurations lose multiples of 7 (round 3: 21 = 3 cells x 7 steps on configs 3 and 5)
     for row in w:
         lab = int(row[10])
         cand = g[g[:, 10] == lab]
@@ -1250,15 +1286,21 @@ def _attribute_bf16_detections(tag, cfg, g, w, opreds, dpreds, min_rows=20):
             so = torch.sigmoid(po["hm"][0].float()).max(0).values
             sd = torch.sigmoid(dpreds[ti]["hm"][0].float().cpu()).max(0).values
             kth = float(torch.topk(sd.flatten(), pre_max).values[-1]) if int((sd > thr).sum()) > pre_max else None
-            cache[ti] = (cx.numpy().ravel(), cy.numpy().ravel(), so.numpy().ravel(), sd.numpy().ravel(), kth)
-        cx, cy, so, sd, kth = cache[ti]
+            ko = float(torch.topk(so.flatten(), pre_max).values[-1]) if int((so > thr).sum()) > pre_max else None
+            cache[ti] = (cx.numpy().ravel(), cy.numpy().ravel(), so.numpy().ravel(), sd.numpy().ravel(), kth, ko)
+        cx, cy, so, sd, kth, ko = cache[ti]
         cell = int(np.argmin(np.abs(cx - row[0]) + np.abs(cy - row[1]) + 10.0 * np.abs(so - row[9])))
         assert abs(cx[cell] - row[0]) < 1e-3 and abs(cy[cell] - row[1]) < 1e-3, "oracle detection not found among its own cells"
-        s_dev = float(sd[cell])
-        if s_dev <= thr + 1.5e-2:
+        lost_cells.add((ti, cell))
+        s_dev, s_ora = float(sd[cell]), float(so[cell])
+        # A score / pre-max decision may differ only by as much as the two pipelines' scores differ AT THIS CELL (measured, not a flat
+        # slack): the oracle had the cell above the bar by (s_ora - bar); the device has it below iff its score moved down by more.
+        dev_move = abs(s_dev - s_ora) + 1e-6
+        if s_dev <= thr and s_ora - thr <= dev_move:
             cat["score"] += 1
-        elif kth is not None and s_dev <= kth + 1.5e-2:
+        elif kth is not None and s_dev <= kth and (ko is None or (s_ora - ko) <= dev_move + abs(kth - ko)):
             cat["pre_cut"] += 1
+            margins.append((s_ora - ko) if ko is not None else 0.0)
         elif len(cand) and float(oops.boxes_iou_bev(nms_layout(row[None, :9]), nms_layout(cand[:, :9])).max()) > iou_thr - 6e-2:
             cat["nms"] += 1
         elif len(cand) >= post_max and float(cand[:, 9].min()) >= s_dev - 1.5e-2:
@@ -1266,9 +1308,12 @@ def _attribute_bf16_detections(tag, cfg, g, w, opreds, dpreds, min_rows=20):
         else:
             cat["unexplained"] += 1
     report(tag + " bf16 detections vs bf16 oracle: not found", float(len(w) - cat["found"]), float(len(w)),
-           "(of %d: score %d, pre-max cut %d, NMS %d, post-max cut %d, unexplained %d)" % (len(w), cat["score"], cat["pre_cut"], cat["nms"], cat["post_cut"], cat["unexplained"]))
+           "(of %d: score %d, pre-max cut %d, NMS %d, post-max cut %d, unexplained %d; %d distinct cells; pre-max losses sat %.1e .. %.1e above the oracle's cut)"
+           % (len(w), cat["score"], cat["pre_cut"], cat["nms"], cat["post_cut"], cat["unexplained"], len(lost_cells), min(margins) if margins else 0.0,
+              max(margins) if margins else 0.0))
     assert cat["unexplained"] == 0, cat
-    assert cat["found"] >= 0.8 * len(w), cat
+    # (a scene with a handful of detections: ONE attributed cell is 7 rows of 21 -- the share rule applies beyond one cell)
+    assert cat["found"] >= 0.8 * len(w) or len(lost_cells) <= 1, (cat, len(lost_cells))
     return cat
 
 
@@ -2069,25 +2114,29 @@ def test_static_step_high_water_mark_capacities_and_overflow(hip):
         step.warm_up([small])
         got = [t.clone() for t in step([small])]
         torch.cuda.synchronize()
-        free = StaticStep(net, vg, capacity=90112)  # data-free capacities, for the comparison of sizes
+        free = StaticStep(net, vg, capacity=90112, row_caps="datafree")  # data-free capacities, for the comparison of sizes
         free.expected = step.expected
         free.capture()
         assert free.caps is None and step.caps is not None and step.caps[1] < 0.2 * 8 * 160000, step.caps
         assert not step.overflowed()
         want_small = net.forward_points([small], vg)
         assert same(want_small, got)
-        step([big])
+        got_big = [t.clone() for t in step([big])]  # (default: checked -- detected and re-run on the eager path)
         torch.cuda.synchronize()
         assert step.overflowed(), (step.level_counts.cpu().tolist(), step.caps)
         want_big = net.forward_points([big], vg)
+        assert same(want_big, got_big), "step(clouds) must return the eager result when the replay overflowed"
         assert same(want_big, step.run_checked([big]))
+        raw = step([big], check=False)  # the unchecked replay: wrong rows, which is why the caller has to look at overflowed()
+        torch.cuda.synchronize()
+        assert step.overflowed() and raw is step.outputs
         again = step([small])
         torch.cuda.synchronize()
         assert not step.overflowed() and same(want_small, again), "an overflowing sweep must not damage the captured step"
         # fp32, 8 clouds per sweep
         clouds = [_dev(synthetic_cloud(seed=30 + i, target_points=12000 + 1500 * i)) for i in range(8)]
         with pytest.raises(NotImplementedError):
-            s8 = StaticStep(net, vg, capacity=24576, batch_size=8)
+            s8 = StaticStep(net, vg, capacity=24576, batch_size=8, row_caps="datafree")
             s8.warm_up(clouds)
             s8.capture()
         s8 = StaticStep(net, vg, capacity=24576, batch_size=8, row_caps="auto")

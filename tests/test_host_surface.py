@@ -184,7 +184,7 @@ def test_c_abi_exports_every_declared_symbol():
     nm = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (fd_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
-    assert L.fd_abi_version() == 4
+    assert L.fd_abi_version() == 5
     assert L.fd_index_num_cols(2, 180, 180) == 2 * 23 * 23 * 64
     assert L.fd_voxelize_workspace_bytes(1000, 100) > 0 and L.fd_nms_workspace_bytes(1000) >= 1000 * 16 * 8
 
@@ -378,3 +378,85 @@ def test_build_lock_and_cpu_pinning_helpers():
         finally:
             os.sched_setaffinity(0, before)
             torch.set_num_threads(max(1, min(len(before), 64)))
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` without a launcher starts its own ranks (bench.self_launch); with fewer devices than ranks it must
+    refuse with a message instead of running one rank and printing n_gpus = 1 (VERDICT r3 #3).  No GPU here: 0 devices < 2."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FD_BENCH_ONE_DEVICE")}
+    if __import__("torch").cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than two devices")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "device(s) are visible" in out.stderr and "n_gpus" not in out.stdout
+
+
+def test_bench_all_cores_probe_child_process():
+    """cpu_baseline's all-core figure is measured by a child process with a wall-clock bound; the child mode prints one line."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--cpu-all-cores-probe", "--points", "4000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("ALLCORES")]
+    assert len(lines) == 1 and float(lines[0].split()[1]) > 0
+
+
+def test_load_checkpoint_follows_the_reference_contract(tmp_path):
+    """det3d/torchie/trainer/checkpoint.py:122-173 (VERDICT r3 #7): a {"state_dict": {"module.<reference key>": tensor}} file -- what the
+    reference's DDP training run saves -- loads into the detector with the wrapper prefix stripped; a bare OrderedDict loads too;
+    a missing file is an IOError, a dict without "state_dict" a RuntimeError, remote names are refused with the reason."""
+    import collections
+
+    from futuredet_amd import build_detector
+    from futuredet_amd.configs import centerpoint_config
+    from futuredet_amd.detectors import load_checkpoint
+    from futuredet_amd.synth import seeded_state_dict
+
+    cfg = centerpoint_config("forecast_n3", "car")
+    src = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    sd = seeded_state_dict(src, 11)
+    src.load_state_dict(sd, strict=False)
+    full = src.state_dict()
+    # reference key names (scn.py / rpn.py / center_head.py module layout)
+    for k, shape in (("backbone.conv_input.0.weight", (3, 3, 3, 5, 16)), ("backbone.conv1.0.conv1.bias", (16,)), ("backbone.conv4.0.weight", (3, 3, 3, 64, 128)),
+                     ("neck.blocks.0.1.weight", (128, 256, 3, 3)), ("bbox_head.shared_conv.0.weight", (64, 512, 3, 3)),
+                     ("bbox_head.tasks.0.hm.0.weight", (64, 64, 3, 3))):
+        assert k in full and tuple(full[k].shape) == shape, (k, tuple(full[k].shape) if k in full else None)
+    wrapped = {"meta": {"epoch": 20}, "state_dict": collections.OrderedDict(("module." + k, v.clone()) for k, v in full.items())}
+    f1 = str(tmp_path / "epoch_20.pth")
+    torch.save(wrapped, f1)
+    dst = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    ck = load_checkpoint(dst, f1, map_location="cpu", strict=True)
+    assert ck["meta"]["epoch"] == 20
+    got = dst.state_dict()
+    assert set(got) == set(full) and all(torch.equal(got[k], full[k]) for k in full)
+
+    f2 = str(tmp_path / "bare.pth")
+    torch.save(collections.OrderedDict(full), f2)
+    dst2 = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    load_checkpoint(dst2, f2)
+    assert all(torch.equal(dst2.state_dict()[k], full[k]) for k in full)
+
+    class Wrapper(torch.nn.Module):  # what DataParallel / DDP look like to load_checkpoint: the model sits in .module
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+
+    dst3 = Wrapper(build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg))
+    load_checkpoint(dst3, f1)
+    assert torch.equal(dst3.module.state_dict()["neck.blocks.0.1.weight"], full["neck.blocks.0.1.weight"])
+
+    with pytest.raises(IOError):
+        load_checkpoint(dst, str(tmp_path / "nope.pth"))
+    f3 = str(tmp_path / "junk.pth")
+    torch.save({"weights": 1}, f3)
+    with pytest.raises(RuntimeError):
+        load_checkpoint(dst, f3)
+    with pytest.raises(NotImplementedError):
+        load_checkpoint(dst, "torchvision://resnet50")
+    # the constructor's pretrained= path goes through the same function (single_stage.py:29-36)
+    net = build_detector(dict(cfg.model, pretrained=f1), train_cfg=None, test_cfg=cfg.test_cfg)
+    assert torch.equal(net.state_dict()["bbox_head.tasks.0.hm.0.weight"], full["bbox_head.tasks.0.hm.0.weight"])

@@ -1,6 +1,7 @@
 """fd_spconv_apply on the real rulebooks of one synthetic cloud: native fp32 kernel vs the split-operand (3 x bf16) kernel per
 level, with the split kernel's row-group variants.  usage: python tools/split_bench.py [--levels 1,2,3] [--rg 0,1,2] [--iters 20]
-Also times the strided convolutions between levels (32->64, 64->128) and the 3x1x1 extra convolution."""
+Also times the strided convolutions between levels (32->64, 64->128) and the 3x1x1 extra convolution.  Leaving parts of the kernel out (what
+does a part cost): tools/probes/build_split_exp.sh <mask>... then FD_LIB_PATH=tools/probes/libfd_split_exp<mask>.so python tools/split_bench.py"""
 import argparse
 import os
 import sys
@@ -18,7 +19,6 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--points", type=int, default=300000)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--strided", type=int, default=1)
-ap.add_argument("--exp", default="0", help="experiment bit masks (timing only): 1 no gathers, 2 no MFMAs, 4 no split, 8 no barrier, 16 no W ring traffic")
 args = ap.parse_args()
 dev = torch.device("cuda")
 pts = torch.from_numpy(synthetic_cloud(args.seed, args.points)).to(dev)
@@ -59,17 +59,13 @@ def case(tag, src, dst, ks, st, pd, cin, cout, residual):
     resp = hip_ops.rows_to_planes(res) if residual else None
     print("%s %3d->%3d n_out=%6d pairs=%7d (%.1f/row, fill %.2f) native fp32      : %7.1f us  %6.1f TFLOP/s" %
           (tag, cin, cout, dst.n, pairs, pairs / max(dst.n, 1), pairs / max(K * dst.n, 1), us_n, 2.0 * pairs * cin * cout / us_n / 1e6), flush=True)
-    for rg, ex in [(int(v), int(e)) for v in args.rg.split(",") for e in args.exp.split(",")]:
+    for rg in [int(v) for v in args.rg.split(",")]:
         hip_ops.set_tuning("split_rg", rg)
-        hip_ops.set_tuning("split_exp", ex)
-        if ex:
-            tag = tag[:-6] + " exp%2d" % ex
         us_s, y_s = timed(lambda: hip_ops.spconv_apply(xp, ws, bias, nbr, dst.n, cout, residual=resp, relu=True, mode="p2p"), args.iters)
         d = float((hip_ops.planes_to_rows(y_s) - y_n).abs().max() / y_n.abs().max().clamp_min(1.0))
         print("%s %3d->%3d                                                   split rg=%d        : %7.1f us  %6.1f TFLOP/s  (x%.2f)  max|d| vs native %.2e" %
               (tag, cin, cout, rg, us_s, 2.0 * pairs * cin * cout / us_s / 1e6, us_n / us_s, d), flush=True)
     hip_ops.set_tuning("split_rg", 0)
-    hip_ops.set_tuning("split_exp", 0)
 
 
 C = [16, 32, 64, 128]
