@@ -134,9 +134,11 @@ class SpMiddleResNetFHD(nn.Module):
             ix.finalize(int(host[i]))
         return idx
 
-    def run_fused(self, idx, feats0, dense_out=None):
+    def run_fused(self, idx, feats0, dense_out=None, fork=False):
         """feats0: [n0, 16] features already in index order (channel padded).  Returns (dense BEV, per-level
-        (features, index))."""
+        (features, index)).  ``fork``: the rulebooks (and work-range tables) of levels 1-4 only need the indexes, not the features:
+        they are built on a side stream while the first level's convolutions run (inside a captured sweep this forks the graph;
+        a sweep's latency loses ~0.1 ms of front-end kernels that used to sit between the convolutions)."""
         dt = self.compute_dtype
         stages = self._stages()
         rb_cache = {}
@@ -166,11 +168,39 @@ class SpMiddleResNetFHD(nn.Module):
                                          dict(s=s, K=K, cin=cin_p, cout=cout_p, n_in=src.n, n_out=dst.n, pairs=pairs, mode=mode), fn)
             return fn()
 
+        main, side = None, None
+        if fork and feats0.is_cuda:
+            main = torch.cuda.current_stream(feats0.device)
+            pool = self.__dict__.setdefault("_side_streams", {})
+            side = pool.get(main.cuda_stream)
+            if side is None:  # one side stream per launch stream: sweeps in flight on different streams fork independently
+                side = pool[main.cuda_stream] = torch.cuda.Stream(device=feats0.device)
+            side.wait_stream(main)  # the indexes are complete
+            with torch.cuda.stream(side):
+                made = []
+                for lvl, (conv, bn, blocks, is_subm_in) in enumerate(stages):
+                    if lvl == 0:
+                        continue
+                    src_l, dst_l = (idx[lvl] if is_subm_in else idx[lvl - 1]), idx[lvl]
+                    made.append(rulebook(src_l, dst_l, conv))
+                    for blk in blocks:
+                        nbr = rulebook(dst_l, dst_l, blk.conv1)
+                        made.append(nbr)
+                        cp = spconv.pad_channels(blk.conv1.out_channels)
+                        if dt == torch.float32 and self.fp32_arith != "split" and nbr.shape[0] == 27 and \
+                                hip_ops._lib.load().fd_spconv_wants_balanced_ranges(cp, cp, 0):
+                            r = hip_ops.ranges_for(nbr, cp, cp)  # cached on the rulebook tensor; spconv_apply finds it there
+                            if r[0] is not None:
+                                made.append(r[0])
+                for t in made:  # allocated on the side stream, consumed by kernels of the main stream
+                    t.record_stream(main)
         x = feats0
         levels = {}
         for lvl, (conv, bn, blocks, is_subm_in) in enumerate(stages):
             src = idx[lvl] if is_subm_in else idx[lvl - 1]
             dst = idx[lvl]
+            if lvl == 1 and side is not None:
+                main.wait_stream(side)  # join: the first level's convolutions are issued, the other levels' rulebooks are needed now
             # a level lives in planes when its block convolutions are split-operand layers; the last level feeds fd_densify (float32)
             planes = split_on and bool(blocks) and spconv.pad_channels(conv.out_channels) >= max(32, self.split_min_channels)
             x = run(conv, bn, x, src, dst, relu=True, out_planes=planes)

@@ -219,119 +219,6 @@ __global__ void __launch_bounds__(256) spconv_bf16(const unsigned short *__restr
     }
 }
 
-// ------------------------------------------------------------------------------------------------- bf16, column split
-// The register kernel above is bound by vector-memory issue: every wave re-reads all of W[k] (up to 32 KB) per tap for
-// only 16-32 rows.  Here the four waves of a workgroup share 64 output rows and split the output columns, so a wave
-// loads only its COUT/4 column slice of W[k] (prefetched one tap ahead), and the 64 gathered input rows of a tap are
-// fetched once per workgroup (wave w gathers row group w with bounds-checked buffer loads, one tap ahead) and passed
-// to the other waves through a double-buffered LDS image laid out in MFMA A-fragment order (linear, conflict-free).
-// 3x fewer vector-memory instructions and 4x less L2->L1 weight traffic than the register kernel at 128 channels.
-template <int CIN, int COUT>
-__global__ void __launch_bounds__(256) spconv_bf16_cs(const unsigned short *__restrict__ in, const void *__restrict__ wp_,
-                                                      const float *__restrict__ bias, const unsigned short *__restrict__ residual,
-                                                      int relu, const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
-                                                      const int *__restrict__ n_out_dev, unsigned short *__restrict__ out, unsigned in_bytes) {
-    constexpr int RG = 4, ROWS = 64;
-    constexpr int NC = CIN / 32, NB = COUT / 16, NBW = NB / 4;
-    static_assert(CIN % 32 == 0 && COUT % 64 == 0, "column split needs CIN % 32 == 0 and COUT % 64 == 0");
-    __shared__ int s_nbr[kMaxTaps * ROWS];
-    __shared__ uint4 s_a[2][RG * NC * 64];
-    __shared__ int s_any[2][RG];
-    const int row0 = blockIdx.x * ROWS;
-    n_out = fd::device_count(n_out, n_out_dev);
-    if (row0 >= n_out) return;
-    for (int t = threadIdx.x; t < K * ROWS; t += 256) {
-        int k = t / ROWS, r = t - k * ROWS;
-        int64_t o = (int64_t)row0 + r;
-        s_nbr[t] = (o < n_out) ? nbr[(int64_t)k * nbr_stride + o] : -1;  // rows >= n_out of the table are never read
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lrow = lane & 15, lq = lane >> 4;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(in), 0, (int)in_bytes, 0x00020000);
-    const bf16x8 *wbase = reinterpret_cast<const bf16x8 *>(wp_) + (wave * NBW) * 64 + lane;
-
-    f32x4 acc[RG][NBW];
-#pragma unroll
-    for (int g = 0; g < RG; ++g)
-#pragma unroll
-        for (int nw = 0; nw < NBW; ++nw) acc[g][nw] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    uint4 a_st[NC];
-    int idx_st;
-    bf16x8 b[NC][NBW], bn[NC][NBW];
-    auto gather = [&](int k) {
-        idx_st = s_nbr[k * ROWS + wave * 16 + lrow];
-        // -1 * (CIN * 2) wraps to just below 2^32: out of range for the buffer, the hardware returns zeros
-        const unsigned voff = (unsigned)idx_st * (unsigned)(CIN * 2) + (unsigned)(lq * 16);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + c * 64, 0, 0);
-            a_st[c] = __builtin_bit_cast(uint4, v);
-        }
-    };
-    auto load_b = [&](int k, bf16x8(&dst)[NC][NBW]) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int nw = 0; nw < NBW; ++nw) dst[c][nw] = wbase[(((int64_t)k * NC + c) * NB + nw) * 64];
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) s_a[buf][(wave * NC + c) * 64 + lane] = a_st[c];
-        const bool any = __ballot(idx_st >= 0) != 0ull;
-        if (lane == 0) s_any[buf][wave] = any;
-    };
-    gather(0);
-    load_b(0, b);
-    stage(0);
-    __syncthreads();
-    for (int k = 0; k < K; ++k) {
-        const int buf = k & 1;
-        if (k + 1 < K) {  // next tap's rows and weight slice fly during this tap's MFMAs
-            gather(k + 1);
-            load_b(k + 1, bn);
-        }
-#pragma unroll
-        for (int g = 0; g < RG; ++g) {
-            if (s_any[buf][g]) {  // workgroup-uniform: no row of this group has the tap
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const bf16x8 af = __builtin_bit_cast(bf16x8, s_a[buf][(g * NC + c) * 64 + lane]);
-#pragma unroll
-                    for (int nw = 0; nw < NBW; ++nw) acc[g][nw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b[c][nw], acc[g][nw], 0, 0, 0);
-                }
-            }
-        }
-        if (k + 1 < K) {
-            stage(buf ^ 1);
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int nw = 0; nw < NBW; ++nw) b[c][nw] = bn[c][nw];
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int g = 0; g < RG; ++g) {
-#pragma unroll
-        for (int nw = 0; nw < NBW; ++nw) {
-            const int col = (wave * NBW + nw) * 16 + lrow;
-            const float bv = bias ? bias[col] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + g * 16 + lq * 4 + r;
-                if (row < n_out) {
-                    float v = acc[g][nw][r] + bv;
-                    if (residual) v += bf2f(residual[(int64_t)row * COUT + col]);
-                    if (relu) v = fmaxf(v, 0.0f);
-                    out[(int64_t)row * COUT + col] = f2bf(v);
-                }
-            }
-        }
-    }
-}
-
 struct LaunchArgs {
     const void *in, *wp;
     const float *bias;
@@ -531,23 +418,8 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
             return FD_EINVAL;
         }
     }
-    if (dtype == 1 && cin >= 32 && cout >= 64 && !fd::tuning(fd::kTuneSpconvBf16V1) && n_in * cin * 2 < (1ll << 31)) {
-        // bf16, wide layers: column-split workgroups (shared gather through LDS, per-wave weight slices)
-        const unsigned in_bytes = (unsigned)(n_in * cin * 2);
-        const dim3 grid((unsigned)((n_out + 63) / 64));
-        hipStream_t st = fd::as_stream(stream);
-#define FD_CS(CI, CO)                                                                                                                    \
-    if (cin == CI && cout == CO) {                                                                                                       \
-        hipLaunchKernelGGL((spconv_bf16_cs<CI, CO>), grid, dim3(256), 0, st, (const unsigned short *)in_feats, wpacked, bias,             \
-                           (const unsigned short *)residual, relu, nbr, nbr_stride, K, (int)n_out, n_out_dev, (unsigned short *)out_feats, in_bytes); \
-        return fd::check_launch("fd_spconv_apply(bf16 column split)");                                                                   \
-    }
-        FD_CS(32, 64)
-        FD_CS(64, 64)
-        FD_CS(64, 128)
-        FD_CS(128, 128)
-#undef FD_CS
-    }
+    // what is left below: the register-resident output-stationary kernels of round 1 -- the path for feature matrices of 2 GB and
+    // more (the kernels above address rows through 32-bit buffer offsets) and the A/B partner of the variant tests
     LaunchArgs a{in_feats, wpacked, bias, residual, relu, nbr, nbr_stride, K, (int)n_out, n_out_dev, out_feats, fd::as_stream(stream)};
     const int rg = pick_rg(n_expected, cin, cout);
     const int key = cin * 1000 + cout;

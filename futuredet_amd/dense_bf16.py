@@ -110,7 +110,7 @@ class RPNPlan(object):
     def __init__(self, rpn, dtype=torch.bfloat16):
         self.dtype = dtype
         self.blocks = [_convs_from_stack(b._modules.values(), dtype) for b in rpn.blocks]
-        self.start = rpn._upsample_start_idx
+        self.start = rpn.first_up
         self.deblocks = []
         for d in rpn.deblocks:
             mods = list(d._modules.values())

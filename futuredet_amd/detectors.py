@@ -14,6 +14,7 @@ from . import hip_ops, registry, sparse
 from .nn_utils import weights_version
 from .registry import DETECTORS
 
+_FORK = os.environ.get("FD_FORK", "0") == "1"  # A/B switch: rulebooks of levels 1-4 on a side stream inside a captured sweep
 _NO_GRAPH = bool(os.environ.get("FD_NO_GRAPH"))  # debugging: run neck + head eagerly
 
 
@@ -245,12 +246,12 @@ class VoxelNet(SingleStageDetector):
         if graph is not None:
             # neck + head have static shapes: replay them as one hipGraph (one launch instead of ~25-60)
             g, static_bev, preds = graph
-            bb.run_fused(idx, feats0, dense_out=static_bev)
+            bb.run_fused(idx, feats0, dense_out=static_bev, fork=static and _FORK)
             mark_stage("sparse_backbone")
             g.replay()
             mark_stage("rpn+head(graph)")
         else:
-            x, _ = bb.run_fused(idx, feats0)
+            x, _ = bb.run_fused(idx, feats0, fork=static and _FORK)
             mark_stage("sparse_backbone")
             x = self.neck(x)
             mark_stage("rpn")

@@ -25,37 +25,33 @@ class RPN(nn.Module):
     def __init__(self, layer_nums, ds_layer_strides, ds_num_filters, us_layer_strides, us_num_filters,
                  num_input_features, norm_cfg=None, name="rpn", logger=None, **kwargs):
         super().__init__()
-        self._layer_strides = ds_layer_strides
-        self._num_filters = ds_num_filters
-        self._layer_nums = layer_nums
-        self._upsample_strides = us_layer_strides
-        self._num_upsample_filters = us_num_filters
-        self._num_input_features = num_input_features
-        if norm_cfg is None:
-            norm_cfg = dict(type="BN", eps=1e-3, momentum=0.01)
-        self._norm_cfg = norm_cfg
-        assert len(self._layer_strides) == len(self._layer_nums)
-        assert len(self._num_filters) == len(self._layer_nums)
-        assert len(self._num_upsample_filters) == len(self._upsample_strides)
-        self._upsample_start_idx = len(self._layer_nums) - len(self._upsample_strides)
-        must_equal = [self._upsample_strides[i] / np.prod(self._layer_strides[: i + self._upsample_start_idx + 1])
-                      for i in range(len(self._upsample_strides))]
-        for v in must_equal:
-            assert v == must_equal[0]
-        in_filters = [self._num_input_features, *self._num_filters[:-1]]
+        # constructor keywords of det3d/models/necks/rpn.py:24-36; the module layout below (blocks.<i>.<j>, deblocks.<i>.<j>) is what
+        # fixes the state-dict keys of the reference's checkpoints
+        self.stage_strides, self.stage_filters, self.stage_layers = list(ds_layer_strides), list(ds_num_filters), list(layer_nums)
+        self.up_strides, self.up_filters = list(us_layer_strides), list(us_num_filters)
+        self.norm_cfg = norm_cfg if norm_cfg is not None else dict(type="BN", eps=1e-3, momentum=0.01)
+        n_stage, n_up = len(self.stage_layers), len(self.up_strides)
+        if not (len(self.stage_strides) == len(self.stage_filters) == n_stage and len(self.up_filters) == n_up <= n_stage):
+            raise ValueError("RPN: ds_layer_strides / ds_num_filters / layer_nums need one entry per stage, us_* one per up-sampled stage")
+        self.first_up = n_stage - n_up  # stages in front of the first one that has a deblock
+        # every deblock must bring its stage to ONE common resolution (their outputs are concatenated)
+        scales = {float(self.up_strides[j]) / float(np.prod(self.stage_strides[: self.first_up + j + 1])) for j in range(n_up)}
+        if len(scales) > 1:
+            raise ValueError("RPN: the deblocks end at different resolutions %s" % sorted(scales))
         blocks, deblocks = [], []
-        for i, layer_num in enumerate(self._layer_nums):
-            block, num_out = self._make_layer(in_filters[i], self._num_filters[i], layer_num, stride=self._layer_strides[i])
-            blocks.append(block)
-            if i - self._upsample_start_idx >= 0:
-                stride = self._upsample_strides[i - self._upsample_start_idx]
-                cout = self._num_upsample_filters[i - self._upsample_start_idx]
-                if stride > 1:
-                    conv = nn.ConvTranspose2d(num_out, cout, stride, stride=stride, bias=False)
+        cin = num_input_features
+        for i in range(n_stage):
+            blocks.append(self._make_layer(cin, self.stage_filters[i], self.stage_layers[i], stride=self.stage_strides[i]))
+            cin = self.stage_filters[i]
+            j = i - self.first_up
+            if j >= 0:
+                up, cout = self.up_strides[j], self.up_filters[j]
+                if up > 1:  # transposed convolution up, or (stride < 1, the PointPillars neck) a strided convolution down
+                    conv = nn.ConvTranspose2d(cin, cout, up, stride=up, bias=False)
                 else:
-                    stride = int(np.round(1 / stride).astype(np.int64))
-                    conv = nn.Conv2d(num_out, cout, stride, stride=stride, bias=False)
-                deblocks.append(Sequential(conv, build_norm_layer(self._norm_cfg, cout)[1], nn.ReLU()))
+                    down = int(round(1.0 / up))
+                    conv = nn.Conv2d(cin, cout, down, stride=down, bias=False)
+                deblocks.append(Sequential(conv, build_norm_layer(self.norm_cfg, cout)[1], nn.ReLU()))
         self.blocks = nn.ModuleList(blocks)
         self.deblocks = nn.ModuleList(deblocks)
         self.compute_dtype = torch.float32
@@ -68,19 +64,19 @@ class RPN(nn.Module):
 
     @property
     def downsample_factor(self):
-        factor = np.prod(self._layer_strides)
-        if len(self._upsample_strides) > 0:
-            factor /= self._upsample_strides[-1]
+        factor = np.prod(self.stage_strides)
+        if self.up_strides:
+            factor /= self.up_strides[-1]
         return factor
 
     def _make_layer(self, inplanes, planes, num_blocks, stride=1):
         block = Sequential(nn.ZeroPad2d(1), nn.Conv2d(inplanes, planes, 3, stride=stride, bias=False),
-                           build_norm_layer(self._norm_cfg, planes)[1], nn.ReLU())
+                           build_norm_layer(self.norm_cfg, planes)[1], nn.ReLU())
         for _ in range(num_blocks):
             block.add(nn.Conv2d(planes, planes, 3, padding=1, bias=False))
-            block.add(build_norm_layer(self._norm_cfg, planes)[1])
+            block.add(build_norm_layer(self.norm_cfg, planes)[1])
             block.add(nn.ReLU())
-        return block, planes
+        return block
 
     def init_weights(self):
         for m in self.modules():
@@ -91,8 +87,8 @@ class RPN(nn.Module):
         ups = []
         for i in range(len(self.blocks)):
             x = self.blocks[i](x)
-            if i - self._upsample_start_idx >= 0:
-                ups.append(self.deblocks[i - self._upsample_start_idx](x))
+            if i >= self.first_up:
+                ups.append(self.deblocks[i - self.first_up](x))
         if len(ups) > 0:
             x = torch.cat(ups, dim=1)
         return x
@@ -140,7 +136,7 @@ class RPN(nn.Module):
         for i, stack in enumerate(blocks):
             for conv in stack:
                 x = conv(x)
-            j = i - self._upsample_start_idx
+            j = i - self.first_up
             if j >= 0:
                 y = x
                 for conv in deblocks[j][:-1]:
