@@ -16,6 +16,9 @@ int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bi
                                 int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, const int *n_out_dev, int cin, int cout, void *out,
                                 const int *ranges, int n_ranges, int out_planes, hipStream_t stream);
 
+// fd_spconv_bf16w.hip: SubM convolutions with an LDS window of input rows (64 / 128 channels); 1 = launched, 0 = not its case
+int spconv_bf16_win_dispatch(const void *in, const void *wp, const float *bias, const void *residual, int relu, const int *nbr, int64_t nbr_stride, int K,
+                             int64_t n_in_bound, int n_out, const int *n_out_dev, int64_t n_expected, int cin, int cout, void *out, hipStream_t stream);
 int spconv_bf16_ws_dispatch(const void *in, const void *wp, const float *bias, const void *residual, int relu, const int *nbr, int64_t nbr_stride, int K,
                             int64_t n_in_bound, int n_out, const int *n_out_dev, int64_t n_expected, int cin, int cout, void *out, hipStream_t stream);
 
@@ -81,7 +84,7 @@ int device_cu_count();  // compute units of the current device, cached per devic
 bool ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done);
 // Tuning / test knobs (fd_tuning_set; initial values are read ONCE from the FD_* environment variables when the
 // library is loaded).  0 = the built-in heuristic.
-enum TuneKey { kTuneSpconvRG = 0, kTuneSpconvV1, kTuneSpconvBf16V1, kTuneV2Depth, kTuneV2TM, kTuneV2LdsPad, kTuneConvNT, kTuneV2RangesPerCU, kTuneV2Uniform, kTuneV2RowCost, kTuneSpconvC32, kTuneBf16GP, kTuneBf16RG, kTuneBf16Depth, kTuneBf16NW, kTuneSplitRG, kTuneStrict, kTuneCount };
+enum TuneKey { kTuneSpconvRG = 0, kTuneSpconvV1, kTuneSpconvBf16V1, kTuneV2Depth, kTuneV2TM, kTuneV2LdsPad, kTuneConvNT, kTuneV2RangesPerCU, kTuneV2Uniform, kTuneV2RowCost, kTuneSpconvC32, kTuneBf16GP, kTuneBf16RG, kTuneBf16Depth, kTuneBf16NW, kTuneSplitRG, kTuneStrict, kTuneBf16Win, kTuneCount };
 int tuning(TuneKey key);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

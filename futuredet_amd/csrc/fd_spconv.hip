@@ -408,6 +408,13 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
     if (dtype == 1 && fd::tuning(fd::kTuneBf16GP) >= 0) {
         // bf16: register accumulators + LDS-shared weights (fd_spconv_bf16.hip); 16 input channels read the tap-pair weight layout
         const void *w = cin == 16 ? (const void *)((const char *)wpacked + (size_t)K * cin * cout * 2) : wpacked;
+        // SubM convolutions of the wide levels can take the variant that stages the input rows of a tile in an LDS window
+        // (fd_spconv_bf16w.hip).  Opt-in ("bf16_win" = 1): bit-identical results, and measured NO faster -- the phase trace shows
+        // these kernels bound by the LDS weight-fragment traffic of lock-stepped waves, not by the gather
+        if (fd::tuning(fd::kTuneBf16Win) > 0 && fd::tuning(fd::kTuneBf16RG) <= 0 &&
+            fd::spconv_bf16_win_dispatch(in_feats, w, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out, n_out_dev, n_expected, cin, cout, out_feats,
+                                         fd::as_stream(stream)))
+            return fd::check_launch("fd_spconv_apply(bf16 window)");
         if (fd::spconv_bf16_ws_dispatch(in_feats, w, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out, n_out_dev, n_expected, cin, cout, out_feats,
                                         fd::as_stream(stream)))
             return fd::check_launch("fd_spconv_apply(bf16 ws)");

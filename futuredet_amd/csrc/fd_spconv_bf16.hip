@@ -273,15 +273,29 @@ __global__ void __launch_bounds__(NW * 64) spconv_bf16_ws(const unsigned short *
                     issue(a_r[(d + DEPTH - 1) % DEPTH], e_next);
                     fetch_idx(t + DEPTH, e_next);
                     const u32x4 *wsrc = s_w + ((d & 1) * FR) * 64 + lane;
+                    // Weight fragments in batches of up to 8, each batch requested in one go BEFORE its MFMAs and the next batch before
+                    // the current one is multiplied: left to itself hipcc reads two fragments, waits, multiplies, reads the next two --
+                    // an exposed LDS round trip per four MFMAs, with both waves of a SIMD in lock step behind the tap barrier
+                    // (phase trace, tools/win_trace.py: a 64 -> 64 tap took ~2000 cycles for 512 of MFMA).
+                    constexpr int FB = (CIN * COUT >= 128 * 128 && RG >= 2) ? 4 : (FR < 8 ? FR : 8), NBATCH = FR / FB;  // (128 -> 128 with two row groups: 8-fragment double buffers spill)
+                    static_assert(FR % FB == 0, "whole batches");
+                    bf16x8 wfb[2][FB];
 #pragma unroll
-                    for (int c = 0; c < NCU; ++c) {
+                    for (int i = 0; i < FB; ++i) wfb[0][i] = __builtin_bit_cast(bf16x8, wsrc[i * 64]);
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const bf16x8 wf = __builtin_bit_cast(bf16x8, wsrc[(c * NB + nb) * 64]);
+                    for (int bt = 0; bt < NBATCH; ++bt) {
+                        if (bt + 1 < NBATCH) {
+#pragma unroll
+                            for (int i = 0; i < FB; ++i) wfb[(bt + 1) & 1][i] = __builtin_bit_cast(bf16x8, wsrc[((bt + 1) * FB + i) * 64]);
+                        }
+#pragma unroll
+                        for (int i = 0; i < FB; ++i) {
+                            const int f = bt * FB + i, c = f / NB, nb = f - c * NB;
 #pragma unroll
                             for (int g = 0; g < RG; ++g)
-                                acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, a_r[d][g][c]), acc[g][nb], 0, 0, 0);
+                                acc[g][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfb[bt & 1][i], __builtin_bit_cast(bf16x8, a_r[d][g][c]), acc[g][nb], 0, 0, 0);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     __syncthreads();
                 }
@@ -426,7 +440,8 @@ bool launch_ring(const WsArgs &a, int rg, int depth) {
         if (WsKernel<CIN, COUT, 1, 2, 8, true>::rows_per_round(a.K) >= n) rg = 1;
         else if (WsKernel<CIN, COUT, 2, 2, 8, true>::rows_per_round(a.K) >= n) rg = 2;
         else if (kMaxRG >= 3 && WsKernel<CIN, COUT, kMaxRG >= 3 ? 3 : 2, 2, 8, true>::rows_per_round(a.K) >= n) rg = 3;
-        else rg = kMaxRG;
+        else rg = kMaxRG >= 4 ? 3 : kMaxRG;  // two passes either way: three row groups per wave (384-row passes) measured best on
+                                              // 64 -> 64 at 155k rows (68 us; rg 2: 72, rg 4: 79 -- tools/spconv_bench.py, round 4)
     }
     if constexpr (kMaxRG >= 4) {
         if (rg >= 4) return WsKernel<CIN, COUT, 4, 2, 8, true>::launch(a);
