@@ -400,7 +400,7 @@ struct WsKernel {
         if (grid < 1) grid = 1;
         const size_t lds = ws_lds_bytes<CIN, COUT, RG, NW, RING>(a.K);
         hipLaunchKernelGGL((spconv_bf16_ws<CIN, COUT, RG, DEPTH, NW, RING>), dim3((unsigned)grid), dim3(NW * 64), lds, a.stream, (const unsigned short *)a.in, (const u32x4 *)a.wp, a.bias, (const unsigned short *)a.residual, a.relu, a.nbr, a.nbr_stride,
-                           a.K, a.n_out, a.n_out_dev, (unsigned short *)a.out, a.in_bytes, fd::tuning(fd::kTuneBf16NW));
+                           a.K, a.n_out, a.n_out_dev, (unsigned short *)a.out, a.in_bytes, 0);
         return true;
     }
 };
@@ -442,6 +442,11 @@ bool launch_ring(const WsArgs &a, int rg, int depth) {
         else if (kMaxRG >= 3 && WsKernel<CIN, COUT, kMaxRG >= 3 ? 3 : 2, 2, 8, true>::rows_per_round(a.K) >= n) rg = 3;
         else rg = kMaxRG >= 4 ? 3 : kMaxRG;  // two passes either way: three row groups per wave (384-row passes) measured best on
                                               // 64 -> 64 at 155k rows (68 us; rg 2: 72, rg 4: 79 -- tools/spconv_bench.py, round 4)
+    }
+    if (fd::tuning(fd::kTuneBf16NW) == 4) {  // experiment: 4-wave workgroups (two per CU, barriers decoupled), rg row groups per wave
+        if (rg >= 4) return WsKernel<CIN, COUT, 4, 2, 4, true>::launch(a);
+        if (rg >= 3) return WsKernel<CIN, COUT, 3, 2, 4, true>::launch(a);
+        return WsKernel<CIN, COUT, 2, 2, 4, true>::launch(a);
     }
     if constexpr (kMaxRG >= 4) {
         if (rg >= 4) return WsKernel<CIN, COUT, 4, 2, 8, true>::launch(a);
