@@ -392,6 +392,13 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
         fd::set_error("fd_spconv_apply: dtype 4 needs a shape of the pair-compacting fp32 kernel (got %d -> %d)", cin, cout);
         return FD_EINVAL;
     }
+    if (dtype == 0 && !fd::tuning(fd::kTuneSpconvV1) && cin == 16 && fd::tuning(fd::kTuneF32ResRG) >= 0) {
+        // the 16-channel level: resident weights + register accumulators + empty-item skipping (fd_spconv_f32r.hip); "f32_res_rg" = -1
+        // keeps the pair-compacting kernel for A/B runs
+        if (fd::spconv_f32_res16_dispatch((const float *)in_feats, wpacked, bias, (const float *)residual, relu, nbr, nbr_stride, K, n_in, (int)n_out,
+                                          n_out_dev, n_expected, cin, cout, (float *)out_feats, fd::as_stream(stream)))
+            return fd::check_launch("fd_spconv_apply(f32 resident)");
+    }
     if (dtype == 0 && !fd::tuning(fd::kTuneSpconvV1) && has_c32_layout(cin, cout, dtype) && fd::tuning(fd::kTuneSpconvC32) >= 0) {
         // 32-column layers: 32-pair items on the 32x32x2 MFMA (fd_spconv_c32.hip); its weight layout follows the 16x16x4 one
         const void *w32 = (const char *)wpacked + (size_t)K * cin * cout * 4;

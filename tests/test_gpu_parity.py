@@ -178,6 +178,18 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
         assert np.array_equal(y_default, other), "bf16: rows-per-wave / ring-depth variants must agree bit for bit"
     for other in ys[1:]:
         assert np.array_equal(ys[0], other), "row-group variants must agree bit for bit (same fma chain per row)"
+    if dtype == "f32" and cin == 16:
+        # 16 input channels default to the resident-weights kernel (fd_spconv_f32r.hip; one and two row groups per wave agree bit
+        # for bit); the pair-compacting kernel is the other fp32 family for this shape
+        try:
+            hip.set_tuning("f32_res_rg", 2)
+            y_rg2 = run()
+            hip.set_tuning("f32_res_rg", -1)
+            y_compact = run()
+        finally:
+            hip.set_tuning("f32_res_rg", 0)
+        if cout == 16:
+            assert np.array_equal(y_default, y_rg2), "resident fp32 kernel: row-group variants must agree bit for bit"
     if dtype == "f32" and (cin, cout) == (32, 32):
         # 32 -> 32 has two pair-compacting kernels: 32-pair items on the 32x32x2 MFMA (default) and 16-pair items on 16x16x4
         try:
@@ -203,6 +215,8 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
         assert_close("spconv_apply bf16 %d->%d round-2 kernel vs oracle" % (cin, cout), y_old, ref_sorted, tol)
     if dtype == "f32" and (cin, cout) == (32, 32):
         assert_close("spconv_apply f32 32->32 16-pair compacting kernel vs oracle", ys[-1], ref_sorted, tol)
+    if dtype == "f32" and cin == 16:
+        assert_close("spconv_apply f32 %d->%d pair-compacting kernel vs oracle" % (cin, cout), y_compact, ref_sorted, tol)
 
 
 # the four conv geometries of SpMiddleResNetFHD (scn.py:99-143) x channel pairs from 16 to 128

@@ -197,7 +197,11 @@ def test_native_kernel_planes_epilogue_is_the_split_of_its_float32_output(hip, c
     w = (rng.standard_normal((27, cin, cout)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
     wpk = hip.pack_spconv_weight(torch.from_numpy(w)).cuda()
     bias = _dev(rng.standard_normal(cout).astype(np.float32))
-    y = hip.spconv_apply(x, wpk, bias, nbr, dst.n, cout, relu=True)
+    try:
+        hip.set_tuning("f32_res_rg", -1)  # the same kernel on both sides (16 input channels default to the resident-weights kernel,
+        y = hip.spconv_apply(x, wpk, bias, nbr, dst.n, cout, relu=True)  # whose summation order differs from the compacting one's)
+    finally:
+        hip.set_tuning("f32_res_rg", 0)
     yp = hip.spconv_apply(x, wpk, bias, nbr, dst.n, cout, relu=True, mode="f2p")
     assert torch.equal(yp, hip.rows_to_planes(y))
     assert torch.equal(hip.planes_to_rows(yp), y)
