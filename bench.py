@@ -22,7 +22,8 @@ reference's eval loop does), per step in the strong-scaling mode.
 
 Rank 0 prints ONE JSON line.  Every number in it is either measured in this run or carries its provenance:
   value              sweeps/s, clouds resident in HBM when the clock starts -> detections on the host (the bench contract's
-                     definition of `value`)
+                     definition of `value`): the MEDIAN of --reps (5) repetitions of the K-step timed region, each with its own
+                     barrier + synchronize + clock; `repetitions` carries min / median / max and every repetition's ms_per_step
   value_host_to_host the same K steps with every cloud starting in pinned host memory (H2D inside the timed region):
                      SURVEY 8(d)'s "points on host -> boxes on host"
   latency_ms_inflight1  a third leg with ONE pass in flight: a sweep's latency
@@ -30,9 +31,12 @@ Rank 0 prints ONE JSON line.  Every number in it is either measured in this run 
                      what binds (fp32: the matrix pipe; bf16: the L1 gather path, reported in the contract's algorithmic-byte
                      accounting); `hbm_algorithmic` and `mfma` carry both views.  traffic / mfma.busy_pmc / dense are PMC
                      figures looked up from profiles/round3_pmc.json for THIS workload and only when the kernel sources are
-                     the ones they were measured on (else null with the reason in *_source)
-  cpu_baseline       the CPU oracle on 64 threads (median of 20 passes) and on all logical CPUs of this box
-  parity_vs_oracle   the detections a step of the TIMED loop returned for bench cloud 0, matched against that oracle pass
+                     the ones they were measured on (else null with the reason in *_source); hbm_copy_measured_gbs is a 512-MB
+                     device copy timed in this run (next to the 8 TB/s spec figure the fractions use)
+  cpu_baseline       the CPU oracle on 64 threads (median of the passes that fit ~28 s) and, measured by a wall-clock-bounded child
+                     process of this run, on all logical CPUs of the box (value_all_cores, or the bound when a pass does not finish)
+  parity_vs_oracle   the detections a step of the TIMED loop returned for bench cloud 0, matched against that oracle pass (fp32; a bf16
+                     run points at the bf16 tests instead: row-wise 1e-3 matching against the fp32 oracle does not apply to it)
 """
 import argparse
 import json
@@ -121,7 +125,7 @@ def workload_key(args):
     return "%s/%s/%d/b%d" % (args.variant, args.dtype, args.points, args.batch)
 
 
-PMC_PROFILE = "round3_pmc.json"  # tools/pmc_round.sh -> tools/publish_profiles.py; keyed by workload, stamped with commit + source fingerprint
+PMC_PROFILE = "round4_pmc.json"  # tools/pmc_round.sh -> tools/publish_profiles.py; keyed by workload, stamped with commit + source fingerprint
 PROF_EVERY = 100  # instrumented steps of the timed region: the last one and every PROF_EVERY-th before it
 
 

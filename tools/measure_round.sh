@@ -1,8 +1,8 @@
-out=gpurun_out/r2h; mkdir -p $out
-run() { name=$1; shift; timeout 300 python bench.py --no-cpu-baseline "$@" > $out/$name.json 2> $out/$name.err; tail -1 $out/$name.json | python -c "
+out=gpurun_out/${1:-r4h}; mkdir -p $out
+run() { name=$1; shift; timeout 300 python bench.py --no-cpu-baseline --steps 50 --reps 3 "$@" > $out/$name.json 2> $out/$name.err; tail -1 $out/$name.json | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}
-print('$name', d['value'], d['ms_per_step'], d.get('value_host_to_host'), r.get('spconv_ms_per_step'), r.get('frac'), (r.get('mfma') or {}).get('frac'))"; }
+print('$name', d['value'], d['ms_per_step'], 'h2h', d.get('value_host_to_host'), 'lat', d.get('latency_ms_inflight1'), 'spconv', r.get('spconv_ms_per_step'), 'frac', r.get('frac'), 'min/max', (d.get('repetitions') or {}).get('value_min'), (d.get('repetitions') or {}).get('value_max'))"; }
 run default --stage-times
 grep stage $out/default.err | tail -2
 run inflight2 --inflight 2
