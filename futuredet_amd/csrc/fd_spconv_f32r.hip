@@ -198,7 +198,10 @@ namespace fd {
 // 16 input channels, 16 or 32 output channels.  1 = launched, 0 = not this kernel's shape.
 int spconv_f32_res16_dispatch(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr, int64_t nbr_stride, int K,
                               int64_t n_in_bound, int n_out, const int *n_out_dev, int64_t n_expected, int cin, int cout, float *out, hipStream_t stream) {
+    // 16 -> 32 (the strided convolution into level 1: 272k output rows, 2.4 pairs per row) is the pair-compacting kernel's: measured
+    // 63 us here against 44 us there (profiles/round4_serial_step_summary.txt of the first run); "f32_res_rg" >= 32 forces it for A/B runs
     if (cin != 16 || (cout != 16 && cout != 32) || n_in_bound * 64 >= (1ll << 31)) return 0;
+    if (cout == 32 && fd::tuning(fd::kTuneF32ResRG) < 32) return 0;
     const unsigned in_bytes = (unsigned)(n_in_bound * 64);
     const int rg = fd::tuning(fd::kTuneF32ResRG);
     if (cout == 16) {

@@ -182,7 +182,7 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
         # 16 input channels default to the resident-weights kernel (fd_spconv_f32r.hip; one and two row groups per wave agree bit
         # for bit); the pair-compacting kernel is the other fp32 family for this shape
         try:
-            hip.set_tuning("f32_res_rg", 2)
+            hip.set_tuning("f32_res_rg", 2 if cout == 16 else 32)  # (16 -> 32 defaults to the compacting kernel: 32 forces the resident one)
             y_rg2 = run()
             hip.set_tuning("f32_res_rg", -1)
             y_compact = run()
@@ -190,6 +190,8 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
             hip.set_tuning("f32_res_rg", 0)
         if cout == 16:
             assert np.array_equal(y_default, y_rg2), "resident fp32 kernel: row-group variants must agree bit for bit"
+        else:
+            assert_close("spconv_apply f32 16->32 resident kernel vs compacting kernel", y_rg2, y_compact, 1e-4)
     if dtype == "f32" and (cin, cout) == (32, 32):
         # 32 -> 32 has two pair-compacting kernels: 32-pair items on the 32x32x2 MFMA (default) and 16-pair items on 16x16x4
         try:
