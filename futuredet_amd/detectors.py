@@ -423,7 +423,8 @@ class PointPillars(SingleStageDetector):
     def __init__(self, reader, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None):
         super().__init__(reader, backbone, neck, bbox_head, train_cfg, test_cfg, pretrained)
 
-    def set_precision(self, dtype=torch.float32, channels_last=None):
+    def set_precision(self, dtype=torch.float32, channels_last=None, fp32_arith=None):
+        assert fp32_arith in (None, "native"), "PointPillars has no sparse convolution: only the native fp32 arithmetic applies"
         channels_last = bool(channels_last)
         self.reader.compute_dtype = dtype
         self.backbone.dense_channels_last = channels_last or dtype == torch.bfloat16 or getattr(self.neck, "use_hip_conv", False)
