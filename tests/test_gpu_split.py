@@ -228,3 +228,52 @@ def test_full_size_config2_fp32_split_vs_oracle(hip):
         for i in range(2):  # eager + graph replay
             got = net.forward_points([_dev(cloud)], cfg.voxel_generator, padded=False)[0]
             _attribute("full size config 2 SPLIT forward_points run %d" % i, _rows(got), _rows(want), cfg.test_cfg, topk_cut=want["topk_cut"])
+
+
+@pytest.mark.parametrize("cin", [64, 128])
+def test_bf16_window_kernel_is_bit_identical_to_the_default(hip, cin):
+    """The LDS-window variant of the bf16 SubM convolution (fd_spconv_bf16w.hip, opt-in `bf16_win` = 1) must return exactly what the
+    default kernel returns -- same MFMAs in the same order, only the source of the operand rows differs -- on a level whose rows span
+    several workgroup passes, with a residual, and when most neighbours lie OUTSIDE the window (rows shuffled: no locality at all)."""
+    rng = np.random.default_rng(cin)
+    src, x = _sparse_level(hip, rng, 2, 11, 96, 90, 0.25, cin)
+    xb = x.bfloat16()
+    w = (rng.standard_normal((27, cin, cin)) * np.sqrt(2.0 / (27 * cin))).astype(np.float32)
+    wpk = hip.pack_spconv_weight(torch.from_numpy(w), torch.bfloat16).cuda()
+    bias = _dev(rng.standard_normal(cin).astype(np.float32))
+    nbr = src.rulebook(src, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    # a rulebook without locality: every valid entry redirected to a random row (still a legal input row)
+    scr = nbr.clone()
+    perm = torch.randperm(src.n, device="cuda", dtype=torch.int64).int()
+    scr[:, :src.n] = torch.where(nbr[:, :src.n] >= 0, perm[nbr[:, :src.n].clamp_min(0).long()], nbr[:, :src.n])
+    for book in (nbr, scr):
+        y0 = hip.spconv_apply(xb, wpk, bias, book, src.n, cin, residual=xb, relu=True)
+        try:
+            hip.set_tuning("bf16_win", 1)
+            y1 = hip.spconv_apply(xb, wpk, bias, book, src.n, cin, residual=xb, relu=True)
+        finally:
+            hip.set_tuning("bf16_win", 0)
+        assert torch.equal(y0, y1)
+    assert src.n > 30000
+
+
+def test_fp32_resident_kernel_edge_cases(hip):
+    """fd_spconv_f32r.hip (the 16-channel level): a level smaller than one tile, a 3 x 1 x 1 kernel (K = 3), rows without any
+    neighbour but themselves, and an empty level -- each against the pair-compacting kernel."""
+    rng = np.random.default_rng(9)
+    for (B, D, H, W, p, ks, pd) in ((1, 3, 6, 5, 0.2, (3, 3, 3), (1, 1, 1)), (2, 9, 30, 31, 0.01, (3, 3, 3), (1, 1, 1)), (1, 8, 24, 20, 0.3, (3, 1, 1), (1, 0, 0))):
+        src, x = _sparse_level(hip, rng, B, D, H, W, p, 16)
+        K = ks[0] * ks[1] * ks[2]
+        w = rng.standard_normal((K, 16, 16)).astype(np.float32)
+        wpk = hip.pack_spconv_weight(torch.from_numpy(w)).cuda()
+        nbr = src.rulebook(src, ks, (1, 1, 1), pd)
+        y = hip.spconv_apply(x, wpk, None, nbr, src.n, 16, residual=x, relu=False)
+        try:
+            hip.set_tuning("f32_res_rg", -1)
+            y_c = hip.spconv_apply(x, wpk, None, nbr, src.n, 16, residual=x, relu=False)
+        finally:
+            hip.set_tuning("f32_res_rg", 0)
+        assert_close("fp32 resident kernel vs compacting kernel, %d rows, K = %d" % (src.n, K), y.cpu().numpy(), y_c.cpu().numpy(), 1e-5)
+    empty = torch.zeros((0, 16), device="cuda")
+    nbr0 = torch.full((27, 64), -1, dtype=torch.int32, device="cuda")
+    assert hip.spconv_apply(empty, wpk if K == 27 else hip.pack_spconv_weight(torch.zeros((27, 16, 16))).cuda(), None, nbr0, 0, 16).shape == (0, 16)
