@@ -17,6 +17,10 @@
 //     writing interleaved pixels) are expressed without extra passes.
 #include "fd_common.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -26,6 +30,11 @@ constexpr int TH = 8, TW = 16;  // output pixels per workgroup (M = 128)
 
 // tuning builds (tools/probes/build_trace.sh): thread 0 of every workgroup accumulates cycles per phase:
 // [0] prologue (first patch in LDS), [1] step loops, [2] slice hand-over (store + next loads), [3] barrier, [4] epilogue, [5] whole
+// ablation builds (tools/probes/build_exp.sh fd_conv2d <tag> -DFD_CONV_EXP=<mask>; results are wrong on purpose): 1 = no weight
+// fragment loads inside the step loop, 2 = no A-fragment LDS reads inside the step loop, 4 = no MFMAs
+#ifndef FD_CONV_EXP
+#define FD_CONV_EXP 0
+#endif
 #ifdef FD_V2_TRACE
 __device__ unsigned long long *g_ctrace;
 #define FD_CT(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -57,9 +66,13 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
     constexpr int NCHUNK16 = PP * 4;                    // 16-byte chunks per 32-channel patch
     constexpr int NLOAD = (NCHUNK16 + 255) / 256;
     constexpr int NT = WNT * WAVES_N * 32;              // output channels per workgroup
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x PP x 64 bytes
+    constexpr int PIXB = 80;                            // LDS bytes per patch pixel (see store_slice)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x PP x PIXB bytes
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index as a SCALAR: everything derived from it (this wave's channel block, hence the weight-fragment offsets) then
+    // lives in SGPRs.  With `tid >> 6` the compiler keeps it in a VGPR and every fragment load of the step loop costs a 64-bit
+    // VALU add + v_readfirstlane + s_nop 4 -- and a VALU instruction waits for the MFMAs in flight on its SIMD
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef FD_V2_TRACE
     unsigned long long cacc[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -88,14 +101,18 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
             }
         }
     };
+    // LDS patch layout: pixel pitch PIXB = 80 bytes (64 of data + 16 of padding).  20 dwords per pixel: 16 pixels with distinct
+    // (index mod 16) hit 16 distinct 4-dword bank groups (20 p mod 64 = 4 (5 p mod 16)), so the ds_read_b128 fragment reads are
+    // conflict free -- and, unlike the XOR swizzle this replaces, the address is LINEAR in the pixel index: the A fragment of
+    // every (tap, k-half) step is one per-lane base register + an immediate offset, no VALU instruction in the step loop.
     auto store_slice = [&](int buf) {
-        unsigned char *dst = smem + buf * (PP * 64);
+        unsigned char *dst = smem + buf * (PP * PIXB);
 #pragma unroll
         for (int i = 0; i < NLOAD; ++i) {
             const int id = tid + i * 256;
             if (id < NCHUNK16) {
                 const int pix = id >> 2, q = id & 3;
-                *reinterpret_cast<uint4 *>(dst + pix * 64 + ((q ^ ((pix >> 2) & 3)) << 4)) = stage[i];
+                *reinterpret_cast<uint4 *>(dst + pix * PIXB + (q << 4)) = stage[i];
             }
         }
     };
@@ -141,19 +158,10 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
     for (int r = 0; r < RING; ++r)
 #pragma unroll
         for (int j = 0; j < WNT; ++j) bw[r][j] = wfrag(j, r < total_iters ? r : 0);
-    // per-lane LDS offsets of the A fragments of every step (tap, k-half), relative to the slice buffer
-    unsigned aoff[ITERS][WMT];
+    // per-lane LDS base of the A fragments (tap (0, 0), k-half 0) relative to the slice buffer; a step adds a compile-time offset
+    unsigned abase[WMT];
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int tap = it >> 1, ks = it & 1;
-        const int ky = tap / KS, kx = tap % KS;
-#pragma unroll
-        for (int i = 0; i < WMT; ++i) {
-            const int pix = (prow[i] + ky) * PW + pcol[i] + kx;
-            const int q = ks * 2 + lk;
-            aoff[it][i] = (unsigned)(pix * 64 + ((q ^ ((pix >> 2) & 3)) << 4));
-        }
-    }
+    for (int i = 0; i < WMT; ++i) abase[i] = (unsigned)((prow[i] * PW + pcol[i]) * PIXB + lk * 16);
     if (nslices > 1) load_slice(1);  // registers hold slice s+1 while slice s is computed
     FD_CT(c_pro);
     FD_CADD(0, c_pro - c_start);
@@ -165,10 +173,14 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
         // of a step (fences): an MFMA occupies the pipe for 32 cycles but issues in 4, what is issued in its shadow is free; lumped
         // after the step's MFMAs the same instructions cost ~100 cycles per 128-cycle step (tools/conv_bf16_trace.py: 4870 cycles
         // per slice for 2304 of MFMA before).
-        const unsigned sbase = (unsigned)((s & 1) * (PP * 64));
-        auto read_a = [&](int it, bf16x8(&a)[WMT]) {
+        unsigned ab[WMT];
 #pragma unroll
-            for (int i = 0; i < WMT; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + sbase + aoff[it][i]);
+        for (int i = 0; i < WMT; ++i) ab[i] = abase[i] + (unsigned)((s & 1) * (PP * PIXB));
+        auto read_a = [&](int it, bf16x8(&a)[WMT]) {
+            const int tap = it >> 1, ks = it & 1;
+            const unsigned imm = (unsigned)(((tap / KS) * PW + tap % KS) * PIXB + ks * 32);  // compile-time: the ds_read offset field
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + ab[i] + imm);
         };
         bf16x8 a[3][WMT];  // ring of three: the fragments of step it + 2 are requested in the middle of step it (1.5 steps = 190 cycles of lead)
         read_a(0, a[0]);
@@ -182,10 +194,15 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
             for (int j = 0; j < WNT; ++j) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < WMT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it % 3][i], bw[slot][j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < WMT; ++i) {
+                    if constexpr (FD_CONV_EXP & 4) asm volatile("" : "+v"(acc[i][j]) : "v"(a[it % 3][i]), "v"(bw[slot][j]));
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it % 3][i], bw[slot][j], acc[i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                if (j == 0 && it + 2 < ITERS) read_a(it + 2, a[(it + 2) % 3]);
-                bw[slot][j] = wfrag(j, nsel);  // the slot just consumed takes the fragment of RING steps ahead
+                if constexpr (!(FD_CONV_EXP & 2)) {
+                    if (j == 0 && it + 2 < ITERS) read_a(it + 2, a[(it + 2) % 3]);
+                }
+                if constexpr (!(FD_CONV_EXP & 1)) bw[slot][j] = wfrag(j, nsel);  // the slot just consumed takes the fragment of RING steps ahead
             }
         }
         // Patch loads go at the END of a slice: vector-memory loads return in order, so a patch load issued at the top
@@ -283,13 +300,367 @@ template <int KS, int S, int WMT, int WNT, int WAVES_M, int WAVES_N>
 void launch_conv(const void *x, const void *wp, const float *bias, void *y, const ConvParams &p, hipStream_t stream) {
     constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
     constexpr int NT = WNT * WAVES_N * 32;
-    size_t lds = 2 * (size_t)PH * PW * 64;
+    size_t lds = 2 * (size_t)PH * PW * 80;
     if (lds < (size_t)TH * TW * NT * 2) lds = (size_t)TH * TW * NT * 2;  // the epilogue transposes the tile through LDS
     auto kern = conv2d_nhwc_bf16<KS, S, WMT, WNT, WAVES_M, WAVES_N>;
     static std::atomic<uint64_t> lds_set{0};
     if (lds > 65536) (void)fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_set);
     dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)(p.Cout_pad / NT));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const unsigned short *)x, (const bf16x8 *)wp, bias, (unsigned short *)y, p);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------ strip kernel
+// Stride-1 convolutions on STRIPS: a workgroup takes M = 128 CONSECUTIVE pixels of the row-major pixel order of one image
+// instead of an 8 x 16 tile.  180 x 180 is 23 x 12 = 276 tiles for 256 compute units -- 20 units carry two workgroups and the
+// layer waits for them (tools: 242 workgroups 15.5 us, 276 workgroups 20.0 us) -- but 254 strips with 0.3 % padding: one
+// workgroup per unit, one round.  A strip touches at most three image rows; the input patch is, per patch row, the hull of the
+// columns its pixels need, rows packed one after the other in LDS (80-byte pixel pitch as above).  Because every A-fragment
+// address is a per-lane base (one per kernel row ky: the patch rows have different origins) + a compile-time offset, an
+// arbitrary pixel -> patch mapping costs nothing in the step loop; the loop itself, the weight ring and the arithmetic order
+// are those of the tile kernel (bit-identical results).
+struct StripParams {
+    int spi;      // strips per image
+    int max_pix;  // patch pixels of the largest strip: the slice buffers are max_pix * 80 bytes apart
+};
+
+template <int KS, int WMT, int WNT, int WAVES_M, int WAVES_N, int NLOAD>
+__global__ void __launch_bounds__(256) conv2d_strip_bf16(const unsigned short *__restrict__ x, const bf16x8 *__restrict__ wp,
+                                                         const float *__restrict__ bias, unsigned short *__restrict__ y, ConvParams p, StripParams sp) {
+    constexpr int M = WMT * WAVES_M * 32;
+    static_assert(WAVES_M * WAVES_N == 4 && M == 128, "strip shape");
+    constexpr int NT = WNT * WAVES_N * 32;
+    constexpr int PIXB = 80;
+    constexpr int RS_MAX = 3, PH_MAX = RS_MAX + KS - 1;  // image rows a strip may touch (host: Wo >= 64), patch rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x max_pix x PIXB bytes
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef FD_V2_TRACE
+    unsigned long long cacc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    FD_CT(c_start);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int b = blockIdx.x / sp.spi, sidx = blockIdx.x - b * sp.spi;
+    const int n0 = blockIdx.y * NT + wn * WNT * 32;
+    const int nslices = p.Cin / 32;
+    const int Wo = p.Wo, HW = p.Ho * p.Wo;
+    // strip geometry (all wave-uniform)
+    const int p0 = sidx * M;
+    const int nvalid = HW - p0 < M ? HW - p0 : M;
+    const int y0 = p0 / Wo, x0 = p0 - y0 * Wo;
+    const int y1 = (p0 + nvalid - 1) / Wo, x1 = p0 + nvalid - 1 - y1 * Wo;
+    int lo[PH_MAX], rowpix[PH_MAX + 1];  // patch row r = input row y0 - pad + r holds patch columns lo[r] .. (column c = input column c - pad)
+    rowpix[0] = 0;
+#pragma unroll
+    for (int r = 0; r < PH_MAX; ++r) {
+        int l = 1 << 30, h = -1;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int yy = y0 + r - ky;  // the output row that reads patch row r with kernel row ky
+            if (yy >= y0 && yy <= y1) {
+                const int xa = yy == y0 ? x0 : 0, xb = yy == y1 ? x1 : Wo - 1;
+                l = xa < l ? xa : l;
+                h = xb + KS - 1 > h ? xb + KS - 1 : h;
+            }
+        }
+        lo[r] = h >= 0 ? l : 0;
+        rowpix[r + 1] = rowpix[r] + (h >= 0 ? h - l + 1 : 0);
+    }
+    const int total_chunks = rowpix[PH_MAX] * 4;
+    auto row_origin = [&](int r, int &lo_r, int &rp_r) {  // (per-lane r)
+        lo_r = lo[0]; rp_r = 0;
+#pragma unroll
+        for (int rr = 1; rr < PH_MAX; ++rr)
+            if (r >= rr) { lo_r = lo[rr]; rp_r = rowpix[rr]; }
+    };
+    // patch chunks of this thread: chunk id = 4 * (LDS pixel index) + 16-byte quarter; global byte offset inside the image (slice 0)
+    // or a value past the buffer (-> zeros: padding pixels), LDS byte offset or ~0 (no chunk)
+    unsigned goff[NLOAD], loff[NLOAD];
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+        const int id = tid + i * 256;
+        int r = 0;
+#pragma unroll
+        for (int rr = 1; rr < PH_MAX; ++rr) r += id >= rowpix[rr] * 4 ? 1 : 0;
+        int lo_r, rp_r;
+        row_origin(r, lo_r, rp_r);
+        const int o = id - rp_r * 4, q = o & 3;
+        const int iy = y0 - p.pad + r, ix = lo_r + (o >> 2) - p.pad;
+        const bool have = id < total_chunks;
+        const bool inb = have && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        goff[i] = inb ? (unsigned)(((iy * p.W + ix) * p.Cin + q * 8) * 2) : 0x80000000u;
+        loff[i] = have ? (unsigned)((id >> 2) * PIXB + (q << 4)) : ~0u;
+    }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(x) + (int64_t)b * p.H * p.W * p.Cin, 0,
+                                                                          p.H * p.W * p.Cin * 2, 0x00020000);
+    const unsigned buf_bytes = (unsigned)sp.max_pix * PIXB;
+    uint4 stage[NLOAD];
+    auto load_slice = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i) stage[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[i], s * 64, 0));
+    };
+    auto store_slice = [&](int buf) {
+        unsigned char *dst = smem + buf * buf_bytes;
+#pragma unroll
+        for (int i = 0; i < NLOAD; ++i)
+            if (loff[i] != ~0u) *reinterpret_cast<uint4 *>(dst + loff[i]) = stage[i];
+    };
+
+    f32x16 acc[WMT][WNT];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // A-fragment bases: lane -> pixel lm of each of its WMT M-tiles (pixels past the strip's end read the last pixel's window),
+    // one base per kernel row
+    const int lm = lane & 31, lk = lane >> 5;
+    unsigned abase[WMT][KS];
+#pragma unroll
+    for (int i = 0; i < WMT; ++i) {
+        int m = (wm * WMT + i) * 32 + lm;
+        m = m < nvalid ? m : nvalid - 1;
+        const int xx = x0 + m;
+        const int dy = (xx >= Wo ? 1 : 0) + (xx >= 2 * Wo ? 1 : 0);
+        const int xc = xx - dy * Wo;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            int lo_r, rp_r;
+            row_origin(dy + ky, lo_r, rp_r);
+            abase[i][ky] = (unsigned)((rp_r + xc - lo_r) * PIXB + lk * 16);
+        }
+    }
+    const int64_t w_nt_stride = (int64_t)nslices * KS * KS * 2 * 64;
+
+    load_slice(0);
+    constexpr int ITERS = KS * KS * 2;
+    constexpr int RING = (ITERS % 6 == 0) ? 6 : 2;
+    const int total_iters = nslices * ITERS;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(wp), 0, (int)p.w_bytes, 0x00020000);
+    const unsigned lane16 = lane * 16;
+    auto wfrag = [&](int j, int it) {
+        const int soff = __builtin_amdgcn_readfirstlane((int)((((n0 >> 5) + j) * w_nt_stride + (int64_t)it * 64) * 16));
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, soff, 0));
+    };
+    // the weight ring is requested BEHIND the first patch slice (loads return in order) and before its LDS stores wait for it:
+    // the two round trips overlap
+    bf16x8 bw[RING][WNT];
+#pragma unroll
+    for (int r = 0; r < RING; ++r)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) bw[r][j] = wfrag(j, r < total_iters ? r : 0);
+    store_slice(0);
+    __syncthreads();
+    if (nslices > 1) load_slice(1);
+    FD_CT(c_pro);
+    FD_CADD(0, c_pro - c_start);
+    for (int s = 0; s < nslices; ++s) {
+        FD_CT(c0);
+        unsigned ab[WMT][KS];
+#pragma unroll
+        for (int i = 0; i < WMT; ++i)
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) ab[i][ky] = abase[i][ky] + (unsigned)(s & 1) * buf_bytes;
+        auto read_a = [&](int it, bf16x8(&a)[WMT]) {
+            const int tap = it >> 1, ks = it & 1;
+            const unsigned imm = (unsigned)((tap % KS) * PIXB + ks * 32);  // compile-time: the ds_read offset field
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + ab[i][tap / KS] + imm);
+        };
+        bf16x8 a[3][WMT];
+        read_a(0, a[0]);
+        if (ITERS > 1) read_a(1, a[1]);
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int slot = it % RING;
+            const int nxt = s * ITERS + it + RING;
+            const int nsel = nxt < total_iters ? nxt : 0;
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < WMT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[it % 3][i], bw[slot][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0 && it + 2 < ITERS) read_a(it + 2, a[(it + 2) % 3]);
+                bw[slot][j] = wfrag(j, nsel);
+            }
+        }
+        FD_CT(c1);
+        if (s + 1 < nslices) store_slice((s + 1) & 1);
+        if (s + 2 < nslices) load_slice(s + 2);
+        FD_CT(c2);
+        __syncthreads();
+        FD_CT(c3);
+        FD_CADD(1, c1 - c0); FD_CADD(2, c2 - c1); FD_CADD(3, c3 - c2);
+    }
+    FD_CT(c_epi);
+    // epilogue: as in the tile kernel; pixel m of the strip is pixel p0 + m of the image
+    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
+    auto out_pixel = [&](int m, int &oy, int &ox) {
+        const int xx = x0 + m;
+        const int dy = (xx >= Wo ? 1 : 0) + (xx >= 2 * Wo ? 1 : 0);
+        oy = y0 + dy;
+        ox = xx - dy * Wo;
+    };
+    const bool wide = ((p.cout_total | p.co_off) & 7) == 0 && (p.Cout_real & 7) == 0;
+    if (wide) {
+        unsigned short *s_out = reinterpret_cast<unsigned short *>(smem);  // [128 pixels][NT channels] bf16
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bool odd = lm & 1;
+        const unsigned sel = odd ? 0x03020706u : 0x05040100u;
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+            const int cl = (wn * WNT + j) * 32 + lm;
+            const int co = blockIdx.y * NT + cl;
+            const float bv = (bias && co < p.Cout_real) ? bias[co] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) {
+                unsigned char *dst = reinterpret_cast<unsigned char *>(s_out) + ((((wm * WMT + i) * 32 + (odd ? 1 : 0) + 4 * lk) * NT + (cl & ~1)) << 1);
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2_t v = {acc[i][j][r] + bv, acc[i][j][r + 1] + bv};
+                    if (p.relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); }
+                    const unsigned mine = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xf, 0xf, true);
+                    const unsigned packed = __builtin_amdgcn_perm(nb, mine, sel);
+                    *reinterpret_cast<unsigned *>(dst + ((((r & 3) + 8 * (r >> 2)) * NT) << 1)) = packed;
+                }
+            }
+        }
+        __syncthreads();
+        FD_CT(c_mid);
+        constexpr int C8 = NT / 8;
+        for (int id = tid; id < M * C8; id += 256) {
+            const int m = id / C8, c8 = id - m * C8;
+            const int co = blockIdx.y * NT + c8 * 8;
+            if (m < nvalid && co < p.Cout_real) {
+                int oy, ox;
+                out_pixel(m, oy, ox);
+                const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
+                *reinterpret_cast<uint4 *>(y + (((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co) =
+                    *reinterpret_cast<const uint4 *>(s_out + m * NT + c8 * 8);
+            }
+        }
+#ifdef FD_V2_TRACE
+        if (tid == 0 && g_ctrace) {
+            const unsigned long long c_end = __builtin_readcyclecounter();
+            unsigned long long *o = g_ctrace + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+            o[0] = cacc[0]; o[1] = cacc[1]; o[2] = cacc[2]; o[3] = cacc[3]; o[4] = c_end - c_epi; o[5] = c_end - c_start; o[6] = c_mid - c_epi; o[7] = c_end;
+        }
+#endif
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+        const int co = n0 + j * 32 + lm;
+        const float bv = (bias && co < p.Cout_real) ? bias[co] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * WMT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (m < nvalid && co < p.Cout_real) {
+                    int oy, ox;
+                    out_pixel(m, oy, ox);
+                    float v = acc[i][j][r] + bv;
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
+                    y[(((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co] = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
+// patch pixels of the largest strip of an H x W image (the host side of the kernel's hull computation)
+template <int KS>
+int strip_max_pix(int Ho, int Wo) {
+    constexpr int M = 128;
+    const int HW = Ho * Wo;
+    int best = 0;
+    for (int p0 = 0; p0 < HW; p0 += M) {
+        const int nvalid = HW - p0 < M ? HW - p0 : M;
+        const int y0 = p0 / Wo, x0 = p0 - y0 * Wo, y1 = (p0 + nvalid - 1) / Wo, x1 = p0 + nvalid - 1 - y1 * Wo;
+        int pix = 0;
+        for (int r = 0; r < y1 - y0 + KS; ++r) {
+            int l = 1 << 30, h = -1;
+            for (int ky = 0; ky < KS; ++ky) {
+                const int yy = y0 + r - ky;
+                if (yy >= y0 && yy <= y1) {
+                    const int xa = yy == y0 ? x0 : 0, xb = yy == y1 ? x1 : Wo - 1;
+                    l = xa < l ? xa : l;
+                    h = xb + KS - 1 > h ? xb + KS - 1 : h;
+                }
+            }
+            if (h >= 0) pix += h - l + 1;
+        }
+        best = pix > best ? pix : best;
+    }
+    return best;
+}
+
+template <int KS, int WMT, int WNT, int WAVES_M, int WAVES_N, int NLOAD>
+void launch_strip(const void *x, const void *wp, const float *bias, void *y, const ConvParams &p, const StripParams &sp, hipStream_t stream) {
+    constexpr int NT = WNT * WAVES_N * 32;
+    size_t lds = 2 * (size_t)sp.max_pix * 80;
+    if (lds < (size_t)128 * NT * 2) lds = (size_t)128 * NT * 2;
+    auto kern = conv2d_strip_bf16<KS, WMT, WNT, WAVES_M, WAVES_N, NLOAD>;
+    static std::atomic<uint64_t> lds_set{0};
+    if (lds > 65536) (void)fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_set);
+    dim3 grid((unsigned)(sp.spi * p.B), (unsigned)(p.Cout_pad / NT));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const unsigned short *)x, (const bf16x8 *)wp, bias, (unsigned short *)y, p, sp);
+}
+
+// stride-1 layers: the strip kernel when the image is wide enough for its three-row patch, the patch fits and the chunk table
+// has a variant; channel block = the widest that still gives every compute unit a workgroup.  Returns 0 -> the tile kernel.
+//
+// OPT-IN (fd_tuning_set("conv_strip", 1)): measured on MI355X (profiles/round4_bf16_dense_strips.txt) a layer alone is 15-20 %
+// faster on strips when they make it one round of workgroups (128 -> 128 at 180 x 180 20.3 -> 17.1 us, 256 -> 256 at 90 x 90
+// 22.6 -> 18.1) and a sweep's latency drops 1.5 % (config 3: 1.80 -> 1.77 ms) -- but with four sweeps in flight, which is what
+// the throughput figure measures, the strips' 80-116 KB of LDS per workgroup (a tile: 29 KB) keep the other sweeps' kernels off
+// the compute unit: config 3 800 -> 771 sweeps/s, config 5 (270 x 270: several rounds either way, bigger patch) 463 -> 443.
+template <int KS>
+int dispatch_strip(const void *x, const void *wp, const float *bias, void *y, const ConvParams &p, hipStream_t stream) {
+    if (fd::tuning(fd::kTuneConvStrip) <= 0 || p.Wo < 64 || p.Ho != p.H || p.Wo != p.W) return 0;
+    if ((int64_t)p.H * p.W * p.Cin * 2 >= (1ll << 31)) return 0;  // (the patch loads address one image through a 2 GB buffer window)
+    StripParams sp;
+    sp.spi = (p.Ho * p.Wo + 127) / 128;
+    // (the hull walk is O(strips) on the host; cache per shape)
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, int> cache;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find({p.Ho, p.Wo});
+        if (it == cache.end()) it = cache.emplace(std::make_pair(p.Ho, p.Wo), strip_max_pix<KS>(p.Ho, p.Wo)).first;
+        sp.max_pix = it->second;
+    }
+    const int need = (sp.max_pix * 4 + 255) / 256;
+    if (need > 12 || 2 * (size_t)sp.max_pix * 80 > 160 * 1024) return 0;
+    const int force = fd::tuning(fd::kTuneConvNT);
+    const int n_cu = fd::device_cu_count();
+    const int64_t strips = (int64_t)sp.spi * p.B;
+    int nt = 32;
+    if (p.Cout_pad % 64 == 0) nt = 64;
+    if (p.Cout_pad % 128 == 0 && (strips * (p.Cout_pad / 128) * 4 >= 3 * n_cu || p.Cout_pad % 64 != 0)) nt = 128;
+    if (nt == 64 && strips * (p.Cout_pad / 64) * 4 < 3 * n_cu) nt = 32;
+    // a layer of one or two slices that is several rounds of workgroups anyway is prologue-bound: the strip's patch (hull of up
+    // to three full-width rows) costs more to fetch than a tile's (64 -> 384 at 180 x 180: 26.4 us on tiles, 28.5 on strips)
+    if (p.Cin < 128 && strips * (p.Cout_pad / nt) > 2 * n_cu && force == 0) return 0;
+    if (force == 128 && p.Cout_pad % 128 == 0) nt = 128;
+    if (force == 64 && p.Cout_pad % 64 == 0) nt = 64;
+    if (force == 32) nt = 32;
+#define FD_STRIP(NL)                                                                                    \
+    if (nt == 128) launch_strip<KS, 2, 2, 2, 2, NL>(x, wp, bias, y, p, sp, stream);                     \
+    else if (nt == 64) launch_strip<KS, 1, 2, 4, 1, NL>(x, wp, bias, y, p, sp, stream);                 \
+    else launch_strip<KS, 1, 1, 4, 1, NL>(x, wp, bias, y, p, sp, stream);
+    if (need <= 4) { FD_STRIP(4) }
+    else if (need <= 8) { FD_STRIP(8) }
+    else { FD_STRIP(12) }
+#undef FD_STRIP
+    return 1;
 }
 
 template <int KS, int S>
@@ -364,8 +735,12 @@ extern "C" int fd_conv2d_nhwc_bf16(const void *x, int B, int H, int W, int cin, 
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
     hipStream_t s = fd::as_stream(stream);
-    if (ks == 3 && stride == 1) dispatch_nt<3, 1>(x, wpacked, bias, y, p, s);
-    else if (ks == 3) dispatch_nt<3, 2>(x, wpacked, bias, y, p, s);
-    else dispatch_nt<1, 1>(x, wpacked, bias, y, p, s);
+    if (ks == 3 && stride == 1) {
+        if (!dispatch_strip<3>(x, wpacked, bias, y, p, s)) dispatch_nt<3, 1>(x, wpacked, bias, y, p, s);
+    } else if (ks == 3) {
+        dispatch_nt<3, 2>(x, wpacked, bias, y, p, s);
+    } else if (!dispatch_strip<1>(x, wpacked, bias, y, p, s)) {
+        dispatch_nt<1, 1>(x, wpacked, bias, y, p, s);
+    }
     return fd::check_launch("fd_conv2d_nhwc_bf16");
 }

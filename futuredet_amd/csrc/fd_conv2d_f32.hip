@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_f32(const float *__restrict__
     constexpr int TAPS = KS * KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 x PP x PIXB bytes
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what derives from it stays in SGPRs
     const int lm = lane & 15, lq = lane >> 4;
     int t = blockIdx.x;
     const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -262,7 +262,7 @@ inline double tile_cost(int Ho, int Wo, int B, int cout, const TileChoice &c, in
 template <int NPB, int NCB>
 __global__ void __launch_bounds__(256) conv1x1_f32(const float *__restrict__ x, const float4 *__restrict__ wp, const float *__restrict__ bias,
                                                    float *__restrict__ y, ConvParamsF p) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what derives from it stays in SGPRs
     const int lm = lane & 15, lq = lane >> 4;
     const int64_t n_px = (int64_t)p.B * p.Ho * p.Wo;
     const int64_t px0 = (int64_t)blockIdx.x * (16 * NPB);

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256, (TY * TX * NBW <= 16) ? FD_WINO_OCC16 : (
 
     FD_WDECL;
     FD_WT(tstart);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what derives from it stays in SGPRs
     const int lm = lane & 15, lq = lane >> 4;
     int t = blockIdx.x;
     const int tx = t % p.tiles_x; t /= p.tiles_x;

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) spconv_f32(const float *__restrict__ in, 
         s_nbr[t] = (o < n_out) ? nbr[(int64_t)k * nbr_stride + o] : -1;  // rows >= n_out of the table are never read
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lrow = lane & 15, lq = lane >> 4;
     const int wrow = wave * 16 * RG;
     if (row0 + wrow >= n_out) return;
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) spconv_bf16(const unsigned short *__restr
         s_nbr[t] = (o < n_out) ? nbr[(int64_t)k * nbr_stride + o] : -1;  // rows >= n_out of the table are never read
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lrow = lane & 15, lq = lane >> 4;
     const int wrow = wave * 16 * RG;
     if (row0 + wrow >= n_out) return;

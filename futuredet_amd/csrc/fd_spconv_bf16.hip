@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(NW * 64) spconv_bf16_ws(const unsigned short *
     constexpr int kSliceInts = (kMaxTaps + 1) * ROWS;                             // one slice buffer (whole 64-entry DMA instructions)
     constexpr int kWaveInts = 2 * kSliceInts + ROWS;                              // two slice buffers + the 'no neighbour' row
     int *s_nbr = reinterpret_cast<int *>(s_w + (RING ? 2 : T) * FR * 64);        // [NW][kWaveInts], wave-private
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what derives from it stays in SGPRs
     const int lrow = lane & 15, lq = lane >> 4;
     n_out = fd::device_count(n_out, n_out_dev);  // capacity launch (fd_common.h)
     int *s = s_nbr + wave * kWaveInts;

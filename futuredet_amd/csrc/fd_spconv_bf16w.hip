@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(NW * 64) spconv_bf16_win(const unsigned short 
     constexpr int kSliceInts = (kMaxTaps + 1) * ROWS;
     constexpr int kWaveInts = kSliceInts + ROWS;                                    // one slice buffer + the 'no neighbour' row
     int *s_nbr = reinterpret_cast<int *>(s_win + (WIN + 1) * PIECES);               // [NW][kWaveInts], wave-private
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what derives from it stays in SGPRs
     const int lrow = lane & 15, lq = lane >> 4;
     n_out = fd::device_count(n_out, n_out_dev);
     int *s = s_nbr + wave * kWaveInts;

@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
     float *s_acc = reinterpret_cast<float *>(s_pad + 32);                                  // [TS][TM + 1][COUT]
     static_assert(kMaxItems <= 32, "item list slot");
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what derives from it stays in SGPRs
     if (n_out_dev) n_out = fd::device_count(n_out, n_out_dev);
     int r_begin, r_end;
     if (ranges) {

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(NW * 64) spconv_p3_ws(const unsigned short *__
                                                                           //  such launches make one or two passes, each waits for its slice)
     constexpr int kWaveInts = kSliceBufs * kSliceInts + ROWS;             // slice buffer(s) + the 'no neighbour' row
     int *s_nbr = reinterpret_cast<int *>(s_w + 3 * FRS * 64);             // [NW][kWaveInts], wave-private
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what derives from it stays in SGPRs
     const int lrow = lane & 31, lh = lane >> 5;
     n_out = fd::device_count(n_out, n_out_dev);
     int *s = s_nbr + wave * kWaveInts;

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     int *s_pad = reinterpret_cast<int *>(s_cnt + 112);                                      // 16 padding entries (tail of the work list)
     float *s_acc = reinterpret_cast<float *>(s_pad + 16);                                   // [TM + 1][COUT], 16-byte aligned for TM = 64 and 128
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what derives from it stays in SGPRs
     // ---- this workgroup's row range, cut into equal chunks of at most TM rows (multiples of 16)
     int r_begin, r_end;
     if (n_out_dev) n_out = fd::device_count(n_out, n_out_dev);  // capacity launch (see fd_common.h)

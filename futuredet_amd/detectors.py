@@ -214,7 +214,7 @@ class VoxelNet(SingleStageDetector):
         mean = torch.empty((B * max_voxels, cpad), dtype=torch.float32, device=dev)
         coors = torch.empty((B * max_voxels, 4), dtype=torch.int32, device=dev)
         npts = torch.empty((B * max_voxels,), dtype=torch.int32, device=dev)
-        nvox = torch.zeros((B,), dtype=torch.int32, device=dev)
+        nvox = torch.empty((B,), dtype=torch.int32, device=dev)  # written by every fd_voxelize call, empty clouds included
         for b, pts in enumerate(clouds):
             sl = slice(b * max_voxels, (b + 1) * max_voxels)
             hip_ops.voxelize(pts, vs, rng, max_points, max_voxels, batch_idx=b, want_voxels=False, want_mean=True,
@@ -231,7 +231,7 @@ class VoxelNet(SingleStageDetector):
         bb = self.backbone
         idx = bb.build_indexes(mark, B, list(grid), dev, voxels=(coors, nvox, max_voxels), static=static, expected=expected, row_caps=row_caps)
         # (static: idx[l].n is the level's capacity; the counts are read by whoever wants them from level_counts, later)
-        self.__dict__["last_level_counts"] = torch.cat([ix.n_dev for ix in idx]) if static else [ix.n for ix in idx]
+        self.__dict__["last_level_counts"] = idx[0].level_counts if static else [ix.n for ix in idx]
         mark_stage("index")
         # every row of the level-0 index is exactly one voxel, and fd_rows_place writes all cpad channels of it: no fill
         feats0 = torch.empty((max(idx[0].n, 1), cpad), dtype=bb.compute_dtype, device=dev)[: idx[0].n]
@@ -469,7 +469,7 @@ class PointPillars(SingleStageDetector):
         voxels = torch.empty((B * max_voxels, max_points, ndim), dtype=torch.float32, device=dev)
         coors = torch.empty((B * max_voxels, 4), dtype=torch.int32, device=dev)
         npts = torch.empty((B * max_voxels,), dtype=torch.int32, device=dev)
-        nvox = torch.zeros((B,), dtype=torch.int32, device=dev)
+        nvox = torch.empty((B,), dtype=torch.int32, device=dev)  # written by every fd_voxelize call, empty clouds included
         grid = np.round((np.array(rng[3:], np.float32) - np.array(rng[:3], np.float32)) / np.array(vs, np.float32)).astype(np.int64)
         canvas = None
         for b, pts in enumerate(clouds):

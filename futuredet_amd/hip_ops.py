@@ -279,6 +279,7 @@ def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device, static=False, ex
         ix.B, ix.D, ix.H, ix.W, ix.ncols, ix.device = plan.B, sh[0], sh[1], sh[2], nc, device
         ix.words, ix.prefix = words_all[off:off + nc], prefix_all[off:off + nc]
         ix.n_dev, ix.n, ix.coords = counts[l:l + 1], None, None
+        ix.level_counts = counts  # all levels' counts in one tensor (n_dev is the slice of this level)
         ix.static, ix.n_expected = False, 0
         lv = levels[l]
         lv.D, lv.H, lv.W = sh

@@ -535,6 +535,55 @@ def test_conv2d_nhwc_bf16_vs_torch(hip, cfg):
     assert bool((out[..., :3] == 7).all()) and bool((out[..., 3 + cout:] == 7).all()), "writes outside the channel window"
 
 
+STRIP_CASES = [(3, 64, 128, 1, 180, 180), (3, 128, 64, 2, 90, 90), (3, 32, 32, 1, 66, 64), (3, 96, 11, 2, 5, 127), (3, 64, 256, 1, 17, 129),
+               (1, 128, 256, 2, 23, 70), (1, 64, 40, 1, 9, 300), (3, 32, 128, 1, 1, 128), (3, 64, 64, 3, 2, 65), (3, 32, 70, 1, 40, 270)]
+
+
+@pytest.mark.parametrize("cfg", STRIP_CASES, ids=lambda c: "k%d_%d-%d_b%d_%dx%d" % c)
+def test_conv2d_bf16_strip_kernel_matches_tile_kernel_and_torch(hip, cfg):
+    """Stride-1 bf16 layers on images at least 64 pixels wide can run on strips of 128 consecutive pixels (one workgroup per compute
+    unit at 180 x 180 instead of 276 tiles for 256 units; opt-in, conv_strip = 1: faster alone, slower with sweeps in flight).  Same
+    summation order as the 8 x 16-tile kernel: the two must agree BIT FOR BIT (conv_strip <= 0 selects the tile kernel) for every channel block width, on shapes whose strips touch one, two
+    and three image rows, end in a partial strip, cross no image boundary in a batch, with a channel-offset output window and
+    the pixel-shuffle placement of the 2 x 2 transposed convolution; and both match torch on the bf16-rounded operands."""
+    ks, cin, cout, B, H, W = cfg
+    rng = np.random.default_rng(cin + cout + H + W)
+    x = torch.from_numpy(rng.standard_normal((B, cin, H, W)).astype(np.float32)).bfloat16()
+    w = torch.from_numpy((rng.standard_normal((cout, cin, ks, ks)) * (2.0 / (cin * ks * ks)) ** 0.5).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    ref = torch.relu(torch.nn.functional.conv2d(x.float(), w.bfloat16().float(), b, padding=1 if ks == 3 else 0))
+    wpk = hip.pack_conv2d_weight(w).cuda()
+    xn = x.cuda().permute(0, 2, 3, 1).contiguous()
+    outs = {}
+    try:
+        for strip in (1, -1):
+            hip.set_tuning("conv_strip", strip)
+            for nt in (0, 64, 32):
+                hip.set_tuning("conv_nt", nt)
+                out = torch.full((B, H, W, cout + 8), 7.0, dtype=torch.bfloat16, device="cuda")
+                hip.conv2d_nhwc_bf16(xn, wpk, b.cuda(), cout, ks, 1, True, out=out, co_off=8 if cout % 8 == 0 else 3)
+                outs[(strip, nt)] = out
+                # pixel-shuffle placement (the transposed convolution's sub-convolutions): output pixel (2 y + 1, 2 x)
+                sh = torch.full((B, 2 * H, 2 * W, cout), 5.0, dtype=torch.bfloat16, device="cuda")
+                hip.conv2d_nhwc_bf16(xn, wpk, b.cuda(), cout, ks, 1, False, out=sh, osy=2, osx=2, ooy=1, oox=0)
+                outs[(strip, nt, "shuffle")] = sh
+    finally:
+        hip.set_tuning("conv_strip", 0)
+        hip.set_tuning("conv_nt", 0)
+    base = outs[(-1, 0)]
+    off = 8 if cout % 8 == 0 else 3
+    got = base[..., off:off + cout].permute(0, 3, 1, 2).float().cpu()
+    assert float((got - ref).abs().max()) <= 1e-2 * max(1.0, float(ref.abs().max()))
+    for key, o in outs.items():
+        ref_o = outs[(-1, key[1], "shuffle")] if len(key) == 3 else outs[(-1, key[1])]
+        assert torch.equal(o, ref_o), "strip kernel differs from the tile kernel: %s" % (key,)
+        if len(key) == 2:
+            assert torch.equal(o, base), "channel block width changes the result: %s" % (key,)
+            assert bool((o[..., :off] == 7).all()) and bool((o[..., off + cout:] == 7).all()), "writes outside the channel window"
+        else:
+            assert bool((o[:, 0::2] == 5).all()) and bool((o[:, 1::2, 1::2] == 5).all()), "writes outside the shuffled pixels"
+
+
 F32_CONV_CASES = [(3, 1, 64, 128, 37, 45, 0), (3, 2, 32, 128, 40, 33, 0), (3, 1, 128, 64, 20, 20, 0), (3, 1, 96, 11, 19, 35, 0),
                   (1, 1, 128, 256, 23, 18, 0), (3, 1, 256, 256, 16, 16, 0), (3, 1, 384, 23, 30, 26, 0)] + \
                  [(3, 1, 48, 70, 29, 31, k) for k in range(1, 17)] + [(3, 2, 16, 130, 33, 27, k) for k in (1, 3, 9, 12, 14)] + \
