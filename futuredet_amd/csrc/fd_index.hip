@@ -30,41 +30,39 @@ struct DownParams {
     int k[3], s[3], p[3];
 };
 
-// one thread per input column
+// one thread per OUTPUT column: out word = z-transform(OR of the k x k input columns of its window).  (The scatter form this
+// replaces -- one thread per input column, an atomicOr per output column it feeds -- took 23 + 18 + 8 + 5 us for the four
+// levels of the backbone: device-scope atomics are served memory-side on this part.  No atomics here, every output column is
+// written exactly once, so the output needs no zero fill.)
 __global__ void __launch_bounds__(256) idx_down(const unsigned long long *__restrict__ in_words, IndexGeom gi, IndexGeom go,
                                                 DownParams dp, unsigned long long *__restrict__ out_words) {
     int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= gi.num_cols()) return;
-    unsigned long long w = in_words[col];
-    if (!w) return;
-    int b, y, x;
-    fd::col_to_byx(gi, col, b, y, x);
-    // z axis: out bit oz set iff some active z and tap kz with z + p - kz = oz * s
+    if (col >= go.num_cols()) return;
+    int b, oy, ox;
+    fd::col_to_byx(go, col, b, oy, ox);
+    unsigned long long acc = 0;
+    if (oy < go.H && ox < go.W) {  // (columns of the 8 x 8 tile padding stay empty)
+        for (int ky = 0; ky < dp.k[1]; ++ky) {
+            const int iy = oy * dp.s[1] - dp.p[1] + ky;
+            if (iy < 0 || iy >= gi.H) continue;
+            for (int kx = 0; kx < dp.k[2]; ++kx) {
+                const int ix = ox * dp.s[2] - dp.p[2] + kx;
+                if (ix < 0 || ix >= gi.W) continue;
+                acc |= in_words[fd::col_of(gi, b, iy, ix)];
+            }
+        }
+    }
+    // z axis: out bit oz set iff some active z = oz * s - p + kz, kz < k
     unsigned long long zo = 0;
-    while (w) {
-        int z = __builtin_ctzll(w);
-        w &= w - 1;
-        for (int kz = 0; kz < dp.k[0]; ++kz) {
-            int t = z + dp.p[0] - kz;
-            if (t < 0 || t % dp.s[0]) continue;
-            int oz = t / dp.s[0];
-            if (oz < go.D) zo |= 1ull << oz;
+    if (acc) {
+        const unsigned long long taps = (1ull << dp.k[0]) - 1ull;
+        for (int oz = 0; oz < go.D; ++oz) {
+            const int lo = oz * dp.s[0] - dp.p[0];
+            const unsigned long long m = lo >= 0 ? (lo < 64 ? taps << lo : 0ull) : taps >> (-lo);
+            if (acc & m) zo |= 1ull << oz;
         }
     }
-    if (!zo) return;
-    for (int ky = 0; ky < dp.k[1]; ++ky) {
-        int ty = y + dp.p[1] - ky;
-        if (ty < 0 || ty % dp.s[1]) continue;
-        int oy = ty / dp.s[1];
-        if (oy >= go.H) continue;
-        for (int kx = 0; kx < dp.k[2]; ++kx) {
-            int tx = x + dp.p[2] - kx;
-            if (tx < 0 || tx % dp.s[2]) continue;
-            int ox = tx / dp.s[2];
-            if (ox >= go.W) continue;
-            atomicOr(&out_words[fd::col_of(go, b, oy, ox)], zo);
-        }
-    }
+    out_words[col] = zo;
 }
 
 __device__ inline int block_excl_scan(int v, int &total, int *sm) {
@@ -207,6 +205,9 @@ __global__ void __launch_bounds__(kScanThreads) idx_scan2_ml(PyramidLevels L, in
     if (threadIdx.x == 0) counts[l] = run;
 }
 
+// COORDS: the levels' coordinate tables exist already (capacity-sized levels of the sync-free step): the thread that computes a
+// column's prefix writes its rows' coordinates too -- no second pass over words + prefix, one launch less
+template <bool COORDS>
 __global__ void __launch_bounds__(kScanThreads) idx_scan3_ml(PyramidLevels L, const int *__restrict__ bsum) {
     __shared__ int sm[4];
     const int l = level_of(L.blk0, L.n, blockIdx.x);
@@ -214,19 +215,33 @@ __global__ void __launch_bounds__(kScanThreads) idx_scan3_ml(PyramidLevels L, co
     int *prefix = L.prefix[l];
     const int64_t ncols = L.geom[l].num_cols();
     int64_t base = (int64_t)(blockIdx.x - L.blk0[l]) * kScanTile + (int64_t)threadIdx.x * kScanItems;
-    int pc[kScanItems];
+    unsigned long long wv[kScanItems];
     int s = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
-        pc[k] = (base + k < ncols) ? __popcll(words[base + k]) : 0;
-        s += pc[k];
+        wv[k] = (base + k < ncols) ? words[base + k] : 0ull;
+        s += __popcll(wv[k]);
     }
     int total;
     int e = block_excl_scan(s, total, sm) + bsum[blockIdx.x];
+    int *coords = COORDS ? L.coords[l] : nullptr;
+    const long long cap = (COORDS && L.coords_rows[l] > 0) ? L.coords_rows[l] : 0x7fffffffll;
+    int b = 0, y0 = 0, x0 = 0;
+    if (COORDS && s) fd::col_to_byx(L.geom[l], base, b, y0, x0);  // (kScanItems = 4 consecutive columns: one row of an 8 x 8 tile)
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         if (base + k < ncols) prefix[base + k] = e;
-        e += pc[k];
+        if (COORDS && coords) {
+            unsigned long long w = wv[k];
+            int row = e;
+            while (w) {
+                const int z = __builtin_ctzll(w);
+                w &= w - 1;
+                if (row < cap) reinterpret_cast<int4 *>(coords)[row] = make_int4(b, z, y0, x0 + k);
+                ++row;
+            }
+        }
+        e += __popcll(wv[k]);
     }
 }
 
@@ -343,6 +358,41 @@ __global__ void __launch_bounds__(256) rows_place(const unsigned long long *__re
     }
 }
 
+// the same with four channels per thread (c_dst % 4 == 0: every caller of the hot path -- 16 padded channels): a quarter of the index
+// lookups, 16-byte (float32) / 8-byte (bf16) stores
+template <bool BF16>
+__global__ void __launch_bounds__(256) rows_place4(const unsigned long long *__restrict__ words, const int *__restrict__ prefix, IndexGeom g,
+                                                   const int *__restrict__ coords, const int *__restrict__ n_dev, int64_t n_max,
+                                                   const float *__restrict__ src, int c_src, void *__restrict__ dst, int c_dst) {
+    const int q4 = c_dst >> 2;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n = n_dev ? (int64_t)n_dev[0] : n_max;
+    if (n > n_max) n = n_max;
+    int64_t i = t / q4;
+    const int ch = (int)(t - i * q4) * 4;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];
+    if (c.x < 0 || c.x >= g.B) return;
+    const int r = lookup_row(words, prefix, g, c.x, c.y, c.z, c.w);
+    if (r < 0) return;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ch + k < c_src ? src[i * c_src + ch + k] : 0.0f;
+    if (BF16) {
+        unsigned short h[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned u = __float_as_uint(v[k]);
+            u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+            h[k] = (unsigned short)(u >> 16);
+        }
+        *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(dst) + (int64_t)r * c_dst + ch) =
+            make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    } else {
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + (int64_t)r * c_dst + ch) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // one thread per (output row, (ky,kx) column pair): fills the kz taps of that column from one word load
 __global__ void __launch_bounds__(256) rulebook_kernel(const unsigned long long *__restrict__ in_words, const int *__restrict__ in_prefix,
                                                        IndexGeom gi, const int *__restrict__ out_coords, const int *__restrict__ n_out_dev,
@@ -422,7 +472,7 @@ extern "C" int fd_index_downsample(const uint64_t *in_words, int B, int D, int H
     for (int i = 0; i < 3; ++i) od[i] = (in[i] + 2 * dp.p[i] - (dp.k[i] - 1) - 1) / dp.s[i] + 1;
     FD_REQUIRE(od[0] > 0 && od[0] <= 64 && od[1] > 0 && od[2] > 0, "fd_index_downsample: bad output grid");
     IndexGeom go = fd::make_geom(B, od[0], od[1], od[2]);
-    int64_t ncols = gi.num_cols();
+    int64_t ncols = go.num_cols();
     hipLaunchKernelGGL(idx_down, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, fd::as_stream(stream),
                        (const unsigned long long *)in_words, gi, go, dp, (unsigned long long *)out_words);
     return fd::check_launch("fd_index_downsample");
@@ -486,6 +536,16 @@ extern "C" int fd_rows_place(const uint64_t *words, const int32_t *prefix, int B
     FD_REQUIRE(c_src > 0 && c_dst >= c_src, "fd_rows_place: c_dst < c_src");
     if (n_max <= 0) return FD_OK;
     IndexGeom g = fd::make_geom(B, D, H, W);
+    if (c_dst % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        dim3 grid4((unsigned)((n_max * (c_dst / 4) + 255) / 256));
+        if (dst_bf16)
+            hipLaunchKernelGGL(rows_place4<true>, grid4, dim3(256), 0, fd::as_stream(stream), (const unsigned long long *)words, prefix, g, coords_in,
+                               n_dev, n_max, src, c_src, dst, c_dst);
+        else
+            hipLaunchKernelGGL(rows_place4<false>, grid4, dim3(256), 0, fd::as_stream(stream), (const unsigned long long *)words, prefix, g, coords_in,
+                               n_dev, n_max, src, c_src, dst, c_dst);
+        return fd::check_launch("fd_rows_place");
+    }
     dim3 grid((unsigned)((n_max * c_dst + 255) / 256));
     if (dst_bf16)
         hipLaunchKernelGGL(rows_place<true>, grid, dim3(256), 0, fd::as_stream(stream), (const unsigned long long *)words, prefix, g, coords_in,
@@ -549,7 +609,12 @@ extern "C" int fd_index_pyramid(const int32_t *coords, const int32_t *n_dev, int
     hipStream_t st = fd::as_stream(stream);
     hipLaunchKernelGGL(idx_scan1_ml, dim3(total_blocks), dim3(kScanThreads), 0, st, L, bsum);
     hipLaunchKernelGGL(idx_scan2_ml, dim3(n_levels), dim3(kScanThreads), 0, st, L, bsum, counts_dev);
-    hipLaunchKernelGGL(idx_scan3_ml, dim3(total_blocks), dim3(kScanThreads), 0, st, L, (const int *)bsum);
+    // every non-empty level brought its coordinate table: write the coordinates in the same pass (fd_index_pyramid_coords is then
+    // not needed); otherwise the caller reads the counts, sizes the tables and calls fd_index_pyramid_coords
+    bool fused = true;
+    for (int l = 0; l < n_levels; ++l) fused = fused && levels[l].coords != nullptr;
+    if (fused) hipLaunchKernelGGL(idx_scan3_ml<true>, dim3(total_blocks), dim3(kScanThreads), 0, st, L, (const int *)bsum);
+    else hipLaunchKernelGGL(idx_scan3_ml<false>, dim3(total_blocks), dim3(kScanThreads), 0, st, L, (const int *)bsum);
     return fd::check_launch("fd_index_pyramid");
 }
 

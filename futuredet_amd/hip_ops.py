@@ -290,8 +290,18 @@ def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device, static=False, ex
         idx.append(ix)
         off += nc
     ws = workspace.get("index_scan", plan.ws_bytes, device)
-    check(L.fd_index_pyramid(_p(coors), _p(nvox), int(n_max), plan.B, len(shapes), levels, _p(counts), _p(ws), ws.numel(), _stream()),
-          "fd_index_pyramid")
+
+    def size_coords(host):
+        total = sum(host)
+        coords_all = torch.empty((max(total, 1), 4), dtype=torch.int32, device=device)
+        o = 0
+        for l, ix in enumerate(idx):
+            ix.n = int(host[l])
+            ix.coords = coords_all[o:o + ix.n]
+            levels[l].coords = (coords_all.data_ptr() + 16 * o) if ix.n else None
+            levels[l].coords_rows = ix.n
+            o += ix.n
+
     if static:
         host = plan.row_caps(int(B) * int(n_max))
         if row_caps is not None:
@@ -299,17 +309,17 @@ def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device, static=False, ex
         for l, ix in enumerate(idx):
             ix.static = True
             ix.n_expected = int(expected[l]) if expected is not None else 0
-    else:
-        host = counts.tolist()  # the only synchronisation of the backbone
-    total = sum(host)
-    coords_all = torch.empty((max(total, 1), 4), dtype=torch.int32, device=device)
-    o = 0
-    for l, ix in enumerate(idx):
-        ix.n = int(host[l])
-        ix.coords = coords_all[o:o + ix.n]
-        levels[l].coords = (coords_all.data_ptr() + 16 * o) if ix.n else None
-        levels[l].coords_rows = ix.n
-        o += ix.n
+        # capacities are known before the scan: the coordinate tables go in with the levels and the scan writes them in its last pass
+        size_coords(host)
+        fused = all(int(h) > 0 for h in host)
+        check(L.fd_index_pyramid(_p(coors), _p(nvox), int(n_max), plan.B, len(shapes), levels, _p(counts), _p(ws), ws.numel(), _stream()),
+              "fd_index_pyramid")
+        if not fused:
+            check(L.fd_index_pyramid_coords(plan.B, len(shapes), levels, _stream()), "fd_index_pyramid_coords")
+        return idx
+    check(L.fd_index_pyramid(_p(coors), _p(nvox), int(n_max), plan.B, len(shapes), levels, _p(counts), _p(ws), ws.numel(), _stream()),
+          "fd_index_pyramid")
+    size_coords(counts.tolist())  # the only synchronisation of the backbone
     check(L.fd_index_pyramid_coords(plan.B, len(shapes), levels, _stream()), "fd_index_pyramid_coords")
     return idx
 

@@ -368,7 +368,9 @@ int fd_nearest_rows(const double *library, int n_library, const double *queries,
  * level l-1 with its ksize/stride/pad (the strided SparseConv3d of scn.py:110,120,130,141); counts_dev[l] receives
  * the active count of level l.  words of every level must be zero-filled by the caller; all levels are scanned by one
  * set of launches: workspace >= fd_index_workspace_bytes(sum of the levels' fd_index_num_cols + 2048 * n_levels).  fd_index_pyramid_coords materialises coords for the levels whose pointer is
- * set (after the host has read the counts and allocated them). */
+ * set (after the host has read the counts and allocated them).  When EVERY level passed to fd_index_pyramid already has its
+ * coords pointer set (capacity-sized tables, coords_rows = capacity), the coordinates are written in the same pass and
+ * fd_index_pyramid_coords need not be called. */
 typedef struct fd_index_level {
     int32_t D, H, W;
     int32_t ksize[3], stride[3], pad[3]; /* how this level derives from the previous one (unused for level 0) */
