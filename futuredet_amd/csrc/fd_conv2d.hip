@@ -57,6 +57,99 @@ struct ConvParams {
     unsigned w_bytes;
 };
 
+#ifdef FD_V2_TRACE
+#define FD_EPI_TRACE_DECL unsigned long long c_mid = 0;
+#define FD_EPI_TRACE_ARG , &c_mid
+#else
+#define FD_EPI_TRACE_DECL
+#define FD_EPI_TRACE_ARG
+#endif
+
+// Epilogue shared by the tile and the strip kernel: + bias, ReLU, round to bf16, store at (y*osy+ooy, x*osx+oox, co_off + co).
+// `out_pixel(m, oy, ox)` maps pixel m (0 .. 127) of the workgroup to its output coordinates and says whether it exists.
+// C/D layout of 32x32: col (channel) = lane & 31, row (pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+template <int WMT, int WNT, int WAVES_M, int WAVES_N, typename PixelFn>
+__device__ __forceinline__ void conv_bf16_epilogue(const f32x16 (&acc)[WMT][WNT], unsigned char *smem, const ConvParams &p, int b,
+                                                   const float *__restrict__ bias, unsigned short *__restrict__ y, const PixelFn &out_pixel,
+                                                   unsigned long long *t_mid = nullptr) {
+    constexpr int NT = WNT * WAVES_N * 32, M = WMT * WAVES_M * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WAVES_M, wn = wave / WAVES_M;
+    const int lm = lane & 31, lk = lane >> 5;
+    const int n0 = blockIdx.y * NT + wn * WNT * 32;
+    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
+    const bool wide = ((p.cout_total | p.co_off) & 7) == 0 && (p.Cout_real & 7) == 0;  // 16-byte aligned channel runs
+    if (wide) {
+        // A lane owns one channel of 16 pixels, i.e. 2-byte stores if written directly (64 store instructions per
+        // wave, issue-bound).  Transpose the tile through LDS instead and store 16 bytes (8 channels) per lane.
+        unsigned short *s_out = reinterpret_cast<unsigned short *>(smem);  // [128 pixels][NT channels] bf16
+        // Lanes l and l ^ 1 hold adjacent channels of the same 16 pixels.  Per pixel pair (r, r + 1): bias, ReLU, one packed
+        // convert (round to nearest even, v_cvt_pk_bf16_f32), the neighbour's pair by a DPP quad permute, one byte permute ->
+        // the even lane owns the (channel pair, pixel r) dword, the odd lane (channel pair, pixel r + 1): 4-byte LDS writes at
+        // compile-time offsets from a per-lane base.  (The older form rounded by hand and exchanged through ds_bpermute: 5.1 k
+        // cycles for this phase, tools/conv_bf16_trace.py.)
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bool odd = lm & 1;
+        const unsigned sel = odd ? 0x03020706u : 0x05040100u;  // v_perm_b32(nb, mine), low half first: odd -> {nb.hi16, mine.hi16}, even -> {mine.lo16, nb.lo16}
+#pragma unroll
+        for (int j = 0; j < WNT; ++j) {
+            const int cl = (wn * WNT + j) * 32 + lm;  // channel inside the block
+            const int co = blockIdx.y * NT + cl;
+            const float bv = (bias && co < p.Cout_real) ? bias[co] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) {
+                unsigned char *dst = reinterpret_cast<unsigned char *>(s_out) + ((((wm * WMT + i) * 32 + (odd ? 1 : 0) + 4 * lk) * NT + (cl & ~1)) << 1);
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2_t v = {acc[i][j][r] + bv, acc[i][j][r + 1] + bv};
+                    if (p.relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); }
+                    const unsigned mine = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
+                    const unsigned packed = __builtin_amdgcn_perm(nb, mine, sel);
+                    // pixel of this dword: (r & 3) + 8 (r >> 2) + 4 lk (+ 1 on the odd lane: inside `dst`)
+                    *reinterpret_cast<unsigned *>(dst + ((((r & 3) + 8 * (r >> 2)) * NT) << 1)) = packed;
+                }
+            }
+        }
+        __syncthreads();
+#ifdef FD_V2_TRACE
+        if (t_mid) *t_mid = __builtin_readcyclecounter();
+#endif
+        constexpr int C8 = NT / 8;
+        for (int id = tid; id < M * C8; id += 256) {
+            const int m = id / C8, c8 = id - m * C8;
+            const int co = blockIdx.y * NT + c8 * 8;
+            int oy, ox;
+            if (out_pixel(m, oy, ox) && co < p.Cout_real) {
+                const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
+                *reinterpret_cast<uint4 *>(y + (((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co) =
+                    *reinterpret_cast<const uint4 *>(s_out + m * NT + c8 * 8);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+        const int co = n0 + j * 32 + lm;
+        const float bv = (bias && co < p.Cout_real) ? bias[co] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * WMT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                int oy, ox;
+                if (out_pixel(m, oy, ox) && co < p.Cout_real) {
+                    float v = acc[i][j][r] + bv;
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
+                    y[(((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co] = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
 // WMT x WNT MFMA tiles (32 x 32) per wave, waves arranged WAVES_M x WAVES_N (product 4); M tile = 128 pixels
 template <int KS, int S, int WMT, int WNT, int WAVES_M, int WAVES_N>
 __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__restrict__ x, const bf16x8 *__restrict__ wp,
@@ -217,83 +310,20 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
         FD_CADD(1, c1 - c0); FD_CADD(2, c2 - c1); FD_CADD(3, c3 - c2);
     }
     FD_CT(c_epi);
-    // epilogue.  C/D layout of 32x32: col (channel) = lane & 31, row (pixel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
-    const bool wide = ((p.cout_total | p.co_off) & 7) == 0 && (p.Cout_real & 7) == 0;  // 16-byte aligned channel runs
-    if (wide) {
-        // A lane owns one channel of 16 pixels, i.e. 2-byte stores if written directly (64 store instructions per
-        // wave, issue-bound).  Transpose the tile through LDS instead and store 16 bytes (8 channels) per lane.
-        unsigned short *s_out = reinterpret_cast<unsigned short *>(smem);  // [128 pixels][NT channels] bf16
-        // Lanes l and l ^ 1 hold adjacent channels of the same 16 pixels.  Per pixel pair (r, r + 1): bias, ReLU, one packed
-        // convert (round to nearest even, v_cvt_pk_bf16_f32), the neighbour's pair by a DPP quad permute, one byte permute ->
-        // the even lane owns the (channel pair, pixel r) dword, the odd lane (channel pair, pixel r + 1): 4-byte LDS writes at
-        // compile-time offsets from a per-lane base.  (The older form rounded by hand and exchanged through ds_bpermute: 5.1 k
-        // cycles for this phase, tools/conv_bf16_trace.py.)
-        typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        const bool odd = lm & 1;
-        const unsigned sel = odd ? 0x03020706u : 0x05040100u;  // v_perm_b32(nb, mine), low half first: odd -> {nb.hi16, mine.hi16}, even -> {mine.lo16, nb.lo16}
-#pragma unroll
-        for (int j = 0; j < WNT; ++j) {
-            const int cl = (wn * WNT + j) * 32 + lm;  // channel inside the block
-            const int co = blockIdx.y * NT + cl;
-            const float bv = (bias && co < p.Cout_real) ? bias[co] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < WMT; ++i) {
-                unsigned char *dst = reinterpret_cast<unsigned char *>(s_out) + ((((wm * WMT + i) * 32 + (odd ? 1 : 0) + 4 * lk) * NT + (cl & ~1)) << 1);
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    f32x2_t v = {acc[i][j][r] + bv, acc[i][j][r + 1] + bv};
-                    if (p.relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); }
-                    const unsigned mine = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xf, 0xf, true);  // quad_perm [1,0,3,2]
-                    const unsigned packed = __builtin_amdgcn_perm(nb, mine, sel);
-                    // pixel of this dword: (r & 3) + 8 (r >> 2) + 4 lk (+ 1 on the odd lane: inside `dst`)
-                    *reinterpret_cast<unsigned *>(dst + ((((r & 3) + 8 * (r >> 2)) * NT) << 1)) = packed;
-                }
-            }
-        }
-        __syncthreads();
-        FD_CT(c_mid);
-        constexpr int C8 = NT / 8;
-        for (int id = tid; id < TH * TW * C8; id += 256) {
-            const int m = id / C8, c8 = id - m * C8;
-            const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-            const int co = blockIdx.y * NT + c8 * 8;
-            if (oy < p.Ho && ox < p.Wo && co < p.Cout_real) {
-                const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
-                *reinterpret_cast<uint4 *>(y + (((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co) =
-                    *reinterpret_cast<const uint4 *>(s_out + m * NT + c8 * 8);
-            }
-        }
+    const auto out_pixel = [&](int m, int &oy, int &ox) {  // pixel m of the 8 x 16 tile, row-major
+        oy = oy0 + m / TW;
+        ox = ox0 + m % TW;
+        return oy < p.Ho && ox < p.Wo;
+    };
+    FD_EPI_TRACE_DECL
+    conv_bf16_epilogue<WMT, WNT, WAVES_M, WAVES_N>(acc, smem, p, b, bias, y, out_pixel FD_EPI_TRACE_ARG);
 #ifdef FD_V2_TRACE
-        if (tid == 0 && g_ctrace) {
-            const unsigned long long c_end = __builtin_readcyclecounter();
-            unsigned long long *o = g_ctrace + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
-            o[0] = cacc[0]; o[1] = cacc[1]; o[2] = cacc[2]; o[3] = cacc[3]; o[4] = c_end - c_epi; o[5] = c_end - c_start; o[6] = c_mid - c_epi; o[7] = c_end;
-        }
+    if (tid == 0 && g_ctrace) {
+        const unsigned long long c_end = __builtin_readcyclecounter();
+        unsigned long long *o = g_ctrace + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+        o[0] = cacc[0]; o[1] = cacc[1]; o[2] = cacc[2]; o[3] = cacc[3]; o[4] = c_end - c_epi; o[5] = c_end - c_start; o[6] = c_mid - c_epi; o[7] = c_end;
+    }
 #endif
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < WNT; ++j) {
-        const int co = n0 + j * 32 + lm;
-        const float bv = (bias && co < p.Cout_real) ? bias[co] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < WMT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * WMT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const int oy = oy0 + m / TW, ox = ox0 + m % TW;
-                if (oy < p.Ho && ox < p.Wo && co < p.Cout_real) {
-                    float v = acc[i][j][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
-                    y[(((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co] = f2bf(v);
-                }
-            }
-        }
-    }
 }
 
 template <int KS, int S, int WMT, int WNT, int WAVES_M, int WAVES_N>
@@ -496,83 +526,22 @@ __global__ void __launch_bounds__(256) conv2d_strip_bf16(const unsigned short *_
         FD_CADD(1, c1 - c0); FD_CADD(2, c2 - c1); FD_CADD(3, c3 - c2);
     }
     FD_CT(c_epi);
-    // epilogue: as in the tile kernel; pixel m of the strip is pixel p0 + m of the image
-    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
-    auto out_pixel = [&](int m, int &oy, int &ox) {
+    const auto out_pixel = [&](int m, int &oy, int &ox) {  // pixel m of the strip = pixel p0 + m of the image
         const int xx = x0 + m;
         const int dy = (xx >= Wo ? 1 : 0) + (xx >= 2 * Wo ? 1 : 0);
         oy = y0 + dy;
         ox = xx - dy * Wo;
+        return m < nvalid;
     };
-    const bool wide = ((p.cout_total | p.co_off) & 7) == 0 && (p.Cout_real & 7) == 0;
-    if (wide) {
-        unsigned short *s_out = reinterpret_cast<unsigned short *>(smem);  // [128 pixels][NT channels] bf16
-        typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        const bool odd = lm & 1;
-        const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-#pragma unroll
-        for (int j = 0; j < WNT; ++j) {
-            const int cl = (wn * WNT + j) * 32 + lm;
-            const int co = blockIdx.y * NT + cl;
-            const float bv = (bias && co < p.Cout_real) ? bias[co] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < WMT; ++i) {
-                unsigned char *dst = reinterpret_cast<unsigned char *>(s_out) + ((((wm * WMT + i) * 32 + (odd ? 1 : 0) + 4 * lk) * NT + (cl & ~1)) << 1);
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    f32x2_t v = {acc[i][j][r] + bv, acc[i][j][r + 1] + bv};
-                    if (p.relu) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); }
-                    const unsigned mine = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xf, 0xf, true);
-                    const unsigned packed = __builtin_amdgcn_perm(nb, mine, sel);
-                    *reinterpret_cast<unsigned *>(dst + ((((r & 3) + 8 * (r >> 2)) * NT) << 1)) = packed;
-                }
-            }
-        }
-        __syncthreads();
-        FD_CT(c_mid);
-        constexpr int C8 = NT / 8;
-        for (int id = tid; id < M * C8; id += 256) {
-            const int m = id / C8, c8 = id - m * C8;
-            const int co = blockIdx.y * NT + c8 * 8;
-            if (m < nvalid && co < p.Cout_real) {
-                int oy, ox;
-                out_pixel(m, oy, ox);
-                const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
-                *reinterpret_cast<uint4 *>(y + (((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co) =
-                    *reinterpret_cast<const uint4 *>(s_out + m * NT + c8 * 8);
-            }
-        }
+    FD_EPI_TRACE_DECL
+    conv_bf16_epilogue<WMT, WNT, WAVES_M, WAVES_N>(acc, smem, p, b, bias, y, out_pixel FD_EPI_TRACE_ARG);
 #ifdef FD_V2_TRACE
-        if (tid == 0 && g_ctrace) {
-            const unsigned long long c_end = __builtin_readcyclecounter();
-            unsigned long long *o = g_ctrace + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
-            o[0] = cacc[0]; o[1] = cacc[1]; o[2] = cacc[2]; o[3] = cacc[3]; o[4] = c_end - c_epi; o[5] = c_end - c_start; o[6] = c_mid - c_epi; o[7] = c_end;
-        }
+    if (tid == 0 && g_ctrace) {
+        const unsigned long long c_end = __builtin_readcyclecounter();
+        unsigned long long *o = g_ctrace + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
+        o[0] = cacc[0]; o[1] = cacc[1]; o[2] = cacc[2]; o[3] = cacc[3]; o[4] = c_end - c_epi; o[5] = c_end - c_start; o[6] = c_mid - c_epi; o[7] = c_end;
+    }
 #endif
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < WNT; ++j) {
-        const int co = n0 + j * 32 + lm;
-        const float bv = (bias && co < p.Cout_real) ? bias[co] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < WMT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * WMT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m < nvalid && co < p.Cout_real) {
-                    int oy, ox;
-                    out_pixel(m, oy, ox);
-                    float v = acc[i][j][r] + bv;
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    const int64_t yy = (int64_t)oy * p.osy + p.ooy, xx = (int64_t)ox * p.osx + p.oox;
-                    y[(((int64_t)b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co] = f2bf(v);
-                }
-            }
-        }
-    }
 }
 
 // patch pixels of the largest strip of an H x W image (the host side of the kernel's hull computation)
