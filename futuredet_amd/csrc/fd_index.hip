@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) idx_coords(const unsigned long long *__re
 
 // ---- all levels of a pyramid in one set of launches (fd_index_pyramid): the words of every level exist before any prefix is
 //      needed, so the three scan phases and the coordinate pass run once over the concatenated blocks of all levels
-//      (5 levels: 15 + 5 launches of ~5 us each become 3 + 1)
+//      (5 levels: 15 + 5 launches of ~5 us each become 2 + 1)
 constexpr int kMaxLevels = 8;
 struct PyramidLevels {
     int n;
@@ -187,28 +187,12 @@ __global__ void __launch_bounds__(kScanThreads) idx_scan1_ml(PyramidLevels L, in
     if (threadIdx.x == 0) bsum[blockIdx.x] = total;
 }
 
-// one workgroup per level
-__global__ void __launch_bounds__(kScanThreads) idx_scan2_ml(PyramidLevels L, int *__restrict__ bsum, int *__restrict__ counts) {
-    __shared__ int sm[4];
-    const int l = blockIdx.x;
-    int *bs = bsum + L.blk0[l];
-    const int nblocks = L.blk0[l + 1] - L.blk0[l];
-    int run = 0;
-    for (int base = 0; base < nblocks; base += kScanThreads) {
-        int j = base + threadIdx.x;
-        int v = j < nblocks ? bs[j] : 0;
-        int total;
-        int e = block_excl_scan(v, total, sm);
-        if (j < nblocks) bs[j] = run + e;
-        run += total;
-    }
-    if (threadIdx.x == 0) counts[l] = run;
-}
-
 // COORDS: the levels' coordinate tables exist already (capacity-sized levels of the sync-free step): the thread that computes a
 // column's prefix writes its rows' coordinates too -- no second pass over words + prefix, one launch less
+// (No middle pass over the block sums: a block sums the totals of its level's blocks in front of it itself -- at most a few
+// thousand values -- and the last block of a level writes the level's count.)
 template <bool COORDS>
-__global__ void __launch_bounds__(kScanThreads) idx_scan3_ml(PyramidLevels L, const int *__restrict__ bsum) {
+__global__ void __launch_bounds__(kScanThreads) idx_scan3_ml(PyramidLevels L, const int *__restrict__ bsum, int *__restrict__ counts) {
     __shared__ int sm[4];
     const int l = level_of(L.blk0, L.n, blockIdx.x);
     const unsigned long long *words = L.words[l];
@@ -223,7 +207,13 @@ __global__ void __launch_bounds__(kScanThreads) idx_scan3_ml(PyramidLevels L, co
         s += __popcll(wv[k]);
     }
     int total;
-    int e = block_excl_scan(s, total, sm) + bsum[blockIdx.x];
+    int e = block_excl_scan(s, total, sm);
+    int before = 0;
+    for (int j = L.blk0[l] + (int)threadIdx.x; j < (int)blockIdx.x; j += kScanThreads) before += bsum[j];
+    int all_before;
+    block_excl_scan(before, all_before, sm);
+    e += all_before;
+    if ((int)blockIdx.x == L.blk0[l + 1] - 1 && threadIdx.x == 0) counts[l] = all_before + total;
     int *coords = COORDS ? L.coords[l] : nullptr;
     const long long cap = (COORDS && L.coords_rows[l] > 0) ? L.coords_rows[l] : 0x7fffffffll;
     int b = 0, y0 = 0, x0 = 0;
@@ -608,13 +598,12 @@ extern "C" int fd_index_pyramid(const int32_t *coords, const int32_t *n_dev, int
     int *bsum = (int *)workspace;
     hipStream_t st = fd::as_stream(stream);
     hipLaunchKernelGGL(idx_scan1_ml, dim3(total_blocks), dim3(kScanThreads), 0, st, L, bsum);
-    hipLaunchKernelGGL(idx_scan2_ml, dim3(n_levels), dim3(kScanThreads), 0, st, L, bsum, counts_dev);
     // every non-empty level brought its coordinate table: write the coordinates in the same pass (fd_index_pyramid_coords is then
     // not needed); otherwise the caller reads the counts, sizes the tables and calls fd_index_pyramid_coords
     bool fused = true;
     for (int l = 0; l < n_levels; ++l) fused = fused && levels[l].coords != nullptr;
-    if (fused) hipLaunchKernelGGL(idx_scan3_ml<true>, dim3(total_blocks), dim3(kScanThreads), 0, st, L, (const int *)bsum);
-    else hipLaunchKernelGGL(idx_scan3_ml<false>, dim3(total_blocks), dim3(kScanThreads), 0, st, L, (const int *)bsum);
+    if (fused) hipLaunchKernelGGL(idx_scan3_ml<true>, dim3(total_blocks), dim3(kScanThreads), 0, st, L, (const int *)bsum, counts_dev);
+    else hipLaunchKernelGGL(idx_scan3_ml<false>, dim3(total_blocks), dim3(kScanThreads), 0, st, L, (const int *)bsum, counts_dev);
     return fd::check_launch("fd_index_pyramid");
 }
 

@@ -5,10 +5,10 @@
 // max_points points per voxel in input order, float32 floor((p-lo)/vs) with a true division) with a
 // deterministic parallel schedule:
 //   K1 hash   : point -> cell key -> open-addressing slot (atomicCAS), atomicMin(first point), atomicAdd(count)
-//   K2-K4 scan: voxel id = rank of the voxel's first point among all first points (exclusive scan over
+//   K2-K3 scan: voxel id = rank of the voxel's first point among all first points (exclusive scan over
 //               points); the same scan carries the per-voxel point counts -> CSR bucket offsets
-//   K5 fill   : point index -> its voxel's bucket (order inside a bucket is arbitrary)
-//   K6 emit   : one lane per voxel selects the max_points smallest point indices of its bucket with an
+//   K4 fill   : point index -> its voxel's bucket (order inside a bucket is arbitrary)
+//   K5 emit   : one lane per voxel selects the max_points smallest point indices of its bucket with an
 //               unrolled insertion network, copies / sums the points in ascending order
 // Wave-level ballots/prefix counts keep the atomics to one per wave where possible (the compiler folds the
 // per-lane atomicAdd(…,1) on a uniform address; the hash itself is lane-divergent by nature).
@@ -87,6 +87,22 @@ __device__ inline void block_scan2(int &a, int &b, int &ta, int &tb, int *sm /*[
     ta = sa; tb = sb;
 }
 
+// block-wide sums of two ints per thread, returned to every thread
+__device__ inline void block_sum2(int &a, int &b, int *sm /*[8]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+    }
+    if (lane == 0) { sm[wave] = a; sm[4 + wave] = b; }
+    __syncthreads();
+    a = 0; b = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) { a += sm[w]; b += sm[4 + w]; }
+    __syncthreads();
+}
+
 __device__ inline void load_flags(const int *pslot, const int *first, const int *cnt, int i, int n, int &f, int &c) {
     f = 0; c = 0;
     if (i < n) {
@@ -113,19 +129,8 @@ __global__ void __launch_bounds__(kScanThreads) vox_scan1(const int *__restrict_
     if (threadIdx.x == 0) { bsum[2 * blockIdx.x] = tf; bsum[2 * blockIdx.x + 1] = tc; }
 }
 
-__global__ void __launch_bounds__(kScanThreads) vox_scan2(int *__restrict__ bsum, int nblocks) {
-    __shared__ int sm[10];
-    int run_f = 0, run_c = 0;
-    for (int base = 0; base < nblocks; base += kScanThreads) {
-        int j = base + threadIdx.x;
-        int f = j < nblocks ? bsum[2 * j] : 0, c = j < nblocks ? bsum[2 * j + 1] : 0;
-        int tf, tc;
-        block_scan2(f, c, tf, tc, sm);
-        if (j < nblocks) { bsum[2 * j] = run_f + f; bsum[2 * j + 1] = run_c + c; }
-        run_f += tf; run_c += tc;
-    }
-}
-
+// (no second pass over the block sums: a block of the third pass sums the totals of the blocks before it itself -- a few hundred
+// values -- which costs less than the launch it replaces)
 __global__ void __launch_bounds__(kScanThreads) vox_scan3(const int *__restrict__ pslot, const int *__restrict__ first,
                                                           const int *__restrict__ cnt, int n, const int *__restrict__ n_dev,
                                                           const int *__restrict__ bsum, int max_voxels, int *__restrict__ vid,
@@ -142,8 +147,11 @@ __global__ void __launch_bounds__(kScanThreads) vox_scan3(const int *__restrict_
     }
     int tf, tc;
     block_scan2(f, c, tf, tc, sm);
-    f += bsum[2 * blockIdx.x];
-    c += bsum[2 * blockIdx.x + 1];
+    int pf = 0, pc = 0;  // totals of the blocks in front of this one
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += kScanThreads) { pf += bsum[2 * j]; pc += bsum[2 * j + 1]; }
+    block_sum2(pf, pc, sm);
+    f += pf;
+    c += pc;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         if (ff[k]) {
@@ -319,7 +327,6 @@ extern "C" int fd_voxelize(const float *points, int64_t n_points, const int32_t 
     const int nsb = (n + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(vox_hash, dim3(nb), dim3(256), 0, stream, points, n, n_points_dev, p, keys, first, cnt, pslot);
     hipLaunchKernelGGL(vox_scan1, dim3(nsb), dim3(kScanThreads), 0, stream, pslot, first, cnt, n, n_points_dev, bsum);
-    hipLaunchKernelGGL(vox_scan2, dim3(1), dim3(kScanThreads), 0, stream, bsum, nsb);
     hipLaunchKernelGGL(vox_scan3, dim3(nsb), dim3(kScanThreads), 0, stream, pslot, first, cnt, n, n_points_dev, bsum, p.max_voxels,
                        vid, boff, vslot, out_num_voxels);
     hipLaunchKernelGGL(vox_fill, dim3(nb), dim3(256), 0, stream, pslot, n, n_points_dev, vid, boff, cursor, bucket);
