@@ -32,9 +32,14 @@ int fd_abi_version(void);
 const char *fd_last_error(void);
 /* Tuning / test knobs (no reference counterpart).  0 = built-in heuristic.  Names: "spconv_rg" (rows per wave of the
  * register sparse-conv kernel: 1|2|4), "spconv_v1" (1: fp32 on the register kernel instead of the compacting one),
- * "spconv_bf16_v1", "v2_depth", "v2_tm", "v2_ldspad", "conv_nt", "v2_ranges_per_cu", "v2_uniform".  Initial values come from the FD_SPCONV_RG,
- * FD_SPCONV_V1, ... environment variables, read once when the library is loaded; nothing on the launch path calls
- * getenv(). */
+ * "spconv_bf16_v1", "v2_depth", "v2_tm", "v2_ldspad", "conv_nt" (output channels per workgroup of the bf16 dense conv: 64 | 32),
+ * "v2_ranges_per_cu", "v2_uniform", "v2_rowcost", "spconv_c32", "bf16_gp", "bf16_rg", "bf16_depth", "bf16_nw", "split_rg",
+ * "strict" (1: a bf16 sparse layer that the gather-pipeline kernels cannot take is an error instead of a fall-back to the register
+ * kernels), "bf16_win" (1: LDS row-window variant of the bf16 RING kernels), "f32_res_rg" (-1: 16-channel fp32 layers on the
+ * pair-compacting kernel instead of the resident-weights one), "conv_strip" (1: stride-1 bf16 dense layers on strips of 128
+ * consecutive pixels instead of 8 x 16 tiles: faster alone, slower with several sweeps in flight; results identical).  Initial
+ * values come from the FD_SPCONV_RG, FD_SPCONV_V1, ... environment variables (FD_ + the upper-case name), read once when the
+ * library is loaded; nothing on the launch path calls getenv(). */
 int fd_tuning_set(const char *name, int value);
 
 /* ---------------------------------------------------------------------------------------------------
