@@ -41,6 +41,9 @@ __device__ unsigned long long *g_c32trace;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxTaps = 27;
+#ifndef FD_C32_OPT
+#define FD_C32_OPT 0  // candidate changes: 1 = bias / residual requested before the list staging waits for the slice, 2 = compaction with all LDS reads first
+#endif
 #ifndef FD_C32_TM
 #define FD_C32_TM 128
 #endif
@@ -120,6 +123,23 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
         if (n_rows <= 0) break;
         C_T(c0);
         // ---- stage the prefetched slice, clear the accumulators
+        constexpr int C4i = COUT / 4, NINIT = TM * C4i / 256;
+        static_assert(TM * C4i % 256 == 0, "whole passes");
+        float4 iv[NINIT], rv[NINIT];
+        auto request_init = [&]() {
+#pragma unroll
+            for (int i = 0; i < NINIT; ++i) {
+                const int t = tid + i * 256, c4 = t % C4i;
+                iv[i] = bias ? reinterpret_cast<const float4 *>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < NINIT; ++i) {
+                const int t = tid + i * 256, r = t / C4i, c4 = t - r * C4i;
+                const int rr = r < n_rows ? r : n_rows - 1;
+                rv[i] = residual ? reinterpret_cast<const float4 *>(residual + (int64_t)(row0 + rr) * COUT)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        if constexpr (FD_C32_OPT & 1) request_init();  // behind the slice loads in the queue: the staging below waits for the slice only
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
             const int t = tid + i * 256;
@@ -128,22 +148,8 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
         }
         // tile copy 0 starts from bias + residual (see fd_spconv_v2.hip: no dependent global loads left in the epilogue)
         {
-            constexpr int C4i = COUT / 4, NINIT = TM * C4i / 256;
-            static_assert(TM * C4i % 256 == 0, "whole passes");
-            float4 iv[NINIT];
-#pragma unroll
-            for (int i = 0; i < NINIT; ++i) {
-                const int t = tid + i * 256, c4 = t % C4i;
-                iv[i] = bias ? reinterpret_cast<const float4 *>(bias)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            if constexpr (!(FD_C32_OPT & 1)) request_init();
             if (residual) {
-                float4 rv[NINIT];
-#pragma unroll
-                for (int i = 0; i < NINIT; ++i) {
-                    const int t = tid + i * 256, r = t / C4i, c4 = t - r * C4i;
-                    const int rr = r < n_rows ? r : n_rows - 1;
-                    rv[i] = reinterpret_cast<const float4 *>(residual + (int64_t)(row0 + rr) * COUT)[c4];
-                }
 #pragma unroll
                 for (int i = 0; i < NINIT; ++i) { iv[i].x += rv[i].x; iv[i].y += rv[i].y; iv[i].z += rv[i].z; iv[i].w += rv[i].w; }
             }
@@ -160,6 +166,42 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
         __syncthreads();
         C_T(c1);
         // ---- in-place compaction per (tap, row half): wave w takes taps w, w + 4, ...; tails are filled with kPad
+        if constexpr (FD_C32_OPT & 2) {
+            // all LDS reads of this wave's taps first, then the padding stores, then ballots + compacted stores: one LDS round trip
+            // for the wave instead of one per tap (LDS operations of a wave execute in order, so the stores cannot overtake the reads)
+            constexpr int NTW = (kMaxTaps + 3) / 4, NG = RW / 64;
+            static_assert(WR == 1, "one row range per tap");
+            int vv[NTW][NG];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int k = wave + 4 * t;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) vv[t][g] = k < K ? s_list[k * TM + g * 64 + lane] : -1;
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int k = wave + 4 * t;
+                if (k < K) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) s_list[k * TM + g * 64 + lane] = kPad;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int k = wave + 4 * t;
+                if (k < K) {
+                    int count = 0;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const unsigned long long m = __ballot(vv[t][g] >= 0);
+                        const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                        if (vv[t][g] >= 0) s_list[k * TM + pos] = (vv[t][g] << 8) | (g * 64 + lane);
+                        count += __popcll(m);
+                    }
+                    if (lane == 0) s_cnt[k * 4] = (unsigned char)count;
+                }
+            }
+        } else
         for (int k = wave; k < K && (!(FD_C32_EXP & 16) || chunk == 0); k += 4) {
 #pragma unroll
             for (int h = 0; h < WR; ++h) {
