@@ -82,7 +82,6 @@ def parse():
                     "for micro-batches below 8 clouds (measured with four passes in flight: fp32 +10 %%, bf16 n3 +10 %%, n3dtf +17 %%, "
                     "PointPillars +60 %%; at 8 clouds per pass the kernels are long enough that the graph changes nothing, -1.6 %%)")
     ap.add_argument("--inflight", type=int, default=4, help="forward passes in flight per GPU, each on its own HIP stream (1 = strictly serial)")
-    ap.add_argument("--channels-last", type=int, default=-1)
     ap.add_argument("--voxel-xy", type=float, default=0.075, help="x/y voxel size (0.05 = the finer grid of BASELINE configs[4])")
     ap.add_argument("--max-voxels", type=int, default=160000)
     ap.add_argument("--class-name", default="car")
@@ -95,10 +94,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the second timed loop (host -> host)")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage GPU times to stderr")
-    ap.add_argument("--fp32-arith", default="native", choices=["native", "split"], help="fp32 only: 'split' runs the sparse levels with >= --split-min-channels "
-                    "channels on the bf16 matrix pipe with three-piece (3 x bf16) operands, fp32 accumulate (fd_spconv_split.hip)")
-    ap.add_argument("--split-min-channels", type=int, default=128)
-    ap.add_argument("--torch-dense", action="store_true", help="A/B: run RPN + head through PyTorch-ROCm (MIOpen) instead of the hand-written MFMA convolutions")
+    ap.add_argument("--no-also", action="store_true", help="default fp32 run only: skip the extra config-3 (forecast_n3, bf16) measurement attached under 'also'")
     ap.add_argument("--dump", default="", help="rank 0 saves the last step's gathered detections (npz: packed, counts) here (tests)")
     pre, _ = ap.parse_known_args()
     if pre.config:  # a preset only moves the DEFAULTS: a flag given on the command line wins over it
@@ -315,31 +311,14 @@ def cpu_all_cores_probe(args):
     print("ALLCORES %.3f" % dt, flush=True)
 
 
-def main():
-    args = parse()
-    if args.cpu_all_cores_probe:
-        return cpu_all_cores_probe(args)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args)  # (does not return)
-    from futuredet_amd import build as fbuild
-    from futuredet_amd import build_detector, dist_infer, lib
+def measure(args, env):
+    """One complete measurement (set-up, warm-up, R repetitions of the K-step timed region, host leg, latency leg, roofline events) of the
+    workload ``args`` names; returns the JSON object on rank 0 (None elsewhere).  ``env``: the process-level state main() set up once."""
+    from futuredet_amd import build_detector, dist_infer
     from futuredet_amd.configs import centerpoint_config
     from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims, tame_scores
 
-    # FD_BENCH_ONE_DEVICE=1 (test hook for 1-GPU boxes): every rank uses cuda:0 and the collectives run over gloo, so the
-    # world > 1 logic (sharded seeds, barriers, MAX over ranks, result gather, rank-0 print) can be exercised anywhere
-    one_dev = bool(os.environ.get("FD_BENCH_ONE_DEVICE"))
-    rank, world, local = dist_infer.init_from_env("gloo" if one_dev else "nccl")
-    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d (or plain `python bench.py --gpus %d`)" % (
-        world, args.gpus, args.gpus, args.gpus)
-    if one_dev:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    fbuild.build_locked()  # rank-local check under a file lock: no rank waits in a collective for another rank's compiler
-    lib.load()
-    cpus = dist_infer.pin_rank_cpus(local if not one_dev else rank, world)  # 256 logical CPUs / 8 ranks = 32 per rank
-
+    rank, world, dev, one_dev, cpus = env["rank"], env["world"], env["dev"], env["one_dev"], env["cpus"]
     is_pp = args.variant == "pp_n3dtf"
     if is_pp:  # secondary line: the PointPillars configs (SURVEY 8f-4); no sparse conv, no roofline object
         from futuredet_amd.configs import pointpillars_config
@@ -357,11 +336,7 @@ def main():
     # all_gather that fails loudly when replicas differ
     replica_checksum = dist_infer.sync_replicas(net, src=0, check=True)
     dtype = torch.float32 if args.dtype == "fp32" else torch.bfloat16
-    if args.torch_dense:
-        net.neck.use_hip_conv = net.bbox_head.use_hip_conv = False
-    net.set_precision(dtype, None if args.channels_last < 0 else bool(args.channels_last), fp32_arith=args.fp32_arith if hasattr(net.backbone, "fp32_arith") else None)
-    if hasattr(net.backbone, "split_min_channels"):
-        net.backbone.split_min_channels = args.split_min_channels
+    net.set_precision(dtype)
     prof = SpconvProfiler()
     net.backbone.profile_hook = prof
 
@@ -662,7 +637,6 @@ def main():
     }
     if rank == 0 and is_pp:
         out["roofline"] = None
-        print(json.dumps(out))
     elif rank == 0:
         # ---- roofline of the dominant kernel (sparse conv apply), from the events recorded in the timed region
         torch.cuda.synchronize()
@@ -801,6 +775,67 @@ def main():
                                                "gpu_rows": out["parity_vs_oracle"]["gpu_rows"], "oracle_rows": out["parity_vs_oracle"]["oracle_rows"]}
             except Exception as e:  # the baseline is reported context, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "sweeps/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+    net.backbone.profile_hook = None
+    return out if rank == 0 else None
+
+
+def main():
+    args = parse()
+    if args.cpu_all_cores_probe:
+        return cpu_all_cores_probe(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # (does not return)
+    from futuredet_amd import build as fbuild
+    from futuredet_amd import dist_infer, lib
+
+    # FD_BENCH_ONE_DEVICE=1 (test hook for 1-GPU boxes): every rank uses cuda:0 and the collectives run over gloo, so the
+    # world > 1 logic (sharded seeds, barriers, MAX over ranks, result gather, rank-0 print) can be exercised anywhere
+    one_dev = bool(os.environ.get("FD_BENCH_ONE_DEVICE"))
+    rank, world, local = dist_infer.init_from_env("gloo" if one_dev else "nccl")
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node %d (or plain `python bench.py --gpus %d`)" % (
+        world, args.gpus, args.gpus, args.gpus)
+    if one_dev:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    fbuild.build_locked()  # rank-local check under a file lock: no rank waits in a collective for another rank's compiler
+    lib.load()
+    cpus = dist_infer.pin_rank_cpus(local if not one_dev else rank, world)  # 256 logical CPUs / 8 ranks = 32 per rank
+    env = dict(rank=rank, world=world, dev=dev, one_dev=one_dev, cpus=cpus)
+    out = measure(args, env)
+    # The default run (BASELINE configs[1], fp32, one GPU) also measures BASELINE configs[2] -- forecast_n3, bf16 conv features, the
+    # same clouds -- in this process, after the headline's legs, and attaches it under "also": three of the five BASELINE
+    # configurations are bf16 and would otherwise never be seen by the driver's run.  value / dtype / config stay the fp32 headline's.
+    is_default = (world == 1 and args.dtype == "fp32" and args.variant == "forecast_n0" and args.points == 300000 and args.batch == 1 and
+                  args.global_batch == 0 and args.scene == "dense" and args.class_name == "car" and not args.no_also)
+    if is_default and out is not None:
+        import copy
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
+        t_also = time.perf_counter()
+        try:
+            a3 = copy.copy(args)
+            for k, v in PRESETS[3].items():
+                setattr(a3, k, v)
+            a3.no_cpu_baseline, a3.reps, a3.dump, a3.stage_times = True, min(args.reps, 3), "", False
+            o3 = measure(a3, env)
+            r3 = o3.get("roofline") or {}
+            out["also"] = {"config3": {
+                "workload": o3["config"]["workload"], "dtype": o3["dtype"], "value": o3["value"], "unit": o3["unit"], "ms_per_step": o3["ms_per_step"],
+                "steps": o3["steps"], "warmup": o3["warmup"], "value_host_to_host": o3["value_host_to_host"],
+                "latency_ms_inflight1": o3["latency_ms_inflight1"], "repetitions": o3["repetitions"],
+                "roofline": {k: r3.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step", "spconv_ms_per_step",
+                                                    "traffic", "traffic_source")},
+                "hbm_algorithmic": r3.get("hbm_algorithmic"), "detections_last_step": o3["config"]["detections_last_step"],
+                "what": "BASELINE configs[2] (forecast_n3, bf16 conv features, fp32 accumulate; the same 317k-point clouds) measured by this process right "
+                        "after the fp32 headline's legs with the same program (set-up, %d warm-up steps, %d repetitions of the %d-step timed region, "
+                        "host leg, one-in-flight latency leg, per-launch HIP events); parity of this configuration: tests/test_gpu_parity.py "
+                        "(teacher-forced layers within one bf16 ulp); %.0f s of wall time" % (a3.warmup, a3.reps, a3.steps, time.perf_counter() - t_also)}}
+        except Exception as e:  # extra context, never a reason to lose the headline
+            out["also"] = {"config3": {"value": None, "failed": repr(e)}}
+    if rank == 0 and out is not None:
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

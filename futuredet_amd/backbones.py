@@ -76,12 +76,7 @@ class SpMiddleResNetFHD(nn.Module):
         self.extra_conv = S(SparseConv3d(128, 128, (3, 1, 1), (2, 1, 1), bias=False), build_norm_layer(norm_cfg, 128)[1],
                             nn.ReLU())
         self.compute_dtype = torch.float32   # torch.bfloat16 selects the bf16 MFMA path (fp32 accumulate)
-        # fp32 only: "split" runs the levels with >= split_min_channels channels on the bf16 matrix pipe with three-piece
-        # operands (fd_spconv_split.hip: fp32 values stored as three bf16 planes between those layers, fp32 accumulate,
-        # fp32-class error); "native" = fp32 MFMA everywhere
-        self.fp32_arith = "native"
-        self.split_min_channels = 128
-        self.dense_channels_last = False
+        self.dense_channels_last = True
         self.dense_dtype = None              # dtype of the BEV map handed to the neck (default: compute dtype)
         self.profile_hook = None             # callable(tag, algorithmic_bytes, flops, fn) used by bench.py
 
@@ -150,22 +145,17 @@ class SpMiddleResNetFHD(nn.Module):
                 rb_cache[key] = src.rulebook(dst, ks, st, pd)
             return rb_cache[key]
 
-        split_on = dt == torch.float32 and self.fp32_arith == "split"
-
-        def run(conv, bn, x, src, dst, relu, residual=None, out_planes=False):
-            """``x`` is float32 [n, C] or planes (bfloat16 [n, 3 C]); ``out_planes``: the consumers are split-operand layers."""
-            in_planes = x.dtype == torch.bfloat16 and dt == torch.float32
-            mode = ("p2p" if out_planes else "p2f") if in_planes else ("f2p" if out_planes else None)
-            wpk, bias, cin_p, cout_p = conv.packed_weight(hip_ops.F32_SPLIT if in_planes else dt, bn)
-            assert x.shape[1] == (3 * cin_p if in_planes else cin_p), (x.shape, cin_p, mode)
+        def run(conv, bn, x, src, dst, relu, residual=None):
+            wpk, bias, cin_p, cout_p = conv.packed_weight(dt, bn)
+            assert x.shape[1] == cin_p, (x.shape, cin_p)
             nbr = rulebook(src, dst, conv)
-            fn = lambda: hip_ops.spconv_apply(x, wpk, bias, nbr, dst.n, cout_p, residual=residual, relu=relu, mode=mode)  # noqa: E731
+            fn = lambda: hip_ops.spconv_apply(x, wpk, bias, nbr, dst.n, cout_p, residual=residual, relu=relu)  # noqa: E731
             if self.profile_hook is not None:
                 s = 4 if dt == torch.float32 else 2
                 K = nbr.shape[0]
                 pairs = lambda: int((nbr[:, : dst.n] >= 0).sum().item())  # noqa: E731
                 return self.profile_hook("spconv_%dx%d_K%d" % (cin_p, cout_p, K),
-                                         dict(s=s, K=K, cin=cin_p, cout=cout_p, n_in=src.n, n_out=dst.n, pairs=pairs, mode=mode), fn)
+                                         dict(s=s, K=K, cin=cin_p, cout=cout_p, n_in=src.n, n_out=dst.n, pairs=pairs), fn)
             return fn()
 
         main, side = None, None
@@ -187,7 +177,7 @@ class SpMiddleResNetFHD(nn.Module):
                         nbr = rulebook(dst_l, dst_l, blk.conv1)
                         made.append(nbr)
                         cp = spconv.pad_channels(blk.conv1.out_channels)
-                        if dt == torch.float32 and self.fp32_arith != "split" and nbr.shape[0] == 27 and \
+                        if dt == torch.float32 and nbr.shape[0] == 27 and \
                                 hip_ops._lib.load().fd_spconv_wants_balanced_ranges(cp, cp, 0):
                             r = hip_ops.ranges_for(nbr, cp, cp)  # cached on the rulebook tensor; spconv_apply finds it there
                             if r[0] is not None:
@@ -201,12 +191,10 @@ class SpMiddleResNetFHD(nn.Module):
             dst = idx[lvl]
             if lvl == 1 and side is not None:
                 main.wait_stream(side)  # join: the first level's convolutions are issued, the other levels' rulebooks are needed now
-            # a level lives in planes when its block convolutions are split-operand layers; the last level feeds fd_densify (float32)
-            planes = split_on and bool(blocks) and spconv.pad_channels(conv.out_channels) >= max(32, self.split_min_channels)
-            x = run(conv, bn, x, src, dst, relu=True, out_planes=planes)
+            x = run(conv, bn, x, src, dst, relu=True)
             for blk in blocks:
-                y = run(blk.conv1, blk.bn1, x, dst, dst, relu=True, out_planes=planes)
-                x = run(blk.conv2, blk.bn2, y, dst, dst, relu=True, residual=x, out_planes=planes)
+                y = run(blk.conv1, blk.bn1, x, dst, dst, relu=True)
+                x = run(blk.conv2, blk.bn2, y, dst, dst, relu=True, residual=x)
             levels[lvl] = (x, dst)
         bev = hip_ops.densify(x, idx[4], out_dtype=self.dense_dtype or dt, channels_last=self.dense_channels_last, out=dense_out)
         return bev, levels
@@ -224,8 +212,6 @@ class SpMiddleResNetFHD(nn.Module):
         multi = {}
         for name, lvl, c in (("conv1", 0, 16), ("conv2", 1, 32), ("conv3", 2, 64), ("conv4", 3, 128)):
             f, ix = levels[lvl]
-            if f.dtype == torch.bfloat16 and self.compute_dtype == torch.float32:
-                f = hip_ops.planes_to_rows(f)  # a split-operand level: back to float32 rows, exactly
             multi[name] = spconv.SparseConvTensor(f[:, :c], None, ix.spatial_shape, batch_size, _index=ix)
         return bev, multi
 
@@ -239,7 +225,7 @@ class PointPillarsScatter(nn.Module):
         super().__init__()
         self.name = "PointPillarsScatter"
         self.nchannels = num_input_features
-        self.dense_channels_last = False
+        self.dense_channels_last = True
 
     def forward(self, voxel_features, coords, batch_size, input_shape, n_dev=None):
         self.nx = int(input_shape[0])

@@ -185,6 +185,7 @@ struct DecCfg {
     float rng[6];
     float iou_thr;
     int pre_max, post_max;
+    int hm_channels;
 };
 
 // A head map as the kernels read it: element (group g, channel ch, BEV cell) of a float32 or bf16 tensor at
@@ -214,7 +215,8 @@ __global__ void __launch_bounds__(256) dec_keys(MapView hm, MapView reg, MapView
     const int g = blockIdx.y;
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= c.HW) return;
-    const float logit = ld(hm, g, 0, cell);
+    float logit = ld(hm, g, 0, cell);
+    for (int ch = 1; ch < c.hm_channels; ++ch) logit = fmaxf(logit, ld(hm, g, ch, cell));  // center_head.py:592: torch.max over the class channels
     const float score = 1.0f / (1.0f + expf(-logit));
     float x, y;
     cell_center(c, reg, g, cell, x, y);
@@ -672,6 +674,8 @@ extern "C" int fd_centerpoint_decode_maps(const fd_map_view *hm, const fd_map_vi
     for (int i = 0; i < 6; ++i) c.rng[i] = cfg->center_range[i];
     c.iou_thr = cfg->nms_iou_threshold;
     c.pre_max = cfg->nms_pre_max; c.post_max = cfg->nms_post_max;
+    c.hm_channels = cfg->hm_channels > 1 ? cfg->hm_channels : 1;
+    FD_REQUIRE(c.hm_channels <= 16, "fd_centerpoint_decode: hm_channels must be <= 16");
     DecWs w = dec_layout(G, c.HW, c.pre_max, c.post_max);
     if (!workspace || workspace_bytes < w.total) {
         fd::set_error("fd_centerpoint_decode: workspace %zu < required %zu", workspace_bytes, w.total);

@@ -120,68 +120,3 @@ extern "C" int fd_densify(const void *feats, int c, int dtype, const uint64_t *w
     }
     return fd::check_launch("fd_densify");
 }
-
-// -------------------------------------------------------------------------------------------------------------------
-// In-place per-channel bias (+ReLU) on an NCHW float32 map: the epilogue MIOpen's fp32 Winograd kernels lack (PyTorch
-// otherwise runs a broadcast add and a clamp as two more passes over the map).  One float4 per thread, HW % 4 == 0.
-namespace {
-__global__ void __launch_bounds__(256) bias_act_nchw(const float4 *__restrict__ x, const float *__restrict__ bias, int C, int hw4, long long n4,
-                                                     int relu, float4 *__restrict__ dst, long long dst_batch4) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const long long chw4 = (long long)C * hw4;
-    const long long bidx = i / chw4, r = i - bidx * chw4;
-    const float b = bias[(int)(r / hw4)];
-    float4 v = x[i];
-    v.x += b; v.y += b; v.z += b; v.w += b;
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    dst[bidx * dst_batch4 + r] = v;  // in place: dst = x, dst_batch4 = C*hw4; into a concat buffer: dst = slice base
-}
-}  // namespace
-
-extern "C" int fd_bias_act_nchw_f32(float *x, const float *bias, int B, int C, int64_t hw, int relu, float *dst, int64_t dst_batch_stride,
-                                    fd_stream_t stream) {
-    FD_REQUIRE(x && bias && B > 0 && C > 0 && hw > 0, "fd_bias_act_nchw_f32: bad argument");
-    FD_REQUIRE(hw % 4 == 0 && hw / 4 < (1ll << 31), "fd_bias_act_nchw_f32: H*W must be a multiple of 4");
-    FD_REQUIRE(!dst || (dst_batch_stride >= (int64_t)C * hw && dst_batch_stride % 4 == 0), "fd_bias_act_nchw_f32: bad destination stride");
-    const long long n4 = (long long)B * C * (hw / 4);
-    float *d = dst ? dst : x;
-    const long long db4 = dst ? dst_batch_stride / 4 : (long long)C * (hw / 4);
-    hipLaunchKernelGGL(bias_act_nchw, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, fd::as_stream(stream),
-                       reinterpret_cast<const float4 *>(x), bias, C, (int)(hw / 4), n4, relu, reinterpret_cast<float4 *>(d), db4);
-    return fd::check_launch("fd_bias_act_nchw_f32");
-}
-
-// -------------------------------------------------------------------------------------------------------------------
-// ConvTranspose2d with kernel = stride = k (rpn.py:81-94) has no overlapping taps: it is a 1x1 convolution to k*k*Cout
-// channels followed by a pixel shuffle.  This kernel is that shuffle fused with the folded-BN shift + ReLU and the
-// concat placement: y[b, (dy*k+dx)*Cout + co, i, j] -> dst[b, co, i*k+dy, j*k+dx] (MIOpen's own path is GEMM + col2im +
-// two elementwise passes).  One thread per output pixel quad along x.
-namespace {
-__global__ void __launch_bounds__(256) shuffle_bias_act(const float *__restrict__ y, const float *__restrict__ bias, int Cout, int H, int W, int k,
-                                                        int relu, float *__restrict__ dst, long long dst_batch, long long n) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const int Wo = W * k, Ho = H * k;
-    const int xo = (int)(t % Wo);
-    long long r = t / Wo;
-    const int yo = (int)(r % Ho);
-    r /= Ho;
-    const int co = (int)(r % Cout);
-    const long long b = r / Cout;
-    const int i = yo / k, dy = yo - i * k, j = xo / k, dx = xo - j * k;
-    float v = y[((b * (long long)(k * k) * Cout + (long long)(dy * k + dx) * Cout + co) * H + i) * W + j] + bias[co];
-    if (relu) v = fmaxf(v, 0.f);
-    dst[b * dst_batch + ((long long)co * Ho + yo) * Wo + xo] = v;
-}
-}  // namespace
-
-extern "C" int fd_shuffle_bias_act_f32(const float *y, const float *bias, int B, int cout, int H, int W, int k, int relu, float *dst,
-                                       int64_t dst_batch_stride, fd_stream_t stream) {
-    FD_REQUIRE(y && bias && dst && B > 0 && cout > 0 && H > 0 && W > 0 && k >= 1 && k <= 8, "fd_shuffle_bias_act_f32: bad argument");
-    FD_REQUIRE(dst_batch_stride >= (int64_t)cout * H * k * W * k, "fd_shuffle_bias_act_f32: bad destination stride");
-    const long long n = (long long)B * cout * H * k * W * k;
-    hipLaunchKernelGGL(shuffle_bias_act, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, fd::as_stream(stream), y, bias, cout, H, W, k, relu, dst,
-                       (long long)dst_batch_stride, n);
-    return fd::check_launch("fd_shuffle_bias_act_f32");
-}

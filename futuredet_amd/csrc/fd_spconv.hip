@@ -272,8 +272,6 @@ inline int64_t pair_layout_elems(int K, int cin, int cout, int dtype) { return (
 
 extern "C" size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype) {
     if (K <= 0 || cin <= 0 || cout <= 0) return 0;
-    if (dtype == 2 || dtype == 3) return (size_t)K * cin * cout * 6;  // three bf16 planes
-    if (dtype == 4) dtype = 0;
     return (size_t)K * cin * cout * (dtype == 0 ? 4 : 2) * (has_c32_layout(cin, cout, dtype) ? 2 : 1) + (size_t)pair_layout_elems(K, cin, cout, dtype) * 2;
 }
 
@@ -282,8 +280,7 @@ extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, i
     FD_REQUIRE(K >= 1 && K <= kMaxTaps, "fd_spconv_pack_weight: K must be in [1,27]");
     FD_REQUIRE(cin % 16 == 0 && cout % 16 == 0 && cin >= 16 && cin <= 128 && cout >= 16 && cout <= 128,
                "fd_spconv_pack_weight: channels must be multiples of 16 in [16,128] (got %d -> %d)", cin, cout);
-    FD_REQUIRE(dtype >= 0 && dtype <= 4, "fd_spconv_pack_weight: dtype must be 0 (f32), 1 (bf16), 2 / 3 (split operands, planes in) or 4 (f32 in, planes out)");
-    if (dtype == 4) dtype = 0;  // native fp32 arithmetic, only the output format differs
+    FD_REQUIRE(dtype == 0 || dtype == 1, "fd_spconv_pack_weight: dtype must be 0 (f32) or 1 (bf16)");
     const int NB = cout / 16;
     auto W = [&](int k, int ci, int co) { return w[((int64_t)k * cin + ci) * cout + co]; };
     auto tobf = [](float v) {
@@ -293,27 +290,6 @@ extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, i
         u += 0x7fffu + ((u >> 16) & 1u);
         return (uint16_t)(u >> 16);
     };
-    if (dtype == 2 || dtype == 3) {
-        // fd_spconv_split.hip: [K][cin / 32][step u = 0, 1][cout / 32][plane h, m, l][lane][8] bf16 (v_mfma_f32_32x32x16_bf16 A
-        // operand).  Lane (column m = lane % 32, half kh = lane / 32) element i is the weight of input channel
-        // 32 c + 16 u + 8 kh + i -- the eight channels the lane's 16-byte gather of step u delivers.
-        FD_REQUIRE(cin % 32 == 0 && cout % 32 == 0, "fd_spconv_pack_weight: split operands need cin and cout multiples of 32");
-        const int NC = cin / 32, NBL = cout / 32;
-        uint16_t *d = (uint16_t *)dst;
-        for (int k = 0; k < K; ++k)
-            for (int c = 0; c < NC; ++c)
-                for (int u = 0; u < 2; ++u)
-                    for (int b = 0; b < NBL; ++b)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int i = 0; i < 8; ++i) {
-                                const int ci = 32 * c + 16 * u + 8 * (lane >> 5) + i;
-                                uint16_t p[3];
-                                fd::split3_host(W(k, ci, 32 * b + (lane & 31)), p[0], p[1], p[2]);
-                                for (int pl = 0; pl < 3; ++pl)
-                                    d[(((((((int64_t)k * NC + c) * 2 + u) * NBL + b) * 3 + pl) * 64) + lane) * 8 + i] = p[pl];
-                            }
-        return FD_OK;
-    }
     if (dtype == 0) {
         const int NC = cin / 16;
         float *d = (float *)dst;
@@ -367,31 +343,12 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
                                const int32_t *nbr, int64_t nbr_stride, const int32_t *ranges, int n_ranges, int K, int64_t n_out,
                                const int32_t *n_out_dev, int64_t n_expected, int cin, int cout, int dtype, void *out_feats, fd_stream_t stream) {
     FD_REQUIRE(K >= 1 && K <= kMaxTaps, "fd_spconv_apply: K must be in [1,27]");
-    FD_REQUIRE(dtype >= 0 && dtype <= 4, "fd_spconv_apply: dtype must be 0 (f32), 1 (bf16), 2 (planes -> planes), 3 (planes -> f32) or 4 (f32 -> planes)");
+    FD_REQUIRE(dtype == 0 || dtype == 1, "fd_spconv_apply: dtype must be 0 (f32) or 1 (bf16)");
     FD_REQUIRE(n_out >= 0 && n_out <= nbr_stride && n_out < (1ll << 31), "fd_spconv_apply: n_out out of range");
     FD_REQUIRE(n_ranges >= 0 && (ranges == nullptr || n_ranges >= 1), "fd_spconv_apply: ranges needs n_ranges >= 1");
     if (n_expected <= 0 || n_expected > n_out) n_expected = n_out;  // only steers launch heuristics
     if (n_out == 0) return FD_OK;  // an empty active set (empty cloud): nothing to compute, buffers may be null
     FD_REQUIRE(in_feats && wpacked && nbr && out_feats, "fd_spconv_apply: null argument");
-    if (dtype == 2 || dtype == 3) {
-        // fp32 values stored as three bf16 planes, multiplied on the bf16 matrix pipe (fd_spconv_split.hip).  No fallback: the
-        // packed weights of these dtypes have no other reader.
-        if (fd::spconv_p3_dispatch(in_feats, wpacked, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out, n_out_dev, n_expected, cin, cout,
-                                   dtype == 2, out_feats, fd::as_stream(stream)))
-            return fd::check_launch("fd_spconv_apply(split)");
-        fd::set_error("fd_spconv_apply: split-operand arithmetic covers 32/64/128 -> 32/64/128 channels below 2 GB of features (got %d -> %d, %lld rows)", cin, cout,
-                      (long long)n_in);
-        return FD_EINVAL;
-    }
-    if (dtype == 4) {
-        // native fp32 arithmetic, output written as planes for a split-operand consumer (the pair-compacting kernel's epilogue)
-        FD_REQUIRE(residual == nullptr, "fd_spconv_apply: dtype 4 (f32 -> planes) takes no residual");
-        if (fd::spconv_f32_compact_dispatch((const float *)in_feats, wpacked, bias, nullptr, relu, nbr, nbr_stride, K, n_in, (int)n_out, n_out_dev, cin, cout,
-                                            out_feats, ranges, n_ranges, 1, fd::as_stream(stream)))
-            return fd::check_launch("fd_spconv_apply(compact, planes out)");
-        fd::set_error("fd_spconv_apply: dtype 4 needs a shape of the pair-compacting fp32 kernel (got %d -> %d)", cin, cout);
-        return FD_EINVAL;
-    }
     if (dtype == 0 && !fd::tuning(fd::kTuneSpconvV1) && cin == 16 && fd::tuning(fd::kTuneF32ResRG) >= 0) {
         // the 16-channel level: resident weights + register accumulators + empty-item skipping (fd_spconv_f32r.hip); "f32_res_rg" = -1
         // keeps the pair-compacting kernel for A/B runs
@@ -409,19 +366,12 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
     if (dtype == 0 && !fd::tuning(fd::kTuneSpconvV1)) {
         // fp32 is MFMA-bound: the pair-compacting kernel (fd_spconv_v2.hip) feeds the matrix core no zero rows
         if (fd::spconv_f32_compact_dispatch((const float *)in_feats, wpacked, bias, (const float *)residual, relu, nbr, nbr_stride, K, n_in,
-                                            (int)n_out, n_out_dev, cin, cout, out_feats, ranges, n_ranges, 0, fd::as_stream(stream)))
+                                            (int)n_out, n_out_dev, cin, cout, (float *)out_feats, ranges, n_ranges, fd::as_stream(stream)))
             return fd::check_launch("fd_spconv_apply(compact)");
     }
     if (dtype == 1 && fd::tuning(fd::kTuneBf16GP) >= 0) {
         // bf16: register accumulators + LDS-shared weights (fd_spconv_bf16.hip); 16 input channels read the tap-pair weight layout
         const void *w = cin == 16 ? (const void *)((const char *)wpacked + (size_t)K * cin * cout * 2) : wpacked;
-        // SubM convolutions of the wide levels can take the variant that stages the input rows of a tile in an LDS window
-        // (fd_spconv_bf16w.hip).  Opt-in ("bf16_win" = 1): bit-identical results, and measured NO faster -- the phase trace shows
-        // these kernels bound by the LDS weight-fragment traffic of lock-stepped waves, not by the gather
-        if (fd::tuning(fd::kTuneBf16Win) > 0 && fd::tuning(fd::kTuneBf16RG) <= 0 &&
-            fd::spconv_bf16_win_dispatch(in_feats, w, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out, n_out_dev, n_expected, cin, cout, out_feats,
-                                         fd::as_stream(stream)))
-            return fd::check_launch("fd_spconv_apply(bf16 window)");
         if (fd::spconv_bf16_ws_dispatch(in_feats, w, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out, n_out_dev, n_expected, cin, cout, out_feats,
                                         fd::as_stream(stream)))
             return fd::check_launch("fd_spconv_apply(bf16 ws)");

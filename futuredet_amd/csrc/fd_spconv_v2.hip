@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
                                                           const float *__restrict__ bias, const float *__restrict__ residual, int relu,
                                                           const int *__restrict__ nbr, int64_t nbr_stride, int K, int n_out,
                                                           const int *__restrict__ n_out_dev, float *__restrict__ out, unsigned in_bytes,
-                                                          const int *__restrict__ ranges, int rows_per_range, int out_planes) {
+                                                          const int *__restrict__ ranges, int rows_per_range) {
     constexpr int NB = COUT / 16, NC = CIN / 16;
     constexpr int WC = NB == 8 ? 4 : (NB >= 2 ? 2 : 1);  // column splits across the 4 waves (64 columns: 2 x 32)
     constexpr int NBW = NB / WC;          // 16-column blocks per wave
@@ -414,17 +414,7 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
             }
         }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (out_planes) {
-            // the consumer is a split-operand layer (fd_spconv_split.hip): row = [h | m | l] bf16 planes, x = h + m + l exactly
-            fd::fd_bf16x4 h, m, l;
-            fd::split3x4((fd::fd_f32x4){v.x, v.y, v.z, v.w}, h, m, l);
-            unsigned short *op = reinterpret_cast<unsigned short *>(out) + (int64_t)row * (3 * COUT) + 4 * c4;
-            *reinterpret_cast<fd::fd_bf16x4 *>(op) = h;
-            *reinterpret_cast<fd::fd_bf16x4 *>(op + COUT) = m;
-            *reinterpret_cast<fd::fd_bf16x4 *>(op + 2 * COUT) = l;
-        } else {
-            reinterpret_cast<float4 *>(out + (int64_t)row * COUT)[c4] = v;
-        }
+        reinterpret_cast<float4 *>(out + (int64_t)row * COUT)[c4] = v;
     }
     __syncthreads();  // the next chunk re-uses the list and the accumulator tile
     if (chunk == 0) FD_T(6);
@@ -451,7 +441,7 @@ inline size_t lds_request(int cin, int cout, int tm) {
 template <int CIN, int COUT, int TM, int DEPTH>
 int launch_compact(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
                    int64_t nbr_stride, int K, int n_out, const int *n_out_dev, float *out, unsigned in_bytes, const int *ranges, int n_ranges,
-                   int out_planes, hipStream_t stream) {
+                   hipStream_t stream) {
     const size_t lds_req = lds_request(CIN, COUT, TM);
     static std::atomic<uint64_t> lds_set{0};  // devices on which this instantiation has its LDS limit raised
     auto kern = spconv_f32_compact<CIN, COUT, TM, DEPTH>;
@@ -470,7 +460,7 @@ int launch_compact(const float *in, const void *wp, const float *bias, const flo
         if (!n_out_dev) n_ranges = (n_out + rows_per - 1) / rows_per;  // (with a device count the kernel makes the split over n_ranges)
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)n_ranges), dim3(256), lds_req, stream, in, (const float4 *)wp, bias, residual, relu, nbr, nbr_stride, K,
-                       n_out, n_out_dev, out, in_bytes, ranges, rows_per, out_planes);
+                       n_out, n_out_dev, out, in_bytes, ranges, rows_per);
     return 1;
 }
 
@@ -603,15 +593,14 @@ extern "C" int fd_spconv_ranges(const int32_t *nbr, int64_t nbr_stride, int K, i
 namespace fd {
 // returns 1 when launched, 0 when this shape is not covered (caller falls back to the register kernel)
 int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr,
-                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, const int *n_out_dev, int cin, int cout, void *out_,
-                                const int *ranges, int n_ranges, int out_planes, hipStream_t stream) {
-    float *out = reinterpret_cast<float *>(out_);
+                                int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, const int *n_out_dev, int cin, int cout, float *out,
+                                const int *ranges, int n_ranges, hipStream_t stream) {
     // (input row << 8 | local row) must fit an int32 and the feature matrix a 31-bit buffer range
     if (n_in_bound >= (1ll << 23) || n_in_bound * cin * 4 >= (1ll << 31)) return 0;
     const unsigned in_bytes = (unsigned)(n_in_bound * cin * 4);
     const int dsel = fd::tuning(fd::kTuneV2Depth), tsel = fd::tuning(fd::kTuneV2TM);  // tuning overrides
 #define FD_LAUNCH(CI, CO, T, D) \
-    launch_compact<CI, CO, T, D>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, out, in_bytes, ranges, n_ranges, out_planes, stream)
+    launch_compact<CI, CO, T, D>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, out, in_bytes, ranges, n_ranges, stream)
 #define FD_CASE(CI, CO, DDEF, TDEF)                                  \
     if (cin == CI && cout == CO) {                                   \
         const int dd = dsel ? dsel : DDEF, tt = tsel ? tsel : TDEF;  \

@@ -105,26 +105,15 @@ class VoxelNet(SingleStageDetector):
         self.__dict__.pop("_graphs", None)
         return super()._apply(fn, *a, **kw)
 
-    def set_precision(self, dtype=torch.float32, channels_last=None, fp32_arith=None):
+    def set_precision(self, dtype=torch.float32, channels_last=None):
         """fp32 (default) or bf16 conv features/weights with fp32 accumulation; voxelizer, indexes, decode and
-        NMS always stay fp32/int.  ``fp32_arith`` ("native" | "split", fp32 only): "split" computes the wide convolutions on the
-        bf16 matrix pipe with three-piece (3 x bf16) operands and fp32 accumulation -- fp32 storage and fp32-class error at 6/16 of
-        the fp32 MFMA time (sparse: fd_spconv_split.hip; dense Winograd GEMMs: fd_conv2d_wino_pc.hip)."""
+        NMS always stay fp32/int.  ``channels_last`` is accepted for compatibility and ignored: the neck and head run on
+        the hand-written NHWC convolutions in both dtypes, so the BEV map is always written channels-last."""
         self.__dict__.pop("_graphs", None)
-        if fp32_arith is not None:
-            assert fp32_arith in ("native", "split"), fp32_arith
-            for m in (self.backbone, self.neck, self.bbox_head):
-                if hasattr(m, "fp32_arith") or m is self.backbone:
-                    m.fp32_arith = fp32_arith
-        if channels_last is None:
-            channels_last = False  # measured on MI355X: MIOpen is as fast or faster on NCHW for these shapes
         self.backbone.compute_dtype = dtype
-        # the neck/head run on the hand-written NHWC MFMA convolutions (bf16 and fp32), so the BEV map is written channels-last
-        self.backbone.dense_channels_last = channels_last or dtype == torch.bfloat16 or getattr(self.neck, "use_hip_conv", False)
+        self.backbone.dense_channels_last = True
         self.neck.compute_dtype = dtype
-        self.neck.channels_last = channels_last
         self.bbox_head.compute_dtype = dtype
-        self.bbox_head.channels_last = channels_last
         return self
 
     def extract_feat(self, data):
@@ -306,8 +295,7 @@ class StaticStep(object):
 
     def _version_key(self):
         m = self.model
-        return (weights_version(m), getattr(m.backbone, "compute_dtype", None), m.neck.compute_dtype, getattr(m.neck, "use_hip_conv", None),
-                getattr(m.backbone, "fp32_arith", None), getattr(m.backbone, "split_min_channels", None))
+        return (weights_version(m), getattr(m.backbone, "compute_dtype", None), m.neck.compute_dtype)
 
     def _load(self, clouds):
         assert len(clouds) == self.B
@@ -423,15 +411,11 @@ class PointPillars(SingleStageDetector):
     def __init__(self, reader, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None):
         super().__init__(reader, backbone, neck, bbox_head, train_cfg, test_cfg, pretrained)
 
-    def set_precision(self, dtype=torch.float32, channels_last=None, fp32_arith=None):
-        assert fp32_arith in (None, "native"), "PointPillars has no sparse convolution: only the native fp32 arithmetic applies"
-        channels_last = bool(channels_last)
+    def set_precision(self, dtype=torch.float32, channels_last=None):
         self.reader.compute_dtype = dtype
-        self.backbone.dense_channels_last = channels_last or dtype == torch.bfloat16 or getattr(self.neck, "use_hip_conv", False)
+        self.backbone.dense_channels_last = True
         self.neck.compute_dtype = dtype
-        self.neck.channels_last = channels_last
         self.bbox_head.compute_dtype = dtype
-        self.bbox_head.channels_last = channels_last
         return self
 
     def extract_feat(self, data):

@@ -1,11 +1,13 @@
 """CenterHead (det3d/models/bbox_heads/center_head.py:81-174 SepHead, :232-390 CenterHead, :542-747 predict).
 
 Constructor signature and state_dict keys follow the reference (shared_conv.{0,1}.*, tasks.{i}.{reg,height,dim,
-rot,vel,hm}.{0,1,3}.*, tasks.{i}.forecast_conv.*, bev_conv.*).  Only the branches reachable from the shipped
-configs exist: "standard" (n0 / n3: one task, velocity split per timestep) and "dense" (n3dtf / n3dtfm: one task
-per timestep, optional chained forecast features and BEV-map branch).  predict() runs the HIP decode + rotated
-NMS (fd_centerpoint_decode) for all (sample, heat-map) groups in one call; the loss is training-only and out of
-scope of this path.
+rot,vel,hm}.{0,1,3}.*, tasks.{i}.forecast_conv.*, bev_conv.*).  Branches: "standard" (n0 / n3: one task, velocity split
+per timestep), "dense" (n3dtf / n3dtfm: one task per timestep, optional chained forecast features and BEV-map branch) and
+"classify" (the reference constructor's DEFAULT, center_head.py:253,329-330,589-595: one task per timestep with a three-class
+heat-map whose channel maximum is the score map); ``reverse`` / ``sparse`` / ``wide_head`` / ``dcn_head`` / ``two_stage`` are
+False in every shipped config and raise.  In eval mode on the device the head runs on the convolution plan of dense_bf16.py
+(the only device path; a head it cannot take raises); predict() runs the HIP decode + rotated NMS (fd_centerpoint_decode) for
+all (sample, heat-map) groups in one call; the loss is training-only and out of scope of this path.
 """
 import copy
 import logging
@@ -14,7 +16,7 @@ import torch
 from torch import nn
 
 from . import hip_ops
-from .nn_utils import FoldedConv, Sequential, fold_stack, kaiming_init, weights_version
+from .nn_utils import Sequential, kaiming_init, weights_version
 from .registry import HEADS
 
 
@@ -48,16 +50,6 @@ class SepHead(nn.Module):
                     if isinstance(m, nn.Conv2d):
                         kaiming_init(m)
             self.__setattr__(head, fc)
-        self._fused = None
-        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate_caches())
-
-    def invalidate_caches(self):
-        self._fused = None
-        self.__dict__.pop("_wv_tensors", None)
-
-    def _apply(self, fn, *a, **kw):
-        self.invalidate_caches()
-        return super()._apply(fn, *a, **kw)
 
     def forward_modules(self, x):
         ret = {}
@@ -68,60 +60,11 @@ class SepHead(nn.Module):
             ret[head] = self.__getattr__(head)(x)
         return ret
 
-    def _fuse(self, dtype, channels_last):
-        """All heads read the same map: their first convs become one conv (Cout = 64*nheads, BN folded, ReLU) and
-        their final convs one block-diagonal conv, so a task costs 2 launches instead of 12."""
-        key = (dtype, channels_last, next(self.parameters()).device, weights_version(self))
-        if self._fused is not None and self._fused[0] == key:
-            return self._fused[1:]
-        names = list(self.heads)
-        pre = fold_stack(self.forecast_conv, dtype, channels_last) if self.forecast_feature else []
-        firsts, finals = [], []
-        for h in names:
-            mods = list(getattr(self, h)._modules.values())
-            st = fold_stack(mods, torch.float32, False)
-            assert len(st) == 2, "fusion assumes num_conv == 2 (all shipped configs)"
-            firsts.append(st[0])
-            finals.append(st[1])
-        w1 = torch.cat([f.weight for f in firsts], 0)
-        b1 = torch.cat([f.bias for f in firsts], 0)
-        hc = firsts[0].weight.shape[0]
-        couts = [f.weight.shape[0] for f in finals]
-        k = finals[0].weight.shape[-1]
-        w2 = torch.zeros((sum(couts), hc * len(names), k, k), dtype=torch.float32, device=w1.device)
-        o = 0
-        for i, f in enumerate(finals):
-            w2[o:o + couts[i], i * hc:(i + 1) * hc] = f.weight
-            o += couts[i]
-        b2 = torch.cat([f.bias for f in finals], 0)
-        mf = torch.channels_last if channels_last else torch.contiguous_format
-        conv1 = (w1.to(dtype).contiguous(memory_format=mf), b1.to(dtype), firsts[0].padding)
-        conv2 = (w2.to(dtype).contiguous(memory_format=mf), b2.to(dtype), finals[0].padding)
-        self._fused = (key, pre, conv1, conv2, names, couts)
-        return self._fused[1:]
-
-    def forward_fused(self, x, dtype, channels_last):
-        pre, (w1, b1, p1), (w2, b2, p2), names, couts = self._fuse(dtype, channels_last)
-        ret = {}
-        for conv in pre:
-            x = conv(x)
-        if self.forecast_feature:
-            ret["feats"] = x
-        y = FoldedConv(w1, b1, 1, p1, True)(x)
-        z = FoldedConv(w2, b2, 1, p2, False)(y)
-        o = 0
-        for name, c in zip(names, couts):
-            ret[name] = z[:, o:o + c]
-            o += c
-        return ret
-
     def forward(self, x):
         return self.forward_modules(x)
 
 
-
 def _drop_caches(module, incompatible_keys=None):
-    module._folded = None
     module._plan = None
     module.__dict__.pop("_wv_tensors", None)
 
@@ -133,8 +76,7 @@ class CenterHead(nn.Module):
                  two_stage=False, reverse=False, sparse=False, dense=False, bev_map=False, forecast_feature=False,
                  classify=True, wide_head=False):
         super().__init__()
-        unsupported = dict(dcn_head=dcn_head, two_stage=two_stage, reverse=reverse, sparse=sparse, classify=classify,
-                           wide_head=wide_head)
+        unsupported = dict(dcn_head=dcn_head, two_stage=two_stage, reverse=reverse, sparse=sparse, wide_head=wide_head)
         on = [k for k, v in unsupported.items() if v]
         if on:
             raise NotImplementedError("CenterHead options %s are False in every shipped centerpoint config and are not "
@@ -142,7 +84,7 @@ class CenterHead(nn.Module):
         self.two_stage, self.reverse, self.sparse, self.dense = two_stage, reverse, sparse, dense
         self.bev_map, self.forecast_feature, self.classify, self.wide_head = bev_map, forecast_feature, classify, wide_head
         self.target_timesteps = 7
-        self.standard = not dense
+        self.standard = not (dense or classify)  # center_head.py:268-271
         num_classes = [len(t["class_names"]) for t in tasks]
         self.class_names = [t["class_names"] for t in tasks]
         self.code_weights = code_weights
@@ -158,6 +100,8 @@ class CenterHead(nn.Module):
         self.tasks = nn.ModuleList()
         if self.dense:
             self.num_classes = self.timesteps * [1]
+        if self.classify:  # center_head.py:329-330 (after the dense rule, as there)
+            self.num_classes = self.timesteps * [3]
         if self.bev_map:
             c = share_conv_channel
             self.bev_conv = nn.Sequential(
@@ -169,17 +113,14 @@ class CenterHead(nn.Module):
         for i, num_cls in enumerate(self.num_classes):
             heads = copy.deepcopy(dict(common_heads))
             for head in heads.keys():
-                if not self.dense and head in ["vel", "rvel"]:
+                if self.standard and head in ["vel", "rvel"]:  # center_head.py:355
                     heads[head] = (self.timesteps * heads[head][0], heads[head][1])
             heads.update(dict(hm=(num_cls, num_hm_conv)))
             cin = 2 * share_conv_channel if (i != 0 and self.forecast_feature) else share_conv_channel
             self.tasks.append(SepHead(cin, heads, bn=True, init_bias=init_bias, final_kernel=3, two_stage=self.two_stage,
                                       forecast_feature=self.forecast_feature, wide_head=self.wide_head))
         self.compute_dtype = torch.float32
-        self.channels_last = False
-        self._folded = None
         self._plan = None
-        self.use_hip_conv = True
         self.register_load_state_dict_post_hook(_drop_caches)
         self.logger.info("Finish CenterHead Initialization")
 
@@ -203,41 +144,16 @@ class CenterHead(nn.Module):
         return ret_dicts
 
     def forward(self, x, bev_map=None, *kwargs):
-        if self.training:
+        if self.training or not x.is_cuda:
             return self.forward_modules(x, bev_map)
-        if x.is_cuda and self.use_hip_conv and self.compute_dtype in (torch.bfloat16, torch.float32):
-            ver = (weights_version(self), self.compute_dtype)
-            if self._plan is None or self._plan[0] != ver:
-                from .dense_bf16 import HeadPlan
+        if self.compute_dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("CenterHead: compute_dtype must be float32 or bfloat16, got %s" % (self.compute_dtype,))
+        ver = (weights_version(self), self.compute_dtype)
+        if self._plan is None or self._plan[0] != ver:
+            from .dense_bf16 import HeadPlan
 
-                try:
-                    self._plan = (ver, HeadPlan(self, self.compute_dtype))
-                except ValueError:
-                    self._plan = (ver, None)
-            if self._plan[1] is not None:
-                return self._plan[1](x.to(self.compute_dtype).permute(0, 2, 3, 1).contiguous(), bev_map)
-        dt, cl = self.compute_dtype, self.channels_last
-        key = (dt, cl, next(self.parameters()).device, weights_version(self.shared_conv) + (weights_version(self.bev_conv) if self.bev_map else 0))
-        if self._folded is None or self._folded[0] != key:
-            shared = fold_stack(self.shared_conv, dt, cl)
-            bev = fold_stack(self.bev_conv, dt, cl) if self.bev_map else None
-            self._folded = (key, shared, bev)
-        _, shared, bev = self._folded
-        x = x.to(dt)
-        if cl:
-            x = x.contiguous(memory_format=torch.channels_last)
-        for conv in shared:
-            x = conv(x)
-        if self.bev_map:
-            y = bev_map.to(dt)
-            for conv in bev:
-                y = conv(y)
-            x = x + y
-        rets = []
-        for i, task in enumerate(self.tasks):
-            inp = torch.cat([x, rets[i - 1]["feats"]], dim=1) if (i != 0 and self.forecast_feature) else x
-            rets.append(task.forward_fused(inp, dt, cl))
-        return rets
+            self._plan = (ver, HeadPlan(self, self.compute_dtype))  # raises ValueError for a head the kernels do not take
+        return self._plan[1](x.to(self.compute_dtype).permute(0, 2, 3, 1).contiguous(), bev_map)
 
     def loss(self, example, preds_dicts, **kwargs):
         raise NotImplementedError("training losses (center_head.py:396-539) are outside the inference hot path")
@@ -251,8 +167,8 @@ class CenterHead(nn.Module):
             if len(vels) == 1:
                 vels = self.target_timesteps * vels
             return [pd], vels, [0] * len(vels), [1] * self.target_timesteps
-        vels = [pd["vel"] for pd in preds_dicts]  # center_head.py:606-607
-        return list(preds_dicts), vels, list(range(len(preds_dicts))), list(self.num_classes)
+        vels = [pd["vel"] for pd in preds_dicts]  # center_head.py:606-607 (dense), :589-595 (classify: one class per step after the channel max)
+        return list(preds_dicts), vels, list(range(len(preds_dicts))), [1] * len(preds_dicts) if self.classify else list(self.num_classes)
 
     @torch.no_grad()
     def predict_packed(self, preds_dicts, test_cfg):
@@ -266,7 +182,8 @@ class CenterHead(nn.Module):
             raise NotImplementedError("only rotated NMS is configured in the shipped test_cfg")
         zbuf, _, where = raws[0]
         T, B, H, W, C = zbuf.shape
-        assert where["hm"][1] == 1, "single-class heat-maps (every shipped task has one class)"
+        hm_channels = where["hm"][1]
+        assert hm_channels == 1 or self.classify, "multi-class heat-maps are decoded as their channel maximum only in the classify mode (center_head.py:589-595)"
         if self.standard:  # center_head.py:559-570: one task, step s = its boxes + velocity channels 2s, 2s+1 (all steps share them when timesteps == 1)
             G = 1
             # center_head.py:559-565 emits one step per velocity pair: ``timesteps`` of them when the head forecasts, else
@@ -281,7 +198,7 @@ class CenterHead(nn.Module):
             S = T
             step_group = list(range(T))
             step_vel = [0] * T
-            num_classes = list(self.num_classes)
+            num_classes = [1] * T if self.classify else list(self.num_classes)
         labels, acc = [], 0
         for ncls in num_classes:
             labels.append(acc)
@@ -291,7 +208,7 @@ class CenterHead(nn.Module):
         if ck not in cache:  # labels do not depend on the data (built in the eager set-up pass, before any graph capture)
             cache[ck] = torch.as_tensor(labels, dtype=torch.int64, device=zbuf.device).view(1, S, 1).expand(B, S, ck[3]).contiguous()
         flat = zbuf[:G].reshape(G * B, H, W, C)
-        cfg = hip_ops.make_decode_cfg(H, W, test_cfg)
+        cfg = hip_ops.make_decode_cfg(H, W, test_cfg, hm_channels=hm_channels)
         views = [hip_ops.nhwc_channel_view(flat, where[k][0]) for k in ("hm", "reg", "height", "dim", "rot")]
         boxes7, scores, cell, count = hip_ops.centerpoint_decode_views(views, G * B, cfg, zbuf.device)
         return hip_ops.assemble_detections(boxes7, scores, cell, count, hip_ops.nhwc_channel_view(flat, where["vel"][0]), B, cfg.nms_post_max,
@@ -309,10 +226,11 @@ class CenterHead(nn.Module):
         if test_cfg.get("per_class_nms", False) or test_cfg.get("circular_nms", False):
             raise NotImplementedError("only rotated NMS is configured in the shipped test_cfg")
         srcs, vels, step_group, num_classes = self._groups(preds_dicts)
-        B, _, H, W = srcs[0]["hm"].shape
-        assert all(s["hm"].shape[1] == 1 for s in srcs), "single-class heat-maps (every shipped task has one class)"
+        B, hm_channels, H, W = srcs[0]["hm"].shape
+        assert all(s["hm"].shape[1] == hm_channels for s in srcs) and (hm_channels == 1 or self.classify), \
+            "multi-class heat-maps are decoded as their channel maximum only in the classify mode (center_head.py:589-595)"
         f = lambda k: torch.cat([s[k].float() for s in srcs], 0).contiguous() if len(srcs) > 1 else srcs[0][k].float().contiguous()  # noqa: E731
-        cfg = hip_ops.make_decode_cfg(H, W, test_cfg)
+        cfg = hip_ops.make_decode_cfg(H, W, test_cfg, hm_channels=hm_channels)
         boxes7, scores, cell, count = hip_ops.centerpoint_decode(f("hm"), f("reg"), f("height"), f("dim"), f("rot"), cfg)
         post = cfg.nms_post_max
         G = len(srcs)

@@ -76,32 +76,6 @@ class _Workspace(object):
 
 workspace = _Workspace()
 _DT = {torch.float32: 0, torch.bfloat16: 1}
-# Split-operand fp32 arithmetic (three bf16 pieces per operand, six bf16 MFMAs, fp32 accumulate; fd_spconv_split.hip).  Feature
-# matrices between split layers are stored as "planes": row = [h | m | l] bf16, x = h + m + l exactly; here a bfloat16 tensor
-# [n, 3 * C].  F32_SPLIT is the ``dtype`` key of the packed weights; spconv_apply's ``mode`` names the storage formats:
-#   "p2p" planes -> planes (residual planes), "p2f" planes -> float32 (residual float32),
-#   "f2p" float32 -> planes with NATIVE fp32 arithmetic (the layer in front of a split region; weights packed as float32)
-F32_SPLIT = "f32_split"
-_DT[F32_SPLIT] = 2
-_SPLIT_MODES = {"p2p": 2, "p2f": 3, "f2p": 4}
-
-
-def rows_to_planes(x, n_dev=None):
-    """float32 [n, C] -> planes (bfloat16 [n, 3 C]); exact (fd_rows_to_planes)."""
-    x = _dev(x, "x", torch.float32)
-    n, c = x.shape
-    out = torch.empty((max(n, 1), 3 * c), dtype=torch.bfloat16, device=x.device)[:n]
-    check(_lib.load().fd_rows_to_planes(_p(x), n, c, _p(n_dev), _p(out), _stream()), "fd_rows_to_planes")
-    return out
-
-
-def planes_to_rows(p, n_dev=None):
-    """planes (bfloat16 [n, 3 C]) -> float32 [n, C]; exact (fd_planes_to_rows)."""
-    p = _dev(p, "p", torch.bfloat16)
-    n, c3 = p.shape
-    out = torch.zeros((max(n, 1), c3 // 3), dtype=torch.float32, device=p.device)[:n]
-    check(_lib.load().fd_planes_to_rows(_p(p), n, c3 // 3, _p(n_dev), _p(out), _stream()), "fd_planes_to_rows")
-    return out
 
 
 def set_tuning(name, value):
@@ -372,21 +346,12 @@ def pack_spconv_weight(w_kio, dtype=torch.float32):
     return host.to(dev)
 
 
-def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=False, out=None, balanced=None, mode=None):
-    """``mode`` (None | "p2p" | "p2f" | "f2p"): storage formats of a split-operand region, see F32_SPLIT above."""
+def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=False, out=None, balanced=None):
     L = _lib.load()
     feats = _dev(feats, "feats")
     dt = _DT[feats.dtype]
     cin = feats.shape[1]
     out_dtype, out_cols = feats.dtype, cout
-    if mode is not None:
-        dt = _SPLIT_MODES[mode]
-        want_in = torch.float32 if mode == "f2p" else torch.bfloat16
-        if feats.dtype != want_in:
-            raise FutureDetHipError("spconv_apply mode %s takes %s features, got %s" % (mode, want_in, feats.dtype))
-        if mode != "f2p":
-            cin = feats.shape[1] // 3
-        out_dtype, out_cols = (torch.float32, cout) if mode == "p2f" else (torch.bfloat16, 3 * cout)
     K, nstride = nbr.shape
     if out is None:
         out = torch.empty((max(n_out, 1), out_cols), dtype=out_dtype, device=feats.device)[:n_out]
@@ -397,7 +362,7 @@ def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=Fal
     # used once) take equal row counts -- see fd_spconv_num_ranges for the measurements.
     ranges, n_ranges = None, 0
     n_dev, n_expected = getattr(nbr, "n_dev", None), getattr(nbr, "n_expected", 0)  # static index: n_out is a capacity
-    if dt in (0, 4) and n_out > 0:
+    if dt == 0 and n_out > 0:
         if balanced is None:
             balanced = K == 27 and cin == cout and bool(L.fd_spconv_wants_balanced_ranges(cin, cout, 0))
         if balanced == "tiles":      # one 128-row tile per workgroup (tuning comparisons)
@@ -559,8 +524,11 @@ def conv2d_wino_f32_num_tiles():
 
 
 # ------------------------------------------------------------------------------------------------ decode / NMS
-def make_decode_cfg(H, W, test_cfg):
+def make_decode_cfg(H, W, test_cfg, hm_channels=1):
+    """``hm_channels`` > 1: the score of a cell is the maximum over that many heat-map channels (CenterHead's ``classify``
+    mode, center_head.py:589-595: torch.max(hm, dim=1) before the sigmoid)."""
     c = DecodeCfg()
+    c.hm_channels = int(hm_channels)
     c.H, c.W = int(H), int(W)
     c.out_size_factor = float(test_cfg["out_size_factor"])
     c.voxel_x, c.voxel_y = float(test_cfg["voxel_size"][0]), float(test_cfg["voxel_size"][1])
@@ -728,30 +696,6 @@ def pillar_scatter(feats, coors4, n_dev, batch_size, ny, nx, out_dtype=None, cha
     sb, sc, sy, sx = out.stride()
     check(L.fd_pillar_scatter(_p(feats), C, feats.stride(0), _DT[feats.dtype], _p(coors4), _p(n_dev), M, batch_size, ny, nx,
                               _p(out), _DT[out.dtype], sb, sc, sy, sx, int(bool(zero_first)), _stream()), "fd_pillar_scatter")
-    return out
-
-
-def bias_act_nchw_(x, bias, relu, out=None):
-    """Per-channel bias (+ReLU) on a contiguous NCHW float32 device tensor (fd_bias_act_nchw_f32): in place, or into
-    ``out`` = a channel slice [B, C, H, W] of a wider contiguous NCHW buffer (the concat destination)."""
-    B, C, H, W = x.shape
-    if out is None:
-        check(_lib.load().fd_bias_act_nchw_f32(_p(x), _p(bias), B, C, H * W, int(bool(relu)), None, 0, _stream()), "fd_bias_act_nchw_f32")
-        return x
-    assert out.shape == x.shape and out.stride()[1:] == (H * W, W, 1)
-    check(_lib.load().fd_bias_act_nchw_f32(_p(x), _p(bias), B, C, H * W, int(bool(relu)), _p(out), out.stride(0), _stream()),
-          "fd_bias_act_nchw_f32")
-    return out
-
-
-def shuffle_bias_act(y, bias, cout, k, relu, out=None):
-    """fd_shuffle_bias_act_f32: y [B, k*k*cout, H, W] -> [B, cout, H*k, W*k] (+bias, +ReLU), optionally into a channel slice."""
-    B, _, H, W = y.shape
-    if out is None:
-        out = torch.empty((B, cout, H * k, W * k), dtype=torch.float32, device=y.device)
-    assert out.shape == (B, cout, H * k, W * k) and out.stride()[1:] == (H * k * W * k, W * k, 1)
-    check(_lib.load().fd_shuffle_bias_act_f32(_p(y), _p(bias), B, cout, H, W, k, int(bool(relu)), _p(out), out.stride(0), _stream()),
-          "fd_shuffle_bias_act_f32")
     return out
 
 

@@ -26,7 +26,7 @@ class MapView(ctypes.Structure):
 class DecodeCfg(ctypes.Structure):
     _fields_ = [("H", c_int), ("W", c_int), ("out_size_factor", c_float), ("voxel_x", c_float), ("voxel_y", c_float),
                 ("pc_x", c_float), ("pc_y", c_float), ("score_threshold", c_float), ("center_range", c_float * 6),
-                ("nms_iou_threshold", c_float), ("nms_pre_max", c_int), ("nms_post_max", c_int)]
+                ("nms_iou_threshold", c_float), ("nms_pre_max", c_int), ("nms_post_max", c_int), ("hm_channels", c_int)]
 
 
 class IndexLevel(ctypes.Structure):  # struct fd_index_level
@@ -97,7 +97,6 @@ SIGNATURES = {
                                  c_void_p, c_int, c_void_p]),
     "fd_pillar_scatter": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_int,
                                   c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
-    "fd_bias_act_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_i64, c_int, c_void_p, c_i64, c_void_p]),
     "fd_forecast_chains": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_det_to_global_boxes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -108,9 +107,6 @@ SIGNATURES = {
     "fd_index_pyramid_coords": (c_int, [c_int, c_int, ctypes.POINTER(IndexLevel), c_void_p]),
     "fd_rows_place": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p,
                               c_int, c_int, c_void_p]),
-    "fd_shuffle_bias_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
-    "fd_rows_to_planes": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
-    "fd_planes_to_rows": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "fd_sweep_assemble_workspace_bytes": (c_size_t, [c_i64]),
     "fd_sweep_assemble": (c_int, [c_void_p, c_int, c_int, c_i64, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

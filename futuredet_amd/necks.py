@@ -1,21 +1,21 @@
 """RPN neck (det3d/models/necks/rpn.py:22-159).  Same constructor, same state_dict keys
 (blocks.{i}.{1,4,...}.weight, deblocks.{i}.0.weight, ...).  In eval mode the stack runs with BatchNorm folded
 into the convolutions (ZeroPad2d merged into the conv padding) on the hand-written MFMA convolutions (dense_bf16.py:
-NHWC, bf16 or fp32, concat and transposed convolution written in place); ``use_hip_conv = False`` selects the
-PyTorch-ROCm (MIOpen) path kept for comparison; training mode keeps the plain module stack."""
+NHWC, bf16 or fp32, concat and transposed convolution written in place).  That plan is the ONLY eval-mode device path: a stack
+it cannot take (a channel count that is not a multiple of the kernels' granule) raises instead of running anywhere else.
+Training mode and host tensors (the CPU tests of the state-dict surface) run the plain nn.Module stack, forward_modules."""
 import logging
 
 import numpy as np
 import torch
 from torch import nn
 
-from .nn_utils import Sequential, build_norm_layer, fold_stack, weights_version
+from .nn_utils import Sequential, build_norm_layer, weights_version
 from .registry import NECKS
 
 
 
 def _drop_caches(module, incompatible_keys=None):
-    module._folded = None
     module._plan = None
     module.__dict__.pop("_wv_tensors", None)
 
@@ -55,10 +55,7 @@ class RPN(nn.Module):
         self.blocks = nn.ModuleList(blocks)
         self.deblocks = nn.ModuleList(deblocks)
         self.compute_dtype = torch.float32
-        self.channels_last = False
-        self._folded = None
         self._plan = None
-        self.use_hip_conv = True
         self.register_load_state_dict_post_hook(_drop_caches)
         (logger or logging.getLogger("RPN")).info("Finish RPN Initialization")
 
@@ -99,54 +96,16 @@ class RPN(nn.Module):
         _drop_caches(self)
         return super()._apply(fn, *a, **kw)
 
-    def _fold(self):
-        key = (self.compute_dtype, self.channels_last, next(self.parameters()).device, weights_version(self))
-        if self._folded is None or self._folded[0] != key:
-            blocks = [fold_stack(b._modules.values(), self.compute_dtype, self.channels_last) for b in self.blocks]
-            deblocks = [fold_stack(d._modules.values(), self.compute_dtype, self.channels_last) for d in self.deblocks]
-            self._folded = (key, blocks, deblocks)
-        return self._folded[1], self._folded[2]
-
     def forward(self, x):
-        if self.training:
+        if self.training or not x.is_cuda:
             return self.forward_modules(x)
-        if x.is_cuda and self.use_hip_conv and self.compute_dtype in (torch.bfloat16, torch.float32):
-            # hand-written MFMA convolutions on NHWC activations (bf16 or fp32); returned as an NCHW-shaped view of the
-            # NHWC buffer.  A stack with a channel count the kernels do not take (not a multiple of 32 / 16) stays on the
-            # PyTorch path below.
-            ver = (weights_version(self), self.compute_dtype)
-            if self._plan is None or self._plan[0] != ver:
-                from .dense_bf16 import RPNPlan
+        if self.compute_dtype not in (torch.bfloat16, torch.float32):
+            raise ValueError("RPN: compute_dtype must be float32 or bfloat16, got %s" % (self.compute_dtype,))
+        # hand-written MFMA convolutions on NHWC activations (bf16 or fp32); returned as an NCHW-shaped view of the NHWC buffer
+        ver = (weights_version(self), self.compute_dtype)
+        if self._plan is None or self._plan[0] != ver:
+            from .dense_bf16 import RPNPlan
 
-                try:
-                    self._plan = (ver, RPNPlan(self, self.compute_dtype))
-                except ValueError:
-                    self._plan = (ver, None)
-            if self._plan[1] is not None:
-                xin = x.to(self.compute_dtype).permute(0, 2, 3, 1).contiguous()  # no copy for a channels-last BEV map
-                return self._plan[1](xin).permute(0, 3, 1, 2)
-        blocks, deblocks = self._fold()
-        x = x.to(self.compute_dtype)
-        if self.channels_last:
-            x = x.contiguous(memory_format=torch.channels_last)
-        # the deblock outputs are written straight into their channel slices of the concatenated map (the epilogue of a
-        # deblock's last conv takes the slice as destination): no torch.cat pass
-        couts = [d[-1].weight.shape[1 if d[-1].transposed else 0] for d in deblocks]
-        cat, co = None, 0
-        for i, stack in enumerate(blocks):
-            for conv in stack:
-                x = conv(x)
-            j = i - self.first_up
-            if j >= 0:
-                y = x
-                for conv in deblocks[j][:-1]:
-                    y = conv(y)
-                last = deblocks[j][-1]
-                if cat is None:
-                    k = last.weight.shape[-1]
-                    H, W = (y.shape[2] * k, y.shape[3] * k) if last.transposed else ((y.shape[2] - k) // last.stride + 1,
-                                                                                     (y.shape[3] - k) // last.stride + 1)
-                    cat = torch.empty((y.shape[0], sum(couts), H, W), dtype=y.dtype, device=y.device)
-                last(y, out=cat[:, co:co + couts[j]])
-                co += couts[j]
-        return cat if cat is not None else x
+            self._plan = (ver, RPNPlan(self, self.compute_dtype))  # raises ValueError for a stack the kernels do not take
+        xin = x.to(self.compute_dtype).permute(0, 2, 3, 1).contiguous()  # no copy for a channels-last BEV map
+        return self._plan[1](xin).permute(0, 3, 1, 2)

@@ -4,7 +4,6 @@ build_norm_layer : det3d/models/utils/norm.py:59-108  ("BN"->BatchNorm2d, "BN1d"
 Sequential.add() : det3d/models/utils/misc.py:22-95   (children named "0","1",...)
 """
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 _NORMS = {"BN": ("bn", nn.BatchNorm2d), "BN1d": ("bn1d", nn.BatchNorm1d), "GN": ("gn", nn.GroupNorm)}
@@ -103,43 +102,12 @@ def fold_bn(w, b, bn, out_axis):
 
 
 class FoldedConv(object):
-    """One conv (+folded BN) (+ReLU) of a dense stack, ready for F.conv2d / F.conv_transpose2d."""
+    """One conv (+folded BN) (+ReLU) of a dense stack: the folded float32 weight / bias and the geometry, as the convolution
+    plan (dense_bf16.py) packs them.  (tools/torch_dense_ab.py runs the same records through F.conv2d for A/B timing.)"""
 
     def __init__(self, weight, bias, stride, padding, relu, transposed=False):
         self.weight, self.bias, self.stride, self.padding, self.relu, self.transposed = \
             weight, bias, stride, padding, relu, transposed
-
-    fuse_relu = True  # one in-place bias(+ReLU) pass after the convolution instead of PyTorch's broadcast add + clamp
-
-    def __call__(self, x, out=None):
-        """``out``: optional destination view (channel slice of a wider NCHW buffer) for the fused epilogue."""
-        if (FoldedConv.fuse_relu and x.is_cuda and x.dtype == torch.float32 and self.bias is not None and x.is_contiguous()):
-            # fp32 NCHW on the GPU: MIOpen's Winograd / GEMM kernels have no epilogue (torch.miopen_convolution_relu runs
-            # conv + add + clamp as three kernels here), so the folded-BN shift and the ReLU are one HIP pass in place
-            if self.transposed and self.padding == 0 and self.weight.shape[-1] == self.stride:
-                # kernel = stride: a 1x1 convolution to k*k*Cout channels + a fused shuffle/bias/ReLU pass
-                from . import hip_ops
-                k = self.stride
-                if getattr(self, "_w1x1", None) is None:  # [Cin, Cout, k, k] -> [(dy,dx,Cout), Cin, 1, 1]
-                    self._w1x1 = self.weight.permute(2, 3, 1, 0).reshape(-1, self.weight.shape[0], 1, 1).contiguous()
-                y = F.conv2d(x, self._w1x1, None)
-                return hip_ops.shuffle_bias_act(y, self.bias, self.weight.shape[1], k, self.relu, out=out)
-            if self.transposed:
-                y = F.conv_transpose2d(x, self.weight, None, stride=self.stride, padding=self.padding)
-            else:
-                y = F.conv2d(x, self.weight, None, stride=self.stride, padding=self.padding)
-            if y.is_contiguous() and (y.shape[2] * y.shape[3]) % 4 == 0:
-                from . import hip_ops
-                return hip_ops.bias_act_nchw_(y, self.bias, self.relu, out=out)
-            y = y + self.bias.view(1, -1, 1, 1)
-            y = F.relu_(y) if self.relu else y
-            return y if out is None else out.copy_(y)
-        if self.transposed:
-            y = F.conv_transpose2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
-        else:
-            y = F.conv2d(x, self.weight, self.bias, stride=self.stride, padding=self.padding)
-        y = F.relu_(y) if self.relu else y
-        return y if out is None else out.copy_(y)
 
 
 def fold_stack(modules, dtype, channels_last):

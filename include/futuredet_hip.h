@@ -28,14 +28,15 @@ extern "C" {
 
 typedef void *fd_stream_t; /* hipStream_t */
 
-int fd_abi_version(void);
+int fd_abi_version(void); /* 6 (round 5: the split-operand dtypes 2-4, fd_rows_to_planes / fd_planes_to_rows and the two
+                             * MIOpen-epilogue helpers of ABI 5 are gone; fd_decode_cfg gained hm_channels) */
 const char *fd_last_error(void);
 /* Tuning / test knobs (no reference counterpart).  0 = built-in heuristic.  Names: "spconv_rg" (rows per wave of the
  * register sparse-conv kernel: 1|2|4), "spconv_v1" (1: fp32 on the register kernel instead of the compacting one),
  * "spconv_bf16_v1", "v2_depth", "v2_tm", "v2_ldspad", "conv_nt" (output channels per workgroup of the bf16 dense conv: 64 | 32),
- * "v2_ranges_per_cu", "v2_uniform", "v2_rowcost", "spconv_c32", "bf16_gp", "bf16_rg", "bf16_depth", "bf16_nw", "split_rg",
+ * "v2_ranges_per_cu", "v2_uniform", "v2_rowcost", "spconv_c32", "bf16_gp", "bf16_rg", "bf16_depth", "bf16_nw",
  * "strict" (1: a bf16 sparse layer that the gather-pipeline kernels cannot take is an error instead of a fall-back to the register
- * kernels), "bf16_win" (1: LDS row-window variant of the bf16 RING kernels), "f32_res_rg" (-1: 16-channel fp32 layers on the
+ * kernels), "f32_res_rg" (-1: 16-channel fp32 layers on the
  * pair-compacting kernel instead of the resident-weights one), "conv_strip" (1: stride-1 bf16 dense layers on strips of 128
  * consecutive pixels instead of 8 x 16 tiles: faster alone, slower with several sweeps in flight; results identical).  Initial
  * values come from the FD_SPCONV_RG, FD_SPCONV_V1, ... environment variables (FD_ + the upper-case name), read once when the
@@ -125,16 +126,7 @@ int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, int B, int D
  *   in_feats  [n_in, cin]  float32 (dtype 0) or bfloat16 (dtype 1);  cin, cout in {16,32,64,128}
  *   wpacked   weights in MFMA fragment order, produced by fd_spconv_pack_weight from [K,cin,cout] float32
  *   bias      [cout] float32 or NULL; residual [n_out,cout] same dtype as out or NULL; relu 0/1
- * Split-operand fp32 arithmetic (dtype 2 / 3 / 4; no reference counterpart -- spconv 1.0 multiplies fp32 by fp32): an fp32
- * value is stored as the exact sum of three bf16 pieces, row = [h[C] | m[C] | l[C]] bfloat16 ("planes", 6 C bytes per row),
- * and a product is six bf16 MFMAs with fp32 accumulate (fd_spconv_split.hip; cin, cout in {32,64,128}):
- *   dtype 2   in_feats planes, out_feats planes, residual planes       (weights packed with dtype 2)
- *   dtype 3   in_feats planes, out_feats float32, residual float32     (weights packed with dtype 2 or 3: same layout)
- *   dtype 4   in_feats float32, out_feats planes, no residual; NATIVE fp32 arithmetic (weights packed with dtype 0 or 4)
- * fd_rows_to_planes / fd_planes_to_rows convert [n, c] float32 <-> planes exactly (c a multiple of 4).
  * ------------------------------------------------------------------------------------------------- */
-int fd_rows_to_planes(const float *src, int64_t n, int c, const int32_t *n_dev, void *dst_planes, fd_stream_t stream);
-int fd_planes_to_rows(const void *src_planes, int64_t n, int c, const int32_t *n_dev, float *dst, fd_stream_t stream);
 size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype);
 int fd_spconv_pack_weight(const float *w_kio_host, int K, int cin, int cout, int dtype, void *wpacked_host);
 int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *wpacked, const float *bias, const void *residual,
@@ -231,6 +223,7 @@ typedef struct fd_decode_cfg {
     float center_range[6];                               /* post_center_limit_range */
     float nms_iou_threshold;
     int nms_pre_max, nms_post_max;
+    int hm_channels; /* 0 / 1: one heat-map channel; n > 1: score = max over n channels (center_head.py:589-595, the `classify` head) */
 } fd_decode_cfg;
 
 /* A head map as the decode reads it: element (group g, channel ch, BEV cell) of a float32 (dtype 0) or bf16 (dtype 1) tensor at
@@ -322,13 +315,6 @@ int fd_pillar_scatter(const void *feats, int c, int feat_stride, int dtype, cons
                       int64_t m_max, int B, int H, int W, void *out, int out_dtype, int64_t stride_b, int64_t stride_c,
                       int64_t stride_y, int64_t stride_x, int zero_first, fd_stream_t stream);
 
-/* In-place per-channel bias (+ReLU when relu != 0) on a contiguous NCHW float32 map with H*W % 4 == 0: the folded
- * BatchNorm shift + activation after each RPN / head convolution (det3d/models/necks/rpn.py:124-142,
- * det3d/models/bbox_heads/center_head.py:129-143) when the convolution itself runs in MIOpen without an epilogue. */
-int fd_bias_act_nchw_f32(float *x, const float *bias, int B, int C, int64_t hw, int relu, float *dst,
-                         int64_t dst_batch_stride, fd_stream_t stream);
-/* dst == NULL: in place.  Otherwise the result goes to dst[b * dst_batch_stride + c * hw + p] -- the channel slice of a
- * wider NCHW buffer, which is how the RPN's torch.cat of the deblock outputs (rpn.py:156-157) is written in place. */
 
 /* ---------------------------------------------------------------------------------------------------
  * Forecast association: the numeric core of `tracker` (det3d/datasets/nuscenes/nuscenes.py:125-257), `match_boxes`
@@ -396,12 +382,6 @@ int fd_index_pyramid_coords(int B, int n_levels, const fd_index_level *levels_ho
 int fd_rows_place(const uint64_t *words, const int32_t *prefix, int B, int D, int H, int W, const int32_t *coords_in,
                   const int32_t *n_dev, int64_t n_max, const float *src, int c_src, void *dst, int c_dst, int dst_bf16,
                   fd_stream_t stream);
-
-/* Epilogue of a ConvTranspose2d with kernel = stride = k (det3d/models/necks/rpn.py:81-94) computed as a 1x1 convolution to
- * k*k*cout channels: y [B, k*k*cout, H, W] (channel = (dy*k+dx)*cout + co) -> dst[b*dst_batch_stride + (co*H*k + i*k+dy)*W*k
- * + j*k+dx] = act(y + bias[co]); dst may be the channel slice of the concatenated RPN output. */
-int fd_shuffle_bias_act_f32(const float *y, const float *bias, int B, int cout, int H, int W, int k, int relu, float *dst,
-                            int64_t dst_batch_stride, fd_stream_t stream);
 
 #ifdef __cplusplus
 }

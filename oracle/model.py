@@ -176,17 +176,19 @@ class SepHead(nn.Module):  # center_head.py:81-174 (bn=True, final_kernel=3 as b
 
 class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from the shipped configs)
     def __init__(self, in_channels, tasks, common_heads, share_conv_channel=64, num_hm_conv=2, timesteps=1,
-                 dense=False, bev_map=False, forecast_feature=False, **kw):
+                 dense=False, bev_map=False, forecast_feature=False, classify=False, **kw):
         super().__init__()
-        for flag in ("reverse", "sparse", "classify", "wide_head", "two_stage", "dcn_head"):
+        for flag in ("reverse", "sparse", "wide_head", "two_stage", "dcn_head"):
             assert not kw.get(flag, False), flag
-        self.dense, self.bev_map, self.forecast_feature = dense, bev_map, forecast_feature
-        self.standard = not dense
+        self.dense, self.bev_map, self.forecast_feature, self.classify = dense, bev_map, forecast_feature, classify
+        self.standard = not (dense or classify)  # :268-271
         self.timesteps = timesteps
         self.target_timesteps = 7
         self.num_classes = [len(t["class_names"]) for t in tasks]
         if dense:
             self.num_classes = timesteps * [1]
+        if classify:  # :329-330
+            self.num_classes = timesteps * [3]
         if bev_map:
             c = share_conv_channel
             self.bev_conv = nn.Sequential(
@@ -198,7 +200,7 @@ class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from 
         self.tasks = nn.ModuleList()
         for i, num_cls in enumerate(self.num_classes):
             heads = copy.deepcopy(dict(common_heads))
-            if not dense and "vel" in heads:
+            if self.standard and "vel" in heads:  # :355
                 heads["vel"] = (timesteps * heads["vel"][0], heads["vel"][1])
             heads.update(dict(hm=(num_cls, num_hm_conv)))
             cin = 2 * share_conv_channel if (i != 0 and forecast_feature) else share_conv_channel
@@ -230,6 +232,9 @@ class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from 
                 d = dict(pd)
                 d["vel"] = v
                 steps.append(d)
+        elif self.classify:  # :589-595: the class channels collapse to their maximum, one class per step afterwards
+            steps = [dict(d, hm=torch.max(d["hm"], dim=1)[0].unsqueeze(1)) for d in preds_dicts]
+            num_classes = self.timesteps * [1]
         else:  # :606-607
             steps = [dict(d) for d in preds_dicts]
             num_classes = self.num_classes

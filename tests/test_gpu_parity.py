@@ -412,7 +412,7 @@ def _rows(res):
     return r.cpu().numpy()
 
 
-@pytest.mark.parametrize("name,T,dense", [("n0", 1, False), ("n3", 7, False), ("n3dtf", 7, True), ("n0big", 1, False)])
+@pytest.mark.parametrize("name,T,dense", [("n0", 1, False), ("n3", 7, False), ("n3dtf", 7, True), ("n0big", 1, False), ("cls", 3, False)])
 def test_predict_matches_reference_golden(hip, golden, name, T, dense):
     """CenterHead.predict on HIP vs the reference's predict outputs (decode + rotated NMS through the compiled
     reference IoU).  Boxes within 1e-3; a detection may differ only if its score is within 1e-5 of the
@@ -425,8 +425,8 @@ def test_predict_matches_reference_golden(hip, golden, name, T, dense):
                            dataset="nuscenes", weight=0.25, code_weights=[1.0] * 10,
                            common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
                            share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=False, sparse=False,
-                           dense=dense, bev_map=False, forecast_feature=False, classify=False, wide_head=False)).cuda().eval()
-    ntask = T if dense else 1
+                           dense=dense, bev_map=False, forecast_feature=False, classify=name == "cls", wide_head=False)).cuda().eval()
+    ntask = T if (dense or name == "cls") else 1  # "cls": the constructor's default mode, three-class heat-maps, channel max in the decode
     preds = [{k: _dev(g["%s_in_t%d_%s" % (name, ti, k)]) for k in ("reg", "height", "dim", "rot", "vel", "hm")}
              for ti in range(ntask)]
     B = preds[0]["hm"].shape[0]
@@ -728,6 +728,59 @@ def test_dense_bf16_plan_vs_torch_modules(hip):
     for k in p_ref[0]:
         assert p[0][k].shape == p_ref[0][k].shape
         assert float((p[0][k] - p_ref[0][k]).abs().max()) <= 3e-2 * max(1.0, float(p_ref[0][k].abs().max())), k
+
+
+def test_default_classify_head_on_the_plan_and_packed_decode(hip, golden):
+    """CenterHead built WITHOUT the ``classify`` keyword (the reference's default is True, center_head.py:253): one task per timestep
+    with a three-class heat-map.  The device path (convolution plan, fp32) reproduces the reference's forward (dense_nets.npz,
+    "cls3"), and the packed decode -- score = maximum over the three heat-map channels, fd_decode_cfg.hm_channels -- returns the
+    detections of the per-task path."""
+    from futuredet_amd import build_head
+    from futuredet_amd.synth import seeded_state_dict
+
+    g = golden("dense_nets.npz")
+    head = build_head(dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])], dataset="nuscenes", weight=0.25,
+                           code_weights=[1.0] * 10, common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
+                           share_conv_channel=64, timesteps=3))
+    assert head.classify and not head.standard and len(head.tasks) == 3
+    head.load_state_dict(seeded_state_dict(head, 12), strict=False)
+    head = head.cuda().eval()
+    y = _dev(g["rpn_y"])
+    with torch.no_grad():
+        preds = head(y)
+    assert head._plan[1] is not None and preds[0].raw is not None, "the convolution plan must be the path that ran"
+    for ti, pd in enumerate(preds):
+        assert pd["hm"].shape[1] == 3
+        for k, v in pd.items():
+            assert_close("classify head on the plan, task %d %s vs reference golden" % (ti, k), v.float().cpu().numpy(), g["head_cls3_t%d_%s" % (ti, k)], 1e-3)
+    cfg = dict(TEST_CFG, score_threshold=0.01)
+    packed = head.predict({"metadata": [None] * y.shape[0]}, preds, cfg)                    # decode reads the plan's NHWC buffer, channel max in dec_keys
+    plain = head.predict({"metadata": [None] * y.shape[0]}, [dict(pd) for pd in preds], cfg)  # per-task tensors (raw is lost with the dict copy)
+    for b in range(y.shape[0]):
+        assert len(packed[b]["scores"]) > 0
+        assert np.array_equal(_rows(packed[b]), _rows(plain[b]))
+        assert set(packed[b]["label_preds"].tolist()) <= {0, 1, 2}
+
+
+def test_unsupported_dense_stack_raises_instead_of_leaving_the_hip_path(hip):
+    """The convolution plan is the only eval-mode device path of the neck and head (round-4 review: a channel count the kernels do
+    not take used to fall to PyTorch / MIOpen without a word)."""
+    import logging
+
+    from futuredet_amd import build_neck
+
+    rpn = build_neck(dict(type="RPN", layer_nums=[1], ds_layer_strides=[1], ds_num_filters=[40], us_layer_strides=[1], us_num_filters=[40],
+                          num_input_features=40, logger=logging.getLogger("RPN"))).cuda().eval()
+    x = torch.randn((1, 40, 16, 16), device="cuda")
+    with torch.no_grad():
+        assert rpn.forward_modules(x).shape == (1, 40, 16, 16)  # (the nn.Module stack itself is fine)
+        for dt in (torch.float32, torch.bfloat16):  # 40 channels: not a multiple of the fp32 (16) or bf16 (32) input granule
+            rpn.compute_dtype = dt
+            with pytest.raises(ValueError):
+                rpn(x)
+        rpn.compute_dtype = torch.float16
+        with pytest.raises(ValueError):
+            rpn(x)
 
 
 # ------------------------------------------------------------------------------------------------ sweep assembly

@@ -132,18 +132,24 @@ def test_state_dict_keys_match_reference(golden):
     rpn = fa.build_neck(dict(type="RPN", layer_nums=[2, 2], ds_layer_strides=[1, 2], ds_num_filters=[16, 32], us_layer_strides=[1, 2],
                              us_num_filters=[32, 32], num_input_features=24, logger=logging.getLogger("RPN")))
     assert sorted(rpn.state_dict().keys()) == list(d["rpn_keys"])
-    for name, T, dense, ff in (("n0", 1, False, False), ("n3", 7, False, False), ("n3dtf", 7, True, True)):
-        head = fa.build_head(dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])], dataset="nuscenes",
-                                  weight=0.25, code_weights=[1.0] * 10,
-                                  common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
-                                  share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=False, sparse=False,
-                                  dense=dense, bev_map=False, forecast_feature=ff, classify=False, wide_head=False))
+    for name, T, dense, ff, classify in (("n0", 1, False, False, False), ("n3", 7, False, False, False), ("n3dtf", 7, True, True, False),
+                                         ("cls3", 3, False, False, True)):
+        kw = dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])], dataset="nuscenes",
+                  weight=0.25, code_weights=[1.0] * 10,
+                  common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
+                  share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=False, sparse=False,
+                  dense=dense, bev_map=False, forecast_feature=ff, classify=False, wide_head=False)
+        if classify:  # the reference constructor's DEFAULT (center_head.py:253): built without the keyword, as the golden was
+            del kw["classify"]
+        head = fa.build_head(kw)
+        assert head.classify == classify
         assert sorted(head.state_dict().keys()) == list(d["head_%s_keys" % name])
 
 
 def test_dense_modules_match_reference_golden_on_cpu(golden):
-    """RPN / CenterHead.forward are PyTorch convolutions (device-agnostic plumbing): the folded-BN eval path and the
-    plain module path both reproduce the reference outputs."""
+    """The nn.Module stacks of RPN / CenterHead (what fixes the state-dict keys; run for host tensors and in training mode)
+    reproduce the reference outputs on the CPU -- including the constructor's default ``classify`` head.  On the device, eval
+    mode runs the convolution plan and nothing else (tests/test_gpu_parity.py)."""
     import logging
 
     from futuredet_amd.synth import seeded_state_dict
@@ -157,12 +163,13 @@ def test_dense_modules_match_reference_golden_on_cpu(golden):
         y_fold, y_mod = rpn(x), rpn.forward_modules(x)
     np.testing.assert_allclose(y_fold.numpy(), d["rpn_y"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(y_mod.numpy(), d["rpn_y"], rtol=1e-4, atol=1e-4)
-    for name, T, dense, ff in (("n0", 1, False, False), ("n3", 7, False, False), ("n3dtf", 7, True, True)):
+    for name, T, dense, ff, classify in (("n0", 1, False, False, False), ("n3", 7, False, False, False), ("n3dtf", 7, True, True, False),
+                                         ("cls3", 3, False, False, True)):
         head = fa.build_head(dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])], dataset="nuscenes",
                                   weight=0.25, code_weights=[1.0] * 10,
                                   common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
                                   share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=False, sparse=False,
-                                  dense=dense, bev_map=False, forecast_feature=ff, classify=False, wide_head=False)).eval()
+                                  dense=dense, bev_map=False, forecast_feature=ff, classify=classify, wide_head=False)).eval()
         head.load_state_dict(seeded_state_dict(head, 12), strict=False)
         with torch.no_grad():
             preds = head(torch.from_numpy(d["rpn_y"]))
@@ -184,7 +191,7 @@ def test_c_abi_exports_every_declared_symbol():
     nm = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (fd_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
-    assert L.fd_abi_version() == 5
+    assert L.fd_abi_version() == 6
     assert L.fd_index_num_cols(2, 180, 180) == 2 * 23 * 23 * 64
     assert L.fd_voxelize_workspace_bytes(1000, 100) > 0 and L.fd_nms_workspace_bytes(1000) >= 1000 * 16 * 8
 
@@ -313,8 +320,8 @@ def test_hip_ops_exposes_every_wrapper():
 
     for name in ("voxelize", "SparseIndex", "build_pyramid", "ranges_for", "rows_permute", "pack_spconv_weight", "spconv_apply",
                  "densify", "pack_conv2d_weight", "conv2d_nhwc_bf16", "pack_conv2d_weight_f32", "conv2d_nhwc_f32", "pack_conv2d_weight_wino", "conv2d_wino_nhwc_f32", "conv2d_shuffle_nhwc_f32", "conv2d_grouped_nhwc_f32", "make_decode_cfg", "centerpoint_decode", "rotated_nms",
-                 "boxes_iou_bev", "sweep_descriptors", "assemble_sweeps", "pillar_encode", "pillar_scatter", "bias_act_nchw_",
-                 "shuffle_bias_act", "forecast_chains", "det_to_global_boxes", "forecast_groups", "set_tuning"):
+                 "boxes_iou_bev", "sweep_descriptors", "assemble_sweeps", "pillar_encode", "pillar_scatter",
+                 "forecast_chains", "det_to_global_boxes", "forecast_groups", "set_tuning"):
         assert hasattr(hip_ops, name), name
 
 

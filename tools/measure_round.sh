@@ -10,7 +10,7 @@ run serial --inflight 1 --stage-times
 grep stage $out/serial.err | tail -2
 run nograph --graph 0
 run serial_nograph --graph 0 --inflight 1
-run torch_dense --torch-dense
+timeout 300 python tools/torch_dense_ab.py > $out/torch_dense_ab.txt 2>&1; tail -1 $out/torch_dense_ab.txt
 run batch2 --batch 2
 run batch8 --batch 8 --no-host-leg
 run config3 --config 3
