@@ -574,6 +574,14 @@ extern "C" int fd_index_pyramid(const int32_t *coords, const int32_t *n_dev, int
     FD_REQUIRE(coords && levels && counts_dev && workspace, "fd_index_pyramid: null argument");
     FD_REQUIRE(n_levels >= 1 && n_levels <= 8 && B >= 1, "fd_index_pyramid: need 1 <= n_levels <= 8 and B >= 1");
     const fd_index_level &l0 = levels[0];
+    FD_REQUIRE(l0.words, "fd_index_pyramid: null level buffer");
+    // level 0 is marked with atomicOr: its words are cleared here (a kernel of this library -- graph-safe, see fd::fill_words);
+    // the words of every other level are overwritten column by column by idx_down
+    {
+        const int64_t nc0 = fd::make_geom(B, l0.D, l0.H, l0.W).num_cols();
+        int rc = fd::fill_words(l0.words, 0u, (size_t)nc0 * 2, fd::as_stream(stream));
+        if (rc != FD_OK) return rc;
+    }
     for (int b = 0; b < B; ++b) {
         int rc = fd_index_mark(coords + (int64_t)b * n_max_per_sample * 4, n_dev ? n_dev + b : nullptr, n_max_per_sample, B, l0.D, l0.H, l0.W,
                                l0.words, stream);

@@ -287,6 +287,7 @@ class StaticStep(object):
         dev = next(model.parameters()).device
         self.points = torch.zeros((self.B, self.capacity, self.ndim), dtype=torch.float32, device=dev)
         self.counts = torch.zeros((self.B,), dtype=torch.int32, device=dev)
+        self._counts_host, self._counts_slot = None, 0
         self.expected = None
         self.graph = None
         self.outputs = None
@@ -299,12 +300,22 @@ class StaticStep(object):
 
     def _load(self, clouds):
         assert len(clouds) == self.B
+        if self._counts_host is None:  # ring of pinned count vectors, each with the event of the copy that last read it
+            self._counts_host = [[torch.empty((self.B,), dtype=torch.int32).pin_memory(), None] for _ in range(8)]
+        slot = self._counts_host[self._counts_slot % len(self._counts_host)]
+        self._counts_slot += 1
+        host = slot[0]
+        if slot[1] is not None:
+            slot[1].synchronize()  # (returns at once unless the stream is eight sweeps behind the host)
         for b, c in enumerate(clouds):
             n = int(c.shape[0])
             if n > self.capacity or c.shape[1] != self.ndim:
                 raise ValueError("cloud of %d x %d rows does not fit the step's %d x %d buffer" % (n, c.shape[1], self.capacity, self.ndim))
             self.points[b, :n].copy_(c, non_blocking=True)
-            self.counts[b:b + 1].fill_(n)
+            host[b] = n
+        self.counts.copy_(host, non_blocking=True)  # one small copy for all samples (was: one fill kernel per sample)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
 
     def __del__(self):
         try:
@@ -374,9 +385,12 @@ class StaticStep(object):
         self.version = self._version_key()
 
     def __call__(self, clouds, bev_map=None, check=True):
-        """Replays the captured sweep.  With capacities from a high-water mark (row_caps="auto") and ``check`` the level counts are
-        read back (one synchronisation) and an overflowing sweep is re-run on the eager path: the result is always correct.
-        ``check=False``: the caller checks ``overflowed()`` itself (no synchronisation here)."""
+        """Replays the captured sweep and returns the graph's static output tensors (``self.outputs``; valid until the next call).
+        With capacities from a high-water mark (row_caps="auto") and ``check`` (the default: always correct) the level counts are read
+        back after the replay -- ONE device synchronisation per call -- and an overflowing sweep is re-run on the eager path, its
+        results copied INTO the static output tensors, so the returned tensors and ``self.outputs`` always agree.
+        ``check=False`` keeps the call asynchronous: the caller copies ``level_counts`` next to its results and asks
+        ``overflowed(counts)`` itself (bench.py does); row_caps="datafree" never overflows and never synchronises."""
         self._set_bev(bev_map)
         if self.graph is None or self.version != self._version_key():
             if self.expected is None:
@@ -385,7 +399,9 @@ class StaticStep(object):
         self._load(clouds)
         self.graph.replay()
         if check and self.caps is not None and self.overflowed():
-            return self.model.forward_points(clouds, self.voxel_cfg, padded=self.padded, bev_map=self.bev)
+            redo = self.model.forward_points(clouds, self.voxel_cfg, padded=self.padded, bev_map=self.bev)
+            for dst, src in zip(self.outputs, redo):  # fixed shapes on both paths (padded / packed results)
+                dst.copy_(src)
         return self.outputs
 
     def overflowed(self, level_counts_host=None):

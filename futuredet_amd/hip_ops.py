@@ -241,8 +241,9 @@ def build_pyramid(coors, nvox, n_max, B, shape0, geoms, device, static=False, ex
     if plan is None:
         plan = _pyramid_plans[key] = _PyramidPlan(B, shape0, geoms, device)
     shapes, ncols = plan.shapes, plan.ncols
-    # fresh buffers every sweep (the indexes are handed out and may outlive the call); one fill covers every level
-    words_all = torch.zeros((sum(ncols),), dtype=torch.int64, device=device)
+    # fresh buffers every sweep (the indexes are handed out and may outlive the call); fd_index_pyramid clears level 0 itself and
+    # overwrites the other levels
+    words_all = torch.empty((sum(ncols),), dtype=torch.int64, device=device)
     prefix_all = torch.empty((sum(ncols),), dtype=torch.int32, device=device)
     counts = torch.empty((len(shapes),), dtype=torch.int32, device=device)
     idx, off = [], 0

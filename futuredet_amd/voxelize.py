@@ -33,37 +33,33 @@ def points_to_voxel(points, voxel_size, coors_range, max_points=35, reverse_inde
     return voxels, coors, num
 
 
+def grid_cells(point_cloud_range, voxel_size):
+    """Cells per axis (x, y, z) of a voxel grid: round((hi - lo) / size) evaluated in float32, the rule fd_voxelize applies to the
+    same two arrays (include/futuredet_hip.h; point_cloud_ops.py:24-29)."""
+    r = np.asarray(point_cloud_range, dtype=np.float32)
+    v = np.asarray(voxel_size, dtype=np.float32)
+    return np.round((r[3:] - r[:3]) / v).astype(np.int64)
+
+
 class VoxelGenerator(object):
+    """Host-side handle of one voxelizer configuration: generate() is points_to_voxel on the HIP voxelizer with the stored geometry.
+    The four read-only attributes are the ones det3d's pipeline stages and configs read (det3d/core/input/voxel_generator.py:5-46)."""
+
     def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000):
-        point_cloud_range = np.array(point_cloud_range, dtype=np.float32)
-        voxel_size = np.array(voxel_size, dtype=np.float32)
-        grid_size = (point_cloud_range[3:] - point_cloud_range[:3]) / voxel_size
-        self._grid_size = np.round(grid_size).astype(np.int64)
-        self._voxel_size = voxel_size
-        self._point_cloud_range = point_cloud_range
-        self._max_num_points = max_num_points
-        self._max_voxels = max_voxels
+        self._spec = dict(voxel_size=np.asarray(voxel_size, dtype=np.float32), point_cloud_range=np.asarray(point_cloud_range, dtype=np.float32),
+                          max_num_points_per_voxel=int(max_num_points), grid_size=grid_cells(point_cloud_range, voxel_size))
+        self._max_voxels = int(max_voxels)
+
+    def __getattr__(self, name):  # voxel_size, point_cloud_range, max_num_points_per_voxel, grid_size
+        spec = self.__dict__.get("_spec", {})
+        if name in spec:
+            return spec[name]
+        raise AttributeError(name)
 
     def generate(self, points, max_voxels=-1):
-        if max_voxels == -1:
-            max_voxels = self._max_voxels
-        return points_to_voxel(points, self._voxel_size, self._point_cloud_range, self._max_num_points, True, max_voxels)
-
-    @property
-    def voxel_size(self):
-        return self._voxel_size
-
-    @property
-    def max_num_points_per_voxel(self):
-        return self._max_num_points
-
-    @property
-    def point_cloud_range(self):
-        return self._point_cloud_range
-
-    @property
-    def grid_size(self):
-        return self._grid_size
+        cap = self._max_voxels if max_voxels == -1 else int(max_voxels)
+        sp = self._spec
+        return points_to_voxel(points, sp["voxel_size"], sp["point_cloud_range"], sp["max_num_points_per_voxel"], True, cap)
 
 
 @PIPELINES.register_module

@@ -94,7 +94,8 @@ size_t fd_index_workspace_bytes(int64_t num_cols);
 /* words must be zeroed by the caller (hipMemsetAsync) before fd_index_mark. */
 int fd_index_mark(const int32_t *coords /*[n,4] (b,z,y,x)*/, const int32_t *n_dev /*device count, or NULL*/,
                   int64_t n_max, int B, int D, int H, int W, uint64_t *words, fd_stream_t stream);
-/* marks the output set of a strided conv: o = (p + pad - k)/stride where integral and inside out grid */
+/* marks the output set of a strided conv: o = (p + pad - k)/stride where integral and inside out grid; every word of out_words is
+ * OVERWRITTEN (gather form, no atomics: nothing is OR-ed into what out_words held before) */
 int fd_index_downsample(const uint64_t *in_words, int B, int D, int H, int W, const int *ksize3,
                         const int *stride3, const int *pad3, uint64_t *out_words, fd_stream_t stream);
 /* exclusive scan of popcounts -> prefix[], total -> n_active_dev[0] */
@@ -357,7 +358,8 @@ int fd_nearest_rows(const double *library, int n_library, const double *queries,
  * _coords above, issued back to back): level 0 is marked from the voxelizer's coords of every sample
  * (coords [B * n_max_per_sample, 4], n_dev[b] = voxel count of sample b or NULL), level l > 0 is derived from
  * level l-1 with its ksize/stride/pad (the strided SparseConv3d of scn.py:110,120,130,141); counts_dev[l] receives
- * the active count of level l.  words of every level must be zero-filled by the caller; all levels are scanned by one
+ * the active count of level l.  The caller need not initialise any level's words (level 0 is cleared by this call, the other
+ * levels are overwritten); all levels are scanned by one
  * set of launches: workspace >= fd_index_workspace_bytes(sum of the levels' fd_index_num_cols + 2048 * n_levels).  fd_index_pyramid_coords materialises coords for the levels whose pointer is
  * set (after the host has read the counts and allocated them).  When EVERY level passed to fd_index_pyramid already has its
  * coords pointer set (capacity-sized tables, coords_rows = capacity), the coordinates are written in the same pass and

@@ -211,6 +211,12 @@ int64_t fdo_rulebook(const int32_t *indices /* [n,4] (b,z,y,x) */, int64_t n,
 /*     bias added after the scatter.  Call sites scn.py:99-141.               */
 /*     fp32 accumulate, taps visited in kernel-offset order.                  */
 /* ------------------------------------------------------------------------- */
+/* Execution: ONE parallel region.  The pair lists are first turned into an output-stationary table inv[k][o] = input row of
+ * output row o under tap k (or -1), then every thread takes blocks of output rows and walks the taps in ascending order.  Per
+ * output element this is the same sequence of float32 operations as the tap-by-tap scatter (taps ascending, input channels
+ * ascending, one multiply and one add each, -ffp-contract=off), so the results are bit-identical to it -- but there is no
+ * fork / join per tap, and no two threads ever touch the same output row: the loop scales with the host's cores (round 4's
+ * tap-by-tap form got slower beyond 64 threads). */
 #if defined(__x86_64__) && defined(__GNUC__)
 __attribute__((target_clones("avx512f", "avx2", "default")))
 #endif
@@ -219,30 +225,43 @@ void fdo_indice_conv(const float *in_feats, int64_t n_in, int cin,
                      const int32_t *pairs /* [K,2,n_in] */, const int32_t *pair_num, int K,
                      float *out_feats /* [n_out,cout] */, int64_t n_out, int cout)
 {
-    memset(out_feats, 0, sizeof(float) * (size_t)(n_out * cout));
-    for (int k = 0; k < K; ++k) {
-        const int32_t *pin = pairs + ((int64_t)k * 2 + 0) * n_in;
-        const int32_t *pout = pairs + ((int64_t)k * 2 + 1) * n_in;
-        const float *W = weight + (int64_t)k * cin * cout;
-        const int32_t np = pair_num[k];
-        /* within one tap every output row occurs at most once -> race free */
-#pragma omp parallel for schedule(static)
-        for (int32_t t = 0; t < np; ++t) {
-            const float *restrict x = in_feats + (int64_t)pin[t] * cin;
-            float *restrict y = out_feats + (int64_t)pout[t] * cout;
-            for (int ci = 0; ci < cin; ++ci) {
-                const float xv = x[ci];
-                const float *restrict w = W + (int64_t)ci * cout;
+    if (n_out <= 0) return;
+    int32_t *inv = (int32_t *)malloc(sizeof(int32_t) * (size_t)K * (size_t)n_out);
+    if (!inv) { memset(out_feats, 0, sizeof(float) * (size_t)(n_out * cout)); return; }
+#pragma omp parallel
+    {
+#pragma omp for schedule(static)
+        for (int64_t t = 0; t < (int64_t)K * n_out; ++t) inv[t] = -1;
+        /* (implicit barrier)  within one tap every output row occurs at most once; taps write disjoint rows of inv */
+        for (int k = 0; k < K; ++k) {
+            const int32_t *pin = pairs + ((int64_t)k * 2 + 0) * n_in;
+            const int32_t *pout = pairs + ((int64_t)k * 2 + 1) * n_in;
+            const int32_t np = pair_num[k];
+#pragma omp for schedule(static) nowait
+            for (int32_t t = 0; t < np; ++t) inv[(int64_t)k * n_out + pout[t]] = pin[t];
+        }
+#pragma omp barrier
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t o = 0; o < n_out; ++o) {
+            float *restrict y = out_feats + o * cout;
+            for (int co = 0; co < cout; ++co) y[co] = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                const int32_t i = inv[(int64_t)k * n_out + o];
+                if (i < 0) continue;
+                const float *restrict x = in_feats + (int64_t)i * cin;
+                const float *W = weight + (int64_t)k * cin * cout;
+                for (int ci = 0; ci < cin; ++ci) {
+                    const float xv = x[ci];
+                    const float *restrict w = W + (int64_t)ci * cout;
 #pragma omp simd
-                for (int co = 0; co < cout; ++co) y[co] += xv * w[co];
+                    for (int co = 0; co < cout; ++co) y[co] += xv * w[co];
+                }
             }
+            if (bias)
+                for (int co = 0; co < cout; ++co) y[co] += bias[co];
         }
     }
-    if (bias) {
-#pragma omp parallel for schedule(static)
-        for (int64_t o = 0; o < n_out; ++o)
-            for (int co = 0; co < cout; ++co) out_feats[o * cout + co] += bias[co];
-    }
+    free(inv);
 }
 
 /* A8. SparseConvTensor.dense(): scatter rows into zeros [B,D,H,W,C] then permute to [B,C,D,H,W]

@@ -1381,7 +1381,7 @@ def _attribute_bf16_detections(tag, cfg, g, w, opreds, dpreds, min_rows=20):
     pre_max, post_max = int(tc["nms"]["nms_pre_max_size"]), int(tc["nms"]["nms_post_max_size"])
     assert len(w) >= min_rows
     dense = len(opreds) > 1
-    cat = dict(found=0, score=0, pre_cut=0, nms=0, post_cut=0, unexplained=0)
+    cat = dict(found=0, score=0, pre_cut=0, range=0, nms=0, post_cut=0, unexplained=0)
     cache = {}
     margins = []  # how far above the oracle's own pre-max cut the detections lost to the device's cut were
     lost_cells = set()  # (task, cell) of the detections not found: the standard head shares ONE heat-map and one box per cell between its
@@ -1394,31 +1394,43 @@ def _attribute_bf16_detections(tag, cfg, g, w, opreds, dpreds, min_rows=20):
             cat["found"] += 1
             continue
         ti = lab if dense else 0
-        if ti not in cache:  # the oracle's decoded centre of every cell of this task's maps, and both score maps
-            po = opreds[ti]
-            reg = po["reg"][0].permute(1, 2, 0)
-            H, W = reg.shape[:2]
-            ys, xs = torch.meshgrid([torch.arange(0, H), torch.arange(0, W)], indexing="ij")
-            cx = (xs + reg[..., 0]) * tc["out_size_factor"] * tc["voxel_size"][0] + tc["pc_range"][0]
-            cy = (ys + reg[..., 1]) * tc["out_size_factor"] * tc["voxel_size"][1] + tc["pc_range"][1]
-            so = torch.sigmoid(po["hm"][0].float()).max(0).values
-            sd = torch.sigmoid(dpreds[ti]["hm"][0].float().cpu()).max(0).values
-            kth = float(torch.topk(sd.flatten(), pre_max).values[-1]) if int((sd > thr).sum()) > pre_max else None
-            ko = float(torch.topk(so.flatten(), pre_max).values[-1]) if int((so > thr).sum()) > pre_max else None
-            cache[ti] = (cx.numpy().ravel(), cy.numpy().ravel(), so.numpy().ravel(), sd.numpy().ravel(), kth, ko)
-        cx, cy, so, sd, kth, ko = cache[ti]
+        if ti not in cache:  # per task: both pipelines' decoded centres, score maps and candidate masks, and both pre-max cuts
+            rng_lim = [float(v) for v in tc["post_center_limit_range"]]
+
+            def decode(pd):
+                """(cx, cy, score, candidate mask) of every cell as predict sees it: the candidates of the top-k are the cells with
+                score > threshold AND centre inside post_center_limit_range (center_head.py:709-716 masks before
+                box_torch_ops.py:259-261 sorts and cuts) -- round 4 computed the cuts over all cells and its margins came out negative."""
+                reg = pd["reg"][0].float().cpu().permute(1, 2, 0)
+                H, W = reg.shape[:2]
+                ys, xs = torch.meshgrid([torch.arange(0, H), torch.arange(0, W)], indexing="ij")
+                cx = (xs + reg[..., 0]) * tc["out_size_factor"] * tc["voxel_size"][0] + tc["pc_range"][0]
+                cy = (ys + reg[..., 1]) * tc["out_size_factor"] * tc["voxel_size"][1] + tc["pc_range"][1]
+                cz = pd["height"][0, 0].float().cpu()
+                sc = torch.sigmoid(pd["hm"][0].float().cpu()).max(0).values
+                ok = (sc > thr) & (cx >= rng_lim[0]) & (cy >= rng_lim[1]) & (cz >= rng_lim[2]) & (cx <= rng_lim[3]) & (cy <= rng_lim[4]) & (cz <= rng_lim[5])
+                cut = float(torch.topk(sc[ok], pre_max).values[-1]) if int(ok.sum()) > pre_max else None
+                return cx.numpy().ravel(), cy.numpy().ravel(), sc.numpy().ravel(), ok.numpy().ravel(), cut
+
+            cache[ti] = decode(opreds[ti]) + decode(dpreds[ti])
+        cx, cy, so, ok_o, ko, cxd, cyd, sd, ok_d, kth = cache[ti]
         cell = int(np.argmin(np.abs(cx - row[0]) + np.abs(cy - row[1]) + 10.0 * np.abs(so - row[9])))
         assert abs(cx[cell] - row[0]) < 1e-3 and abs(cy[cell] - row[1]) < 1e-3, "oracle detection not found among its own cells"
+        assert ok_o[cell] and (ko is None or so[cell] >= ko), "an oracle detection must be one of the oracle's own pre-max candidates"
         lost_cells.add((ti, cell))
         s_dev, s_ora = float(sd[cell]), float(so[cell])
         # A score / pre-max decision may differ only by as much as the two pipelines' scores differ AT THIS CELL (measured, not a flat
         # slack): the oracle had the cell above the bar by (s_ora - bar); the device has it below iff its score moved down by more.
         dev_move = abs(s_dev - s_ora) + 1e-6
+        in_dev_topk = bool(ok_d[cell]) and (kth is None or s_dev > kth)  # the cell IS one of the device's pre-max candidates
         if s_dev <= thr and s_ora - thr <= dev_move:
             cat["score"] += 1
-        elif kth is not None and s_dev <= kth and (ko is None or (s_ora - ko) <= dev_move + abs(kth - ko)):
+        elif not in_dev_topk and kth is not None and s_dev <= kth and (ko is None or (s_ora - ko) <= dev_move + abs(kth - ko)):
             cat["pre_cut"] += 1
             margins.append((s_ora - ko) if ko is not None else 0.0)
+        elif not ok_d[cell] and s_dev > thr and max(abs(float(cxd[cell]) - float(cx[cell])), abs(float(cyd[cell]) - float(cy[cell]))) + 1e-3 >= min(
+                abs(float(cx[cell]) - rng_lim[0]), abs(float(cx[cell]) - rng_lim[3]), abs(float(cy[cell]) - rng_lim[1]), abs(float(cy[cell]) - rng_lim[4])):
+            cat["range"] += 1  # the device's centre of this cell left post_center_limit_range by no more than the two centres differ
         elif len(cand) and float(oops.boxes_iou_bev(nms_layout(row[None, :9]), nms_layout(cand[:, :9])).max()) > iou_thr - 6e-2:
             cat["nms"] += 1
         elif len(cand) >= post_max and float(cand[:, 9].min()) >= s_dev - 1.5e-2:
@@ -1426,10 +1438,11 @@ def _attribute_bf16_detections(tag, cfg, g, w, opreds, dpreds, min_rows=20):
         else:
             cat["unexplained"] += 1
     report(tag + " bf16 detections vs bf16 oracle: not found", float(len(w) - cat["found"]), float(len(w)),
-           "(of %d: score %d, pre-max cut %d, NMS %d, post-max cut %d, unexplained %d; %d distinct cells; pre-max losses sat %.1e .. %.1e above the oracle's cut)"
-           % (len(w), cat["score"], cat["pre_cut"], cat["nms"], cat["post_cut"], cat["unexplained"], len(lost_cells), min(margins) if margins else 0.0,
+           "(of %d: score %d, pre-max cut %d, range %d, NMS %d, post-max cut %d, unexplained %d; %d distinct cells; pre-max losses sat %.1e .. %.1e above the oracle's cut)"
+           % (len(w), cat["score"], cat["pre_cut"], cat["range"], cat["nms"], cat["post_cut"], cat["unexplained"], len(lost_cells), min(margins) if margins else 0.0,
               max(margins) if margins else 0.0))
     assert cat["unexplained"] == 0, cat
+    assert all(m >= 0.0 for m in margins), ("a detection lost to the pre-max cut must sit AT or ABOVE the oracle's own cut", margins)
     # (a scene with a handful of detections: ONE attributed cell is 7 rows of 21 -- the share rule applies beyond one cell)
     assert cat["found"] >= 0.8 * len(w) or len(lost_cells) <= 1, (cat, len(lost_cells))
     return cat

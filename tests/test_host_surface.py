@@ -400,15 +400,21 @@ def test_bench_refuses_more_ranks_than_devices():
     assert out.returncode == 2 and "device(s) are visible" in out.stderr and "n_gpus" not in out.stdout
 
 
-def test_bench_all_cores_probe_child_process():
-    """cpu_baseline's all-core figure is measured by a child process with a wall-clock bound; the child mode prints one line."""
-    import subprocess
-    import sys
+def test_bench_cpu_baseline_reports_the_all_core_sample():
+    """bench.cpu_baseline runs the oracle on every logical CPU of the host in-process (the sparse conv is one OpenMP region over output
+    rows: no fork / join per tap) and matches the rows it is given against the oracle's detections."""
+    import bench
+    from futuredet_amd.configs import centerpoint_config
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims
 
-    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--cpu-all-cores-probe", "--points", "4000"], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("ALLCORES")]
-    assert len(lines) == 1 and float(lines[0].split()[1]) > 0
+    cfg = centerpoint_config("forecast_n0")
+    net = fa.build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    sd = tame_box_dims(seeded_state_dict(net, 7))
+    cloud = synthetic_cloud(seed=0, target_points=3000)
+    out, par = bench.cpu_baseline(cfg, sd, cloud, np.zeros((0, 11), np.float32), budget_s=(0.5, 0.5))
+    assert out["cores"] in (os.cpu_count(), 64) and out["host_cpu_count"] == os.cpu_count() and out["kind"] == "port"
+    assert out["value"] > 0 and out["value_all_cores"] > 0 and out["value_all_cores_passes"] >= 3
+    assert par["gpu_rows"] == 0 and par["unmatched"] == par["oracle_rows"]
 
 
 def test_load_checkpoint_follows_the_reference_contract(tmp_path):
