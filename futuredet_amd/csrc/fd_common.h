@@ -15,6 +15,12 @@ int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bi
                                 int64_t nbr_stride, int K, int64_t n_in_bound, int n_out, const int *n_out_dev, int cin, int cout, float *out,
                                 const int *ranges, int n_ranges, hipStream_t stream);
 
+// fd_spconv_bf16win.hip: 64 -> 64, 128 -> 128 with an LDS window of input rows and 32-row MFMA tiles; its weight layout
+// follows the standard one in the packed buffer (spconv_bf16_win_weight_bytes > 0); 1 = launched, 0 = shape not covered
+size_t spconv_bf16_win_weight_bytes(int K, int cin, int cout);
+void spconv_bf16_win_pack(const float *w, int K, int cin, int cout, uint16_t (*tobf)(float), uint16_t *dst);
+int spconv_bf16_win_dispatch(const void *in, const void *wp_win, const float *bias, const void *residual, int relu, const int *nbr, int64_t nbr_stride, int K,
+                             int64_t n_in_bound, int n_out, const int *n_out_dev, int64_t n_expected, int cin, int cout, void *out, hipStream_t stream);
 int spconv_bf16_ws_dispatch(const void *in, const void *wp, const float *bias, const void *residual, int relu, const int *nbr, int64_t nbr_stride, int K,
                             int64_t n_in_bound, int n_out, const int *n_out_dev, int64_t n_expected, int cin, int cout, void *out, hipStream_t stream);
 
@@ -77,7 +83,7 @@ int device_cu_count();  // compute units of the current device, cached per devic
 bool ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done);
 // Tuning / test knobs (fd_tuning_set; initial values are read ONCE from the FD_* environment variables when the
 // library is loaded).  0 = the built-in heuristic.
-enum TuneKey { kTuneSpconvRG = 0, kTuneSpconvV1, kTuneSpconvBf16V1, kTuneV2Depth, kTuneV2TM, kTuneV2LdsPad, kTuneConvNT, kTuneV2RangesPerCU, kTuneV2Uniform, kTuneV2RowCost, kTuneSpconvC32, kTuneBf16GP, kTuneBf16RG, kTuneBf16Depth, kTuneBf16NW, kTuneStrict, kTuneF32ResRG, kTuneConvStrip, kTuneCount };
+enum TuneKey { kTuneSpconvRG = 0, kTuneSpconvV1, kTuneSpconvBf16V1, kTuneV2Depth, kTuneV2TM, kTuneV2LdsPad, kTuneConvNT, kTuneV2RangesPerCU, kTuneV2Uniform, kTuneV2RowCost, kTuneSpconvC32, kTuneBf16GP, kTuneBf16RG, kTuneBf16Depth, kTuneBf16NW, kTuneStrict, kTuneBf16Win, kTuneF32ResRG, kTuneConvStrip, kTuneCount };
 int tuning(TuneKey key);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

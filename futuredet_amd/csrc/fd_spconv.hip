@@ -272,7 +272,8 @@ inline int64_t pair_layout_elems(int K, int cin, int cout, int dtype) { return (
 
 extern "C" size_t fd_spconv_packed_weight_bytes(int K, int cin, int cout, int dtype) {
     if (K <= 0 || cin <= 0 || cout <= 0) return 0;
-    return (size_t)K * cin * cout * (dtype == 0 ? 4 : 2) * (has_c32_layout(cin, cout, dtype) ? 2 : 1) + (size_t)pair_layout_elems(K, cin, cout, dtype) * 2;
+    return (size_t)K * cin * cout * (dtype == 0 ? 4 : 2) * (has_c32_layout(cin, cout, dtype) ? 2 : 1) + (size_t)pair_layout_elems(K, cin, cout, dtype) * 2 +
+           (dtype == 1 ? fd::spconv_bf16_win_weight_bytes(K, cin, cout) : 0);
 }
 
 extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, int dtype, void *dst) {
@@ -283,7 +284,7 @@ extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, i
     FD_REQUIRE(dtype == 0 || dtype == 1, "fd_spconv_pack_weight: dtype must be 0 (f32) or 1 (bf16)");
     const int NB = cout / 16;
     auto W = [&](int k, int ci, int co) { return w[((int64_t)k * cin + ci) * cout + co]; };
-    auto tobf = [](float v) {
+    auto tobf = [](float v) -> uint16_t {
         union { float f; uint32_t u; } cvt;
         cvt.f = v;
         uint32_t u = cvt.u;
@@ -319,6 +320,8 @@ extern "C" int fd_spconv_pack_weight(const float *w, int K, int cin, int cout, i
                         for (int j = 0; j < 8; ++j)
                             d[((((int64_t)k * NC + c) * NB + nb) * 64 + lane) * 8 + j] =
                                 tobf(W(k, 32 * c + 8 * (lane >> 4) + j, 16 * nb + (lane & 15)));
+        // the LDS-window kernel's 32x32x16 fragment order follows (fd_spconv_bf16win.hip)
+        if (fd::spconv_bf16_win_weight_bytes(K, cin, cout)) fd::spconv_bf16_win_pack(w, K, cin, cout, +tobf, d + (int64_t)K * cin * cout);
     } else {
         uint16_t *d = (uint16_t *)dst;
         for (int k = 0; k < K; ++k)
@@ -372,6 +375,12 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
     if (dtype == 1 && fd::tuning(fd::kTuneBf16GP) >= 0) {
         // bf16: register accumulators + LDS-shared weights (fd_spconv_bf16.hip); 16 input channels read the tap-pair weight layout
         const void *w = cin == 16 ? (const void *)((const char *)wpacked + (size_t)K * cin * cout * 2) : wpacked;
+        // 64 -> 64, 128 -> 128 (the SubM layers of levels 2 and 3): LDS window of input rows + 32-row register tiles
+        // (fd_spconv_bf16win.hip); "bf16_win" = -1 keeps the RING / RESIDENT kernels (A/B runs, variant tests)
+        if (fd::tuning(fd::kTuneBf16Win) >= 0 && fd::spconv_bf16_win_weight_bytes(K, cin, cout) &&
+            fd::spconv_bf16_win_dispatch(in_feats, (const char *)wpacked + (size_t)K * cin * cout * 2, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out,
+                                         n_out_dev, n_expected, cin, cout, out_feats, fd::as_stream(stream)))
+            return fd::check_launch("fd_spconv_apply(bf16 window)");
         if (fd::spconv_bf16_ws_dispatch(in_feats, w, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out, n_out_dev, n_expected, cin, cout, out_feats,
                                         fd::as_stream(stream)))
             return fd::check_launch("fd_spconv_apply(bf16 ws)");

@@ -36,7 +36,8 @@ const char *fd_last_error(void);
  * "spconv_bf16_v1", "v2_depth", "v2_tm", "v2_ldspad", "conv_nt" (output channels per workgroup of the bf16 dense conv: 64 | 32),
  * "v2_ranges_per_cu", "v2_uniform", "v2_rowcost", "spconv_c32", "bf16_gp", "bf16_rg", "bf16_depth", "bf16_nw",
  * "strict" (1: a bf16 sparse layer that the gather-pipeline kernels cannot take is an error instead of a fall-back to the register
- * kernels), "f32_res_rg" (-1: 16-channel fp32 layers on the
+ * kernels), "bf16_win" (-1: the 64 -> 64 / 128 -> 128 bf16 layers on the RING / RESIDENT kernels instead of the LDS-window
+ * kernel of round 5), "f32_res_rg" (-1: 16-channel fp32 layers on the
  * pair-compacting kernel instead of the resident-weights one), "conv_strip" (1: stride-1 bf16 dense layers on strips of 128
  * consecutive pixels instead of 8 x 16 tiles: faster alone, slower with several sweeps in flight; results identical).  Initial
  * values come from the FD_SPCONV_RG, FD_SPCONV_V1, ... environment variables (FD_ + the upper-case name), read once when the

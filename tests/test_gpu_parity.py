@@ -148,12 +148,13 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
     wpk = hip.pack_spconv_weight(torch.from_numpy(w), tdt).cuda()
     run = lambda: hip.spconv_apply(x, wpk, _dev(bias), nbr, src.n, cout, residual=res, relu=True).float().cpu().numpy()  # noqa: E731
     v1_knob = "spconv_v1" if dtype == "f32" else "spconv_bf16_v1"
-    y_ws = []
+    y_ws, y_ring, y_ring_v = [], None, []
     try:
         y_default = run()
         if dtype == "bf16":
-            # the round-3 kernel (fd_spconv_bf16.hip): rows per wave x gather-ring depth variants must agree bit for bit with
-            # the default (fixed summation order: taps ascending, channel chunks ascending)
+            # the default kernel family of the shape -- the LDS-window kernel (fd_spconv_bf16win.hip) for 64 -> 64 and 128 -> 128,
+            # the round-3 RESIDENT / RING kernels (fd_spconv_bf16.hip) otherwise: rows per wave x gather-ring depth variants must agree
+            # bit for bit with the default (fixed summation order: taps ascending, channel chunks ascending)
             for rg in (1, 2, 3, 4):
                 for depth in (2, 4):
                     hip.set_tuning("bf16_rg", rg)
@@ -161,6 +162,13 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
                     y_ws.append(run())
             hip.set_tuning("bf16_rg", 0)
             hip.set_tuning("bf16_depth", 0)
+            if cin == cout and cin >= 64:  # the RING kernels behind the window kernel: their own variants, bit for bit
+                hip.set_tuning("bf16_win", -1)
+                y_ring = run()
+                for rg in (1, 2, 3):
+                    hip.set_tuning("bf16_rg", rg)
+                    y_ring_v.append(run())
+                hip.set_tuning("bf16_rg", 0)
             hip.set_tuning("bf16_gp", -1)  # the older kernels: column split (default where it applies) ...
             y_old = run()
         hip.set_tuning(v1_knob, 1)          # ... and the register kernel
@@ -174,6 +182,9 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
         hip.set_tuning("bf16_rg", 0)
         hip.set_tuning("bf16_depth", 0)
         hip.set_tuning("bf16_gp", 0)
+        hip.set_tuning("bf16_win", 0)
+    for other in y_ring_v:
+        assert np.array_equal(y_ring, other), "bf16 RING / RESIDENT kernels: rows-per-wave variants must agree bit for bit"
     for other in y_ws:
         assert np.array_equal(y_default, other), "bf16: rows-per-wave / ring-depth variants must agree bit for bit"
     for other in ys[1:]:
@@ -215,10 +226,76 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
     assert_close("spconv_apply %s %d->%d register kernel vs oracle" % (dtype, cin, cout), ys[0], ref_sorted, tol)
     if dtype == "bf16":
         assert_close("spconv_apply bf16 %d->%d round-2 kernel vs oracle" % (cin, cout), y_old, ref_sorted, tol)
+        if y_ring is not None:
+            assert_close("spconv_apply bf16 %d->%d RING / RESIDENT kernel (behind the window kernel) vs oracle" % (cin, cout), y_ring, ref_sorted, tol)
     if dtype == "f32" and (cin, cout) == (32, 32):
         assert_close("spconv_apply f32 32->32 16-pair compacting kernel vs oracle", ys[-1], ref_sorted, tol)
     if dtype == "f32" and cin == 16:
         assert_close("spconv_apply f32 %d->%d pair-compacting kernel vs oracle" % (cin, cout), y_compact, ref_sorted, tol)
+
+
+@pytest.mark.parametrize("c", [64, 128])
+def test_bf16_window_kernel_without_locality_multi_pass_and_device_count(hip, c):
+    """fd_spconv_bf16win.hip: correctness must not depend on the rulebook's locality (an item with a neighbour outside the LDS window
+    takes the global gather), on the number of passes of a workgroup, or on where the row count comes from.  (a) a SubM rulebook of a
+    sorted index, (b) the same rulebook with its input rows PERMUTED at random (no locality at all: every item gathers), (c) the same with
+    the row count read from device memory and a capacity-sized launch -- all against a float64 host evaluation of
+    sum_k in[nbr[k][o]] @ W[k] on the bf16-rounded operands (2e-2), (b) and (c) bit-identical to (a); row-group variants of (b) bit for
+    bit (58k rows: at one row group per wave the 256 workgroups need two passes each)."""
+    rng = np.random.default_rng(c)
+    B, D, H, W = 1, 21, 96, 96  # ~58k rows: more than 256 workgroups x 128 rows, so one row group per wave needs two passes
+    idx, feats = _random_sparse(rng, B, D, H, W, 0.3, c)
+    src = hip.SparseIndex(B, D, H, W, torch.device("cuda"))
+    n_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    src.mark(_dev(idx))
+    src.scan(n_dev)
+    src.finalize(int(n_dev.cpu()[0]))
+    n = src.n
+    x = hip.rows_permute(_dev(feats), src.lookup(_dev(idx)), c, torch.bfloat16, n_rows=n)
+    w = (rng.standard_normal((27, c, c)) * np.sqrt(2.0 / (27 * c))).astype(np.float32)
+    bias = rng.standard_normal(c).astype(np.float32)
+    wpk = hip.pack_spconv_weight(torch.from_numpy(w), torch.bfloat16).cuda()
+    nbr = src.rulebook(src, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    res = _dev(rng.standard_normal((n, c)).astype(np.float32)).bfloat16()
+    y_a = hip.spconv_apply(x, wpk, _dev(bias), nbr, n, c, residual=res, relu=True)
+    # float64 evaluation of the definition on the rounded operands (torch matmul in double precision: not one of our kernels)
+    xf, wf = x.double(), torch.from_numpy(w).bfloat16().double().cuda()
+    ref = _dev(bias).double().repeat(n, 1)
+    for k in range(27):
+        m = nbr[k, :n] >= 0
+        ref[m] += xf[nbr[k, :n][m].long()] @ wf[k]
+    ref = torch.clamp_min(ref + res.double(), 0).cpu().numpy()
+    assert_close("bf16 window kernel %d->%d vs float64 evaluation of the definition (%d rows)" % (c, c, n), y_a.float().cpu().numpy(), ref, 2e-2)
+    # (b) permuted input rows: x2[perm[i]] = x[i], rulebook entries renamed -- the same sums, no locality
+    perm = torch.from_numpy(rng.permutation(n)).cuda()
+    x2 = torch.empty_like(x)
+    x2[perm] = x
+    nbr2 = nbr.clone()
+    sel = nbr2[:, :n] >= 0
+    nbr2[:, :n][sel] = perm[nbr2[:, :n][sel].long()].int()
+    for a in ("n_out", "n_dev", "n_expected"):
+        if hasattr(nbr, a):
+            setattr(nbr2, a, getattr(nbr, a))
+    y_b = hip.spconv_apply(x2, wpk, _dev(bias), nbr2, n, c, residual=res, relu=True)
+    assert torch.equal(y_a, y_b), "a rulebook without locality must give the same bits (every item on the gather path)"
+    try:
+        for rg in (1, 2, 4):
+            hip.set_tuning("bf16_rg", rg)
+            assert torch.equal(y_b, hip.spconv_apply(x2, wpk, _dev(bias), nbr2, n, c, residual=res, relu=True))
+            assert torch.equal(y_a, hip.spconv_apply(x, wpk, _dev(bias), nbr, n, c, residual=res, relu=True))
+    finally:
+        hip.set_tuning("bf16_rg", 0)
+    # (c) capacity launch with the row count on the device (what a captured sweep does): rows beyond the count are not written
+    cap = n + 777
+    nbr3 = torch.full((27, (cap + 63) // 64 * 64), -1, dtype=torch.int32, device="cuda")
+    nbr3[:, :n] = nbr[:, :n]
+    nbr3.n_out, nbr3.n_dev, nbr3.n_expected = cap, torch.tensor([n], dtype=torch.int32, device="cuda"), 2000  # (a low estimate: several passes)
+    x3 = torch.cat([x, torch.zeros((cap - n, c), dtype=x.dtype, device="cuda")])
+    res3 = torch.cat([res, torch.zeros((cap - n, c), dtype=x.dtype, device="cuda")])
+    out3 = torch.full((cap, c), 7.0, dtype=torch.bfloat16, device="cuda")
+    hip.spconv_apply(x3, wpk, _dev(bias), nbr3, cap, c, residual=res3, relu=True, out=out3)
+    assert torch.equal(out3[:n], y_a) and bool((out3[n:] == 7.0).all())
+    report("bf16 window kernel %d->%d: permuted rulebook, row-group variants and a device-count capacity launch bit-identical" % (c, c), 0.0, 0.0)
 
 
 # the four conv geometries of SpMiddleResNetFHD (scn.py:99-143) x channel pairs from 16 to 128

@@ -26,6 +26,7 @@ ap.add_argument("--gp", default="0", help="bf16: comma list of bf16_gp knob valu
 ap.add_argument("--rg", default="0", help="bf16 gather pipeline: comma list of row groups per wave (0 = heuristic)")
 ap.add_argument("--exp", type=int, default=0, help="bf16: experiment knob (timing only, results wrong)")
 ap.add_argument("--bdepth", default="0", help="bf16 gather pipeline: comma list of ring depths (0 = heuristic)")
+ap.add_argument("--win", default="0", help="bf16: comma list of bf16_win knob values (0 = LDS-window kernel where it applies, -1 = RING / RESIDENT kernels)")
 args = ap.parse_args()
 dev = torch.device("cuda")
 dt = torch.float32 if args.dtype == "fp32" else torch.bfloat16
@@ -52,9 +53,13 @@ for lvl in [int(v) for v in args.levels.split(",")]:
     ref = None
     variants = [(rpc, mode, 0, 0, 0) for rpc in [int(v) for v in args.rpc.split(",")] for mode in args.modes.split(",")]
     if args.dtype != "fp32":
-        variants = [(0, "uniform", gp, rg, bd) for gp in [int(v) for v in args.gp.split(",")] for rg in [int(v) for v in args.rg.split(",")]
+        variants = [(0, "uniform", gp + 10 * wn, rg, bd) for wn in [int(v) for v in args.win.split(",")] for gp in [int(v) for v in args.gp.split(",")]
+                    for rg in [int(v) for v in args.rg.split(",")]
                     for bd in [int(v) for v in args.bdepth.split(",")] if gp == 0 or (rg == int(args.rg.split(",")[0]) and bd == int(args.bdepth.split(",")[0]))]
     for rpc, mode, gp, rg, bd in variants:
+        wn = -1 if gp <= -5 else 0   # (gp carries the bf16_win knob in its tens: 0 / -10)
+        gp = gp - 10 * wn
+        hip_ops.set_tuning("bf16_win", wn)
         hip_ops.set_tuning("v2_ranges_per_cu", rpc)
         hip_ops.set_tuning("bf16_gp", gp)
         hip_ops.set_tuning("bf16_rg", rg)
@@ -69,11 +74,12 @@ for lvl in [int(v) for v in args.levels.split(",")]:
             torch.cuda.synchronize()
             if ref is None:
                 ref = {}
-            if gp not in ref:
-                ref[gp] = y.clone()
+            key = (gp, wn)
+            if key not in ref:
+                ref[key] = y.clone()
                 for other in ([] if args.exp else ref.values()):  # two bf16 kernel families: same data, different summation trees
                     assert float((other.float() - y.float()).abs().max()) <= 2e-2 * float(other.float().abs().max()), "bf16 kernels disagree"
-            assert torch.equal(ref[gp], y), "work distribution changed the result"
+            assert torch.equal(ref[key], y), "work distribution changed the result"
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.iters):
@@ -83,7 +89,8 @@ for lvl in [int(v) for v in args.levels.split(",")]:
             us = 1e3 * e0.elapsed_time(e1) / args.iters
             s = 4 if dt == torch.float32 else 2
             bgs = s * pairs * 2 * C + 8 * pairs + s * 27 * C * C
-            tag = "%-8s rpc=%d" % (mode, rpc) if args.dtype == "fp32" else "gp=%d rg=%d depth=%d" % (gp, rg, bd)
+            tag = "%-8s rpc=%d" % (mode, rpc) if args.dtype == "fp32" else "win=%d gp=%d rg=%d depth=%d" % (wn, gp, rg, bd)
             print("level %d C=%3d n=%6d pairs=%7d (%.1f/row) %s %s: %7.1f us  %6.1f TFLOP/s  B_gs %.0f GB/s" %
                   (lvl, C, ix.n, pairs, pairs / ix.n, args.dtype, tag, us, 2.0 * pairs * C * C / us / 1e6, bgs / us / 1e3), flush=True)
     hip_ops.set_tuning("v2_ranges_per_cu", 0)
+    hip_ops.set_tuning("bf16_win", 0)
