@@ -390,112 +390,302 @@ __global__ void __launch_bounds__(kSelThreads) dec_select(const unsigned *__rest
     }
 }
 
-// The same selection with the keys of a group held in REGISTERS (PER per thread, cell = tid + 1024 j: coalesced loads, one pass over
-// global memory instead of six) and ties resolved inside the radix selection: the selection runs over the 49-bit value
-// (score bits << 17 | 0x1ffff - cell), which is unique per cell and orders equal scores by ascending cell -- exactly "all keys > T,
-// then the first take_eq keys == T in cell order" of dec_select above, without its two extra passes and second block scan.
-// Four histogram passes (12 + 12 + 12 + 13 bits), one block scan for the output slots (slot order is free: the bitonic sort over the
-// unique (score, cell) words fixes the final order), then the same sort and box decode.  74 -> ~30 us on the saturated 180 x 180 map.
-template <int PER>
-__global__ void __launch_bounds__(kSelThreads) dec_select_reg(const unsigned *__restrict__ keys_all, MapView reg, MapView height, MapView dim, MapView rot,
-                                                              DecCfg c, int npad, float *__restrict__ sel_boxes, float *__restrict__ nms_boxes,
-                                                              float *__restrict__ sel_scores, int *__restrict__ sel_cell, int *__restrict__ sel_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *s_sort = reinterpret_cast<unsigned long long *>(smem);     // [npad]
-    int *s_hist = reinterpret_cast<int *>(smem + (size_t)npad * 8);                // [8192]
-    int *s_misc = s_hist + 8192;                                                   // [32]
-    const int g = blockIdx.x;
-    const unsigned *keys = keys_all + (int64_t)g * c.HW;
-    const int tid = threadIdx.x;
-    unsigned k[PER];
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int cell = tid + j * kSelThreads;
-        k[j] = cell < c.HW ? keys[cell] : 0u;
-        cnt += k[j] != 0u;
+// ---------------------------------------------------------------- stages 1-2, round 5: histogram with the keys, selection without a sort
+// The round-4 selection (one workgroup per group: four radix passes over the keys, an LDS bitonic sort of the pre_max survivors, the box
+// decode) took 52 us of a sweep's 113-us back end.  Now:
+//   dec_keys_hist   every block of 1024 cells writes its keys AND a 1024-bin histogram of them -- bins of equal width over the only range a
+//                   key can lie in, (score_threshold, 1.0] as float32 bit patterns -- so the selection starts from the histogram;
+//   dec_select_hist one workgroup per group sums the block histograms, finds the bin in which the pre_max-th best key lies, takes every key
+//                   above that bin, and resolves the (few dozen) keys INSIDE it by ranking them against each other (all pairs, LDS broadcast);
+//                   a degenerate map (thousands of equal scores) takes three radix passes over the remaining 37 bits instead.  The
+//                   survivors are written UNSORTED as (score bits << 32 | ~cell) words;
+//   dec_rank_decode the order is a rank: element i goes to slot #{j : word_j > word_i} (the words are unique) -- spread over
+//                   ceil(pre_max / 256) workgroups per group, four threads per element; the thread that owns the element decodes its box
+//                   (exp / atan2) and writes box, pcdet-layout footprint, score and cell at the slot.
+// Same result as before by construction: the order is (score descending, cell ascending), ties included.
+struct KeyBins {
+    unsigned base;   // keys are > base (the threshold's bit pattern; 0 for a threshold <= 0)
+    int shift;       // bin of key k = (k - base) >> shift, < 1024
+};
+inline KeyBins make_key_bins(float thr) {
+    KeyBins kb;
+    union { float f; unsigned u; } c;
+    c.f = thr > 0.f ? thr : 0.f;
+    kb.base = c.u;
+    const unsigned range = 0x3f800000u > kb.base ? 0x3f800000u - kb.base : 1u;  // scores are sigmoids: <= 1.0f
+    int bits = 0;
+    while ((range >> bits) != 0u) ++bits;
+    kb.shift = bits > 10 ? bits - 10 : 0;
+    return kb;
+}
+__device__ inline int key_bin(const KeyBins &kb, unsigned k) {
+    const unsigned d = (k - kb.base) >> kb.shift;
+    return (int)(d < 1023u ? d : 1023u);  // (a key above 1.0f cannot occur; clamped rather than trusted)
+}
+
+// LDS histogram update that survives concentrated keys.  A plain atomicAdd per lane serialises on the bank when many lanes hit one bin --
+// and heat-map scores DO concentrate (random-weight and saturated maps: all keys within a few bins): 64 lanes on one address cost 64 LDS
+// cycles per instruction, which is where the 52 us of round 4's four radix passes went.  Up to four rounds of "the first active lane's bin:
+// one lane adds the number of lanes that share it"; lanes left after that (spread keys: little contention anyway) add for themselves.
+__device__ inline void hist_add(int *hist, int bin, bool active) {
+    unsigned long long todo = __ballot(active);
+#pragma unroll 1
+    for (int round = 0; round < 4 && todo; ++round) {
+        const int leader = __builtin_ctzll(todo);
+        const int b0 = __builtin_amdgcn_readlane(bin, leader);  // (leader is wave-uniform)
+        const unsigned long long same = __ballot(active && bin == b0) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b0], (int)__builtin_popcountll(same));
+        todo &= ~same;
     }
-    block_sum_1024(cnt, s_misc);
-    const int M = s_misc[16];
-    __syncthreads();
-    // the value a cell competes with: (score bits, 0x1ffff - cell), 49 bits, unique per cell -- kept as its two 32-bit halves
-    // (no 64-bit temporaries: 32 .. 72 keys per thread leave little room in the 128 registers of a 1024-thread workgroup)
-    unsigned Tk = 0u, Tc = 0u;  // select (k, ci) >= (Tk, Tc); M <= pre_max: every valid key (k >= 1)
-    if (M > c.pre_max) {
-        int need = c.pre_max;
-        unsigned p0 = 0u, p1 = 0u, p2 = 0u;
-        auto radix_pass = [&](int nb, auto digit_of, auto matches) -> unsigned {
-            for (int i = tid; i < nb; i += kSelThreads) s_hist[i] = 0;
-            __syncthreads();
+    if (active && ((todo >> (threadIdx.x & 63)) & 1ull)) atomicAdd(&hist[bin], 1);
+}
+
+constexpr int kKeyBlock = 1024;  // cells per block of dec_keys_hist
+__global__ void __launch_bounds__(256) dec_keys_hist(MapView hm, MapView reg, MapView height, DecCfg c, KeyBins kb, unsigned *__restrict__ keys,
+                                                     int *__restrict__ hist_part /*[G][blocks][1024]*/) {
+    __shared__ int s_hist[1024];
+    const int g = blockIdx.y, tid = threadIdx.x;
 #pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                const unsigned ci = 0x1ffffu - (unsigned)(tid + j * kSelThreads);
-                if (k[j] != 0u && matches(k[j], ci)) atomicAdd(&s_hist[digit_of(k[j], ci)], 1);
-            }
-            find_bin<8>(s_hist, nb, need, s_misc, s_misc + 20);
-            const unsigned b = (unsigned)s_misc[20];
-            need -= s_misc[21];
-            __syncthreads();
-            return b;
-        };
-        p0 = radix_pass(4096, [](unsigned kk, unsigned) { return (int)(kk >> 20); }, [](unsigned, unsigned) { return true; });
-        p1 = radix_pass(4096, [](unsigned kk, unsigned) { return (int)((kk >> 8) & 0xfffu); }, [&](unsigned kk, unsigned) { return (kk >> 20) == p0; });
-        const unsigned k24 = (p0 << 12) | p1;
-        p2 = radix_pass(4096, [](unsigned kk, unsigned ci) { return (int)(((kk & 0xffu) << 4) | (ci >> 13)); }, [&](unsigned kk, unsigned) { return (kk >> 8) == k24; });
-        Tk = (k24 << 8) | (p2 >> 4);
-        const unsigned c4 = p2 & 0xfu;
-        const unsigned p3 = radix_pass(8192, [](unsigned, unsigned ci) { return (int)(ci & 0x1fffu); }, [&](unsigned kk, unsigned ci) { return kk == Tk && (ci >> 13) == c4; });
-        Tc = (c4 << 13) | p3;  // (need == 1 here: the values are unique)
-    } else {
-        Tk = 1u;
-    }
-    auto selected = [&](unsigned kk, unsigned ci) { return kk != 0u && (kk > Tk || (kk == Tk && ci >= Tc)); };
-    for (int i = tid; i < npad; i += kSelThreads) s_sort[i] = 0ull;
-    int n_sel = 0;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) n_sel += selected(k[j], 0x1ffffu - (unsigned)(tid + j * kSelThreads));
-    int pos = block_sum_1024(n_sel, s_misc);
-    const int S = s_misc[16];  // = min(M, pre_max)
+    for (int i = 0; i < 4; ++i) s_hist[tid + 256 * i] = 0;
     __syncthreads();
+    unsigned kk[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const unsigned cell = (unsigned)(tid + j * kSelThreads);
-        if (selected(k[j], 0x1ffffu - cell)) s_sort[pos++] = ((unsigned long long)k[j] << 32) | (unsigned)(0xffffffffu - cell);
-    }
-    __syncthreads();
-    // bitonic sort descending over npad entries (zeros sink to the end)
-    for (int k2 = 2; k2 <= npad; k2 <<= 1) {
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < npad; t += kSelThreads) {
-                int ixj = t ^ j;
-                if (ixj > t) {
-                    unsigned long long a = s_sort[t], b = s_sort[ixj];
-                    bool desc = ((t & k2) == 0);
-                    if (desc ? (a < b) : (a > b)) { s_sort[t] = b; s_sort[ixj] = a; }
-                }
-            }
-            __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+        const int cell = blockIdx.x * kKeyBlock + tid + 256 * i;
+        if (cell < c.HW) {
+            float logit = ld(hm, g, 0, cell);
+            for (int ch = 1; ch < c.hm_channels; ++ch) logit = fmaxf(logit, ld(hm, g, ch, cell));  // center_head.py:592: torch.max over the class channels
+            const float score = 1.0f / (1.0f + expf(-logit));
+            float x, y;
+            cell_center(c, reg, g, cell, x, y);
+            const float z = ld(height, g, 0, cell);
+            const bool ok = score > c.thr && x >= c.rng[0] && y >= c.rng[1] && z >= c.rng[2] && x <= c.rng[3] && y <= c.rng[4] && z <= c.rng[5];
+            const unsigned k = ok ? __float_as_uint(score) : 0u;
+            keys[(int64_t)g * c.HW + cell] = k;
+            kk[i] = k;
         }
     }
-    if (tid == 0) sel_count[g] = S;
-    for (int i = tid; i < S; i += kSelThreads) {
-        const unsigned long long e = s_sort[i];
-        const int cell = (int)(0xffffffffu - (unsigned)(e & 0xffffffffull));
-        const float score = __uint_as_float((unsigned)(e >> 32));
-        float x, y;
-        cell_center(c, reg, g, cell, x, y);
-        const float z = ld(height, g, 0, cell);
-        const float d0 = expf(ld(dim, g, 0, cell)), d1 = expf(ld(dim, g, 1, cell)), d2 = expf(ld(dim, g, 2, cell));
-        const float yaw = atan2f(ld(rot, g, 0, cell), ld(rot, g, 1, cell));
-        const int64_t o = ((int64_t)g * c.pre_max + i);
-        float *sb = sel_boxes + o * 7;
-        sb[0] = x; sb[1] = y; sb[2] = z; sb[3] = d0; sb[4] = d1; sb[5] = d2; sb[6] = yaw;
-        float *nb = nms_boxes + o * 7;  // box_torch_ops.py:256-257: [x,y,z,dim1,dim0,dim2,-yaw-pi/2]
-        nb[0] = x; nb[1] = y; nb[2] = z; nb[3] = d1; nb[4] = d0; nb[5] = d2;
-        nb[6] = __fsub_rn(-yaw, 1.5707963267948966f);
-        sel_scores[o] = score;
-        sel_cell[o] = cell;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hist_add(s_hist, kk[i] ? key_bin(kb, kk[i]) : 0, kk[i] != 0u);  // (outside the divergent part: the helper uses wave ballots)
+    __syncthreads();
+    int *dst = hist_part + ((int64_t)g * gridDim.x + blockIdx.x) * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[tid + 256 * i] = s_hist[tid + 256 * i];
+}
+
+#ifdef FD_DEC_TRACE  // tuning builds: thread 0 of dec_select_hist stamps its phases (tools/decode_trace.py)
+__device__ unsigned long long *g_dectrace;
+#define FD_DT(i) do { if (threadIdx.x == 0 && g_dectrace) g_dectrace[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FD_DT(i)
+#endif
+constexpr int kMaxCand = 1024;  // keys of the threshold bin ranked against each other in LDS; more take the radix passes
+// (the keys of the group live in LDS for the whole kernel -- 130 KB for the 180 x 180 map -- and every phase is a short loop over them: the
+//  round-4 kernel and the first version of this one held them in 32 registers per thread, unrolled every phase 32 times and spilled 392
+//  registers to scratch memory: 75 us, of which 60 in the two "trivial" counting / compaction loops)
+__global__ void __launch_bounds__(kSelThreads) dec_select_hist(const unsigned *__restrict__ keys_all, const int *__restrict__ hist_part, int n_blocks, DecCfg c,
+                                                               KeyBins kb, unsigned long long *__restrict__ sel_words /*[G][pre_max]*/,
+                                                               int *__restrict__ sel_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *s_hist = reinterpret_cast<int *>(smem);                                           // [2048]: [0, 1024) the key bins; all of it in the radix passes
+    unsigned long long *s_cand = reinterpret_cast<unsigned long long *>(s_hist + 2048);     // [kMaxCand]
+    int *s_misc = reinterpret_cast<int *>(s_cand + kMaxCand);                               // [32]
+    unsigned *s_keys = reinterpret_cast<unsigned *>(s_misc + 32);                           // [HW rounded up to 4096]
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const unsigned *keys = keys_all + (int64_t)g * c.HW;
+    unsigned long long *out = sel_words + (int64_t)g * c.pre_max;
+    const int HWp = (c.HW + 4095) & ~4095;
+    FD_DT(0);
+    // ---- the group's histogram: bin tid = sum over the blocks (coalesced: consecutive threads, consecutive bins); keys -> LDS
+    {
+        const int *hp = hist_part + (int64_t)g * n_blocks * 1024 + tid;
+        int v = 0;
+#pragma unroll 8
+        for (int b = 0; b < n_blocks; ++b) v += hp[(int64_t)b * 1024];
+        s_hist[tid] = v;
     }
+    {
+        // 16-byte loads where the four cells exist, all of a thread's loads in flight before the first LDS store (HWp / 4096 <= 8 rounds)
+        uint4 kv[8];
+        const int last4 = ((c.HW - 1) & ~3) - (((c.HW & 3) != 0 || (((uintptr_t)keys) & 15) != 0) ? 4 : 0);  // last 4-cell piece that is whole and aligned
+        const bool al = (((uintptr_t)keys) & 15) == 0 && last4 >= 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {  // unconditional loads at a clamped index (all in flight together); pieces past the whole ones are patched below
+            const int i0 = tid * 4 + r * 4 * kSelThreads;
+            const int ic = al ? (i0 <= last4 ? i0 : last4) : 0;
+            kv[r] = al ? *reinterpret_cast<const uint4 *>(keys + ic) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i0 = tid * 4 + r * 4 * kSelThreads;
+            if (i0 < HWp) {
+                uint4 v = kv[r];
+                if (!al || i0 > last4) {  // the ragged end (and unaligned maps): cell by cell
+                    v.x = i0 < c.HW ? keys[i0] : 0u;
+                    v.y = i0 + 1 < c.HW ? keys[i0 + 1] : 0u;
+                    v.z = i0 + 2 < c.HW ? keys[i0 + 2] : 0u;
+                    v.w = i0 + 3 < c.HW ? keys[i0 + 3] : 0u;
+                }
+                *reinterpret_cast<uint4 *>(s_keys + i0) = v;
+            }
+        }
+    }
+    __syncthreads();
+    FD_DT(1);
+    // one block scan from the top bin down: thread t owns bin 1023 - t.  The bin in which the cumulative count reaches pre_max is the
+    // threshold bin (none when fewer keys than pre_max are valid: every key is taken)
+    {
+        const int h = s_hist[1023 - tid];
+        const int acc = block_sum_1024(h, s_misc);  // keys in the bins above this thread's
+        const int M_all = s_misc[16];
+        __syncthreads();
+        if (tid == 0) { s_misc[20] = -1; s_misc[21] = 0; s_misc[22] = 0; s_misc[23] = 0; }
+        __syncthreads();
+        if (M_all > c.pre_max && acc < c.pre_max && acc + h >= c.pre_max) { s_misc[20] = 1023 - tid; s_misc[21] = acc; }
+        __syncthreads();
+    }
+    const int M = s_misc[16];
+    const int bsel = s_misc[20], above = s_misc[21];  // every key in a bin > bsel is taken; bsel = -1: all of them
+    const int n_cand = bsel >= 0 ? s_hist[bsel] : 0, need = c.pre_max - above;  // (n_cand >= need by the choice of the bin)
+    FD_DT(2);
+#ifdef FD_DEC_TRACE
+    if (threadIdx.x == 0 && g_dectrace) { g_dectrace[blockIdx.x * 16 + 8] = (unsigned long long)M; g_dectrace[blockIdx.x * 16 + 9] = (unsigned long long)n_cand; g_dectrace[blockIdx.x * 16 + 10] = (unsigned long long)need; }
+#endif
+    // ---- one pass over the keys: those above the bin go straight to the output, those inside it to the LDS list (or, when the whole bin is
+    //      taken, to the output as well).  Slots come from two LDS counters, one atomicAdd per wave and round (ballot + lane rank); the order
+    //      of the survivors is free: dec_rank_decode ranks them.  (Two counting loops and two block scans in front of the writes, as first
+    //      written, were 10 of this kernel's 17 us.)
+    const bool list = bsel >= 0 && need > 0 && n_cand <= kMaxCand && n_cand > need;  // the bin's keys are ranked in LDS
+    const bool all_in = bsel >= 0 && n_cand == need;                               // the whole bin is taken
+    const int lane = tid & 63;
+#pragma unroll 4
+    for (int i = tid; i < HWp; i += kSelThreads) {  // (HWp is a multiple of 4096: whole waves run every round)
+        const unsigned k = s_keys[i];
+        const int b = k ? key_bin(kb, k) : -2;
+        const bool is_def = b > bsel, is_cand = b == bsel && b >= 0;
+        const unsigned long long w = ((unsigned long long)k << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+        const unsigned long long md = __ballot(is_def), mc = __ballot(is_cand);
+        if (md) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_misc[22], (int)__builtin_popcountll(md));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (is_def) out[base + (int)__builtin_popcountll(md & ((1ull << lane) - 1ull))] = w;
+        }
+        if (mc && (list || all_in)) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_misc[23], (int)__builtin_popcountll(mc));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int slot = base + (int)__builtin_popcountll(mc & ((1ull << lane) - 1ull));
+            if (is_cand) {
+                if (all_in) out[above + slot] = w;
+                else s_cand[slot] = w;
+            }
+        }
+    }
+    if (tid == 0) sel_count[g] = M < c.pre_max ? M : c.pre_max;
+    FD_DT(3);
+    if (bsel < 0 || need <= 0 || all_in) return;  // (uniform)
+    if (list) {
+        const int n_pad = (n_cand + 7) & ~7;
+        __syncthreads();
+        if (tid >= n_cand && tid < n_pad) s_cand[tid] = 0ull;  // (a zero word is greater than nothing)
+        __syncthreads();
+        if (tid < n_cand) {
+            const unsigned long long w = s_cand[tid];
+            int rank = 0;
+            for (int jj = 0; jj < n_pad; jj += 8) {  // eight independent LDS reads per round (the plain loop was one dependent round trip per word)
+                unsigned long long o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = s_cand[jj + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank += o[u] > w;
+            }
+            if (rank < need) out[above + rank] = w;
+        }
+        FD_DT(4);
+        return;
+    }
+    // ---- degenerate: more keys in one bin than the LDS list holds (thousands of equal scores).  Radix selection over what is left of the
+    //      49-bit value (score bits << 17 | 0x1ffff - cell): the low `shift` key bits and the cell, 11 + 11 + 11 + 4 bits from the top.
+    auto low_of = [&](unsigned kk, unsigned cell) -> unsigned long long {
+        return ((unsigned long long)((kk - kb.base) & ((1u << kb.shift) - 1u)) << 17) | (unsigned long long)(0x1ffffu - cell);
+    };
+    int need_r = need;
+    unsigned long long prefix = 0ull, pmask = 0ull;
+    const int shifts[4] = {26, 15, 4, 0}, bits[4] = {11, 11, 11, 4};
+    for (int pass = 0; pass < 4; ++pass) {
+        const int nb = 1 << bits[pass];
+        __syncthreads();
+        for (int i = tid; i < nb; i += kSelThreads) s_hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < HWp; i += kSelThreads) {  // (whole waves run every round: hist_add uses ballots)
+            const unsigned k = s_keys[i];
+            const bool cand = k != 0u && key_bin(kb, k) == bsel;
+            const unsigned long long v = cand ? low_of(k, (unsigned)i) : 0ull;
+            hist_add(s_hist, (int)((v >> shifts[pass]) & (unsigned long long)(nb - 1)), cand && (v & pmask) == prefix);
+        }
+        find_bin<2>(s_hist, nb, need_r, s_misc, s_misc + 20);
+        const unsigned long long b = (unsigned long long)s_misc[20];
+        need_r -= s_misc[21];
+        prefix |= b << shifts[pass];
+        pmask |= (unsigned long long)(nb - 1) << shifts[pass];
+    }
+    __syncthreads();
+    // prefix = the smallest selected value (the values are unique): take every key of the bin >= it
+    int n_take = 0;
+    for (int i = tid; i < HWp; i += kSelThreads) {
+        const unsigned k = s_keys[i];
+        n_take += (k != 0u && key_bin(kb, k) == bsel && low_of(k, (unsigned)i) >= prefix);
+    }
+    int tpos = block_sum_1024(n_take, s_misc);
+    __syncthreads();
+    for (int i = tid; i < HWp; i += kSelThreads) {
+        const unsigned k = s_keys[i];
+        if (k != 0u && key_bin(kb, k) == bsel && low_of(k, (unsigned)i) >= prefix) out[above + tpos++] = ((unsigned long long)k << 32) | (unsigned)(0xffffffffu - (unsigned)i);
+    }
+}
+
+constexpr int kRankElems = 64;  // elements per workgroup of dec_rank_decode (four threads each): 16 workgroups for pre_max 1000
+__global__ void __launch_bounds__(256) dec_rank_decode(const unsigned long long *__restrict__ sel_words, const int *__restrict__ sel_count, MapView reg,
+                                                        MapView height, MapView dim, MapView rot, DecCfg c, int G, float *__restrict__ sel_boxes,
+                                                        float4 *__restrict__ planes, float *__restrict__ sel_scores, int *__restrict__ sel_cell) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *s_w = reinterpret_cast<unsigned long long *>(smem);  // [S]
+    const int g = blockIdx.y, tid = threadIdx.x;
+    const int S = sel_count[g];
+    if ((int)blockIdx.x * kRankElems >= S) return;  // (uniform)
+    const unsigned long long *words = sel_words + (int64_t)g * c.pre_max;
+    const int S_pad = (S + 31) & ~31;  // (the LDS request is for pre_max rounded up to 32 words; zero words are greater than nothing)
+    for (int i = tid; i < S_pad; i += 4 * kRankElems) s_w[i] = i < S ? words[i] : 0ull;
+    __syncthreads();
+    const int e = blockIdx.x * kRankElems + (tid >> 2), q = tid & 3;
+    const bool live = e < S;
+    const unsigned long long w = live ? s_w[e] : ~0ull;
+    int rank = 0;
+    for (int j0 = 0; j0 < S_pad; j0 += 32) {  // thread q of an element takes words q, q + 4, ...: eight independent LDS reads per round
+        unsigned long long o[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o[u] = s_w[j0 + q + 4 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += o[u] > w;
+    }
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    if (!live || q != 0) return;
+    const int cell = (int)(0xffffffffu - (unsigned)(w & 0xffffffffull));
+    const float score = __uint_as_float((unsigned)(w >> 32));
+    float x, y;
+    cell_center(c, reg, g, cell, x, y);
+    const float z = ld(height, g, 0, cell);
+    const float d0 = expf(ld(dim, g, 0, cell)), d1 = expf(ld(dim, g, 1, cell)), d2 = expf(ld(dim, g, 2, cell));
+    const float yaw = atan2f(ld(rot, g, 0, cell), ld(rot, g, 1, cell));
+    const int64_t o = (int64_t)g * c.pre_max + rank;
+    float *sb = sel_boxes + o * 7;
+    sb[0] = x; sb[1] = y; sb[2] = z; sb[3] = d0; sb[4] = d1; sb[5] = d2; sb[6] = yaw;
+    const float nb[7] = {x, y, z, d1, d0, d2, __fsub_rn(-yaw, 1.5707963267948966f)};  // box_torch_ops.py:256-257: [x,y,z,dim1,dim0,dim2,-yaw-pi/2]
+    store_footprint(planes, (int64_t)G * c.pre_max, o, make_footprint(nb));
+    sel_scores[o] = score;
+    sel_cell[o] = cell;
 }
 
 // ---------------------------------------------------------------- stage 3: IoU mask words (upper triangle)
@@ -595,9 +785,151 @@ __global__ void __launch_bounds__(256) iou_pairs(const float *__restrict__ a, in
     out[t] = footprint_iou(make_footprint(ba), make_footprint(bb));
 }
 
+// Final assembly of predict's output (center_head.py:559-570,606-607,672-697): output step s takes the boxes of group
+// step_group[s], its two velocity channels vel_channel[s], vel_channel[s] + 1 of that group's velocity map at the kept cells, and the
+// label offset label_of[s].  One packed row per kept box: x y z w l h vx vy yaw score label; rows k >= count are zero.
+struct AsmSteps {
+    int S;
+    int group[kMaxSteps], vel_channel[kMaxSteps], label[kMaxSteps];
+};
+
+// ---------------------------------------------------------------- stages 4-6, round 5: sweep from LDS + gather + assembly in one launch
+// The round-4 sweep (one wave, mask words from global memory: a dependent L2 round trip per diagonal block and per kept row, 21 us),
+// dec_gather and assemble_kernel are one kernel now: the workgroup first stages the upper triangle of the group's mask words in LDS
+// (128 KB for pre_max 1000), one wave then runs the greedy sweep -- not over all rows but from kept row to kept row: the next row to
+// keep is the lowest clear bit of the diagonal word, at most post_max iterations of ~150 cycles -- and all threads write the outputs:
+// the kept boxes / scores / cells of the group and, when asked for, the packed rows of every output step that reads this group
+// (x y z w l h vx vy yaw score label, the velocity gathered from the map view at the kept cell).
+__global__ void __launch_bounds__(1024) nms_sweep_tail(const unsigned long long *__restrict__ mask_all, const int *__restrict__ counts, int n_max, int col_blocks,
+                                                       int post_max, const float *__restrict__ sel_boxes, const float *__restrict__ sel_scores,
+                                                       const int *__restrict__ sel_cell, float *__restrict__ out_boxes, float *__restrict__ out_scores,
+                                                       int *__restrict__ out_cell, int *__restrict__ out_count, MapView vel, AsmSteps st, int B,
+                                                       float *__restrict__ packed, int *__restrict__ counts_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(smem);              // [n_max][col_blocks]
+    int *s_keep = reinterpret_cast<int *>(s_mask + (size_t)n_max * col_blocks);             // [128] kept rows, [128] = their number
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = counts ? counts[g] : n_max;
+    const unsigned long long *mask = mask_all + (int64_t)g * n_max * col_blocks;
+    FD_DT(11);
+    {
+        // (words left of the diagonal are never read and nms_mask does not write them: whatever is there is copied along, harmlessly;
+        //  batches of eight 16-byte loads in flight per thread -- a load-wait-store loop over 128 KB was most of this kernel's 26 us)
+        const int n2 = (n * col_blocks + 1) / 2;  // 16-byte pieces (the group's slice starts 16-byte aligned: n_max * col_blocks * 8 bytes, col_blocks even or the tail is one word)
+        const bool wide = ((n_max * col_blocks) & 1) == 0;
+        if (wide) {
+            const ulonglong2 *m2 = reinterpret_cast<const ulonglong2 *>(mask);
+            ulonglong2 *s2 = reinterpret_cast<ulonglong2 *>(s_mask);
+            for (int i0 = tid; i0 < n2; i0 += 8 * 1024) {
+                ulonglong2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {  // unconditional loads at a clamped index: the eight are in flight together (predicated loads
+                    const int idx = i0 + u * 1024 < n2 ? i0 + u * 1024 : n2 - 1;  // made hipcc wait for each and park it in scratch memory)
+                    v[u] = m2[idx];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u * 1024 < n2) s2[i0 + u * 1024] = v[u];
+            }
+        } else {
+            for (int i = tid; i < n * col_blocks; i += 1024) s_mask[i] = mask[i];
+        }
+    }
+    __syncthreads();
+    FD_DT(12);
+    if (tid < 64) {
+        unsigned long long remv = 0ull;  // lane j: removed-bits word of column block j
+        int kept = 0;
+        const int nblk = (n + 63) / 64;
+        for (int blk = 0; blk < nblk && kept < post_max; ++blk) {
+            const int rows_here = min(64, n - blk * 64);
+            const unsigned long long rowmask = rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull);
+            // lane t: the diagonal word of row blk * 64 + t (one LDS read per block); the inner loop then runs on v_readlane alone, and the
+            // kept rows' other words are OR-ed into remv by LDS reads nobody waits for before the next block (a read + shuffle per kept
+            // row, as first written, cost 280 cycles each)
+            const unsigned long long diag = lane < rows_here ? s_mask[(size_t)(blk * 64 + lane) * col_blocks + blk] : 0ull;
+            auto lane_word = [&](unsigned long long v, int j) -> unsigned long long {  // v of lane j (j uniform): two v_readlane
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), j);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), j);
+                return ((unsigned long long)hi << 32) | lo;
+            };
+            // scalar work only, as little of it as possible (a lone wave issues an instruction every ~5 cycles: the first version of this loop
+            // had 32 of them and an LDS store per kept row, 280 cycles): lowest clear bit, that row's diagonal word, clear + mask.
+            // A row's diagonal word only has bits ABOVE the row, and everything below t is decided: no 'rows after t' mask is needed.
+            unsigned long long avail = ~lane_word(remv, blk) & rowmask, keep_bits = 0ull;
+            int room = post_max - kept;
+            while (avail && room > 0) {
+                const int t = __builtin_ctzll(avail);
+                keep_bits |= 1ull << t;
+                avail &= avail - 1ull;
+                avail &= ~lane_word(diag, t);
+                --room;
+            }
+            // the kept rows of this block, in order, to the keep list: lane t holds bit t
+            if ((keep_bits >> lane) & 1ull) s_keep[kept + (int)__builtin_popcountll(keep_bits & ((1ull << lane) - 1ull))] = blk * 64 + lane;
+            kept += (int)__builtin_popcountll(keep_bits);
+            // fold the kept rows' words into the later column blocks: four independent LDS reads per round
+            while (keep_bits) {
+                unsigned long long w4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    w4[u] = 0ull;
+                    if (keep_bits) {
+                        const int t = __builtin_ctzll(keep_bits);
+                        keep_bits &= keep_bits - 1ull;
+                        if (lane < col_blocks && lane > blk && lane * 64 < n) w4[u] = s_mask[(size_t)(blk * 64 + t) * col_blocks + lane];
+                    }
+                }
+                remv |= (w4[0] | w4[1]) | (w4[2] | w4[3]);
+            }
+        }
+        if (lane == 0) s_keep[128] = kept;
+    }
+    __syncthreads();
+    FD_DT(13);
+    const int kept = s_keep[128];
+    if (tid == 0) out_count[g] = kept;
+    for (int k = tid; k < post_max; k += 1024) {
+        const int64_t o = (int64_t)g * post_max + k;
+        if (k < kept) {
+            const int64_t sidx = (int64_t)g * n_max + s_keep[k];
+            for (int d = 0; d < 7; ++d) out_boxes[o * 7 + d] = sel_boxes[sidx * 7 + d];
+            out_scores[o] = sel_scores[sidx];
+            out_cell[o] = sel_cell[sidx];
+        } else {
+            for (int d = 0; d < 7; ++d) out_boxes[o * 7 + d] = 0.0f;
+            out_scores[o] = 0.0f;
+            out_cell[o] = -1;
+        }
+    }
+    if (!packed) return;
+    const int grp = g / B, b = g - grp * B;  // decode groups are group-major: [G][B]
+    for (int s_i = 0; s_i < st.S; ++s_i) {
+        if (st.group[s_i] != grp) continue;
+        if (tid == 0) counts_out[b * st.S + s_i] = kept;
+        for (int k = tid; k < post_max; k += 1024) {
+            float *o = packed + (((int64_t)b * st.S + s_i) * post_max + k) * 11;
+            if (k < kept) {
+                const int64_t sidx = (int64_t)g * n_max + s_keep[k];
+                const float *bx = sel_boxes + sidx * 7;
+                const int cc = sel_cell[sidx];
+                o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2]; o[3] = bx[3]; o[4] = bx[4]; o[5] = bx[5];
+                o[6] = ld(vel, g, st.vel_channel[s_i], cc);
+                o[7] = ld(vel, g, st.vel_channel[s_i] + 1, cc);
+                o[8] = bx[6];
+                o[9] = sel_scores[sidx];
+                o[10] = (float)st.label[s_i];
+            } else {
+#pragma unroll
+                for (int d = 0; d < 11; ++d) o[d] = 0.0f;
+            }
+        }
+    }
+}
+
 struct DecWs {
-    size_t keys, sel_boxes, nms_boxes, sel_scores, sel_cell, sel_count, mask, keep, foot, total;
-    int col_blocks, npad;
+    size_t keys, sel_boxes, nms_boxes, sel_scores, sel_cell, sel_count, mask, keep, foot, hist, words, total;
+    int col_blocks, npad, key_blocks;
 };
 DecWs dec_layout(int G, int HW, int pre_max, int post_max) {
     DecWs w;
@@ -615,19 +947,15 @@ DecWs dec_layout(int G, int HW, int pre_max, int post_max) {
     w.mask = take(sizeof(unsigned long long) * (size_t)G * pre_max * w.col_blocks);
     w.keep = take(sizeof(int) * (size_t)G * post_max);
     w.foot = take(sizeof(Footprint) * (size_t)G * pre_max);
+    w.key_blocks = (HW + kKeyBlock - 1) / kKeyBlock;
+    w.hist = take(sizeof(int) * 1024 * (size_t)G * w.key_blocks);
+    w.words = take(sizeof(unsigned long long) * (size_t)G * pre_max);
     w.total = off;
     return w;
 }
 
 }  // namespace
 
-// Final assembly of predict's output (center_head.py:559-570,606-607,672-697): output step s takes the boxes of group
-// step_group[s], its two velocity channels vel_channel[s], vel_channel[s] + 1 of that group's velocity map at the kept cells, and the
-// label offset label_of[s].  One packed row per kept box: x y z w l h vx vy yaw score label; rows k >= count are zero.
-struct AsmSteps {
-    int S;
-    int group[kMaxSteps], vel_channel[kMaxSteps], label[kMaxSteps];
-};
 __global__ void __launch_bounds__(128) assemble_kernel(const float *__restrict__ boxes7, const float *__restrict__ scores, const int *__restrict__ cell,
                                                        const int *__restrict__ count, MapView vel, AsmSteps st, int B, int post,
                                                        float *__restrict__ packed, int *__restrict__ counts_out) {
@@ -658,9 +986,15 @@ extern "C" size_t fd_decode_workspace_bytes(int G, const fd_decode_cfg *cfg) {
     return dec_layout(G, cfg->H * cfg->W, cfg->nms_pre_max, cfg->nms_post_max).total;
 }
 
-extern "C" int fd_centerpoint_decode_maps(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view *height, const fd_map_view *dim,
-                                          const fd_map_view *rot, int G, const fd_decode_cfg *cfg, float *out_boxes7, float *out_scores, int32_t *out_cell,
-                                          int32_t *out_count, void *workspace, size_t workspace_bytes, fd_stream_t stream_) {
+#ifdef FD_DEC_TRACE
+extern "C" int fd_debug_set_dectrace(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_dectrace), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#endif
+
+namespace {
+// shared body of fd_centerpoint_decode_maps / fd_centerpoint_decode_packed (vel == nullptr: no packed assembly)
+int decode_impl(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view *height, const fd_map_view *dim, const fd_map_view *rot, int G,
+                const fd_decode_cfg *cfg, float *out_boxes7, float *out_scores, int32_t *out_cell, int32_t *out_count, void *workspace,
+                size_t workspace_bytes, const fd_map_view *vel, int B, const AsmSteps *steps, float *packed, int32_t *counts_out, hipStream_t stream) {
     FD_REQUIRE(hm && reg && height && dim && rot && cfg && out_boxes7 && out_scores && out_cell && out_count, "fd_centerpoint_decode: null argument");
     FD_REQUIRE(hm->data && reg->data && height->data && dim->data && rot->data, "fd_centerpoint_decode: null map");
     for (const fd_map_view *v : {hm, reg, height, dim, rot}) FD_REQUIRE(v->dtype == 0 || v->dtype == 1, "fd_centerpoint_decode: map dtype must be 0 (f32) or 1 (bf16)");
@@ -681,36 +1015,93 @@ extern "C" int fd_centerpoint_decode_maps(const fd_map_view *hm, const fd_map_vi
         fd::set_error("fd_centerpoint_decode: workspace %zu < required %zu", workspace_bytes, w.total);
         return FD_EWORKSPACE;
     }
-    hipStream_t stream = fd::as_stream(stream_);
     char *ws = (char *)workspace;
     unsigned *keys = (unsigned *)(ws + w.keys);
     float *sel_boxes = (float *)(ws + w.sel_boxes), *nms_boxes = (float *)(ws + w.nms_boxes), *sel_scores = (float *)(ws + w.sel_scores);
     int *sel_cell = (int *)(ws + w.sel_cell), *sel_count = (int *)(ws + w.sel_count), *keep = (int *)(ws + w.keep);
     unsigned long long *mask = (unsigned long long *)(ws + w.mask);
+    float4 *foot = (float4 *)(ws + w.foot);
+    const int64_t n_total = (int64_t)G * c.pre_max;
     const MapView vh = as_view(*hm), vr = as_view(*reg), vz = as_view(*height), vd = as_view(*dim), vt = as_view(*rot);
-    hipLaunchKernelGGL(dec_keys, dim3((c.HW + 255) / 256, G), dim3(256), 0, stream, vh, vr, vz, c, keys);
-    if (c.HW <= 32 * kSelThreads) {  // a group's keys fit the registers of one workgroup (72 keys per thread, the 270 x 270 map, spill)
-        const size_t lds = (size_t)w.npad * 8 + 8192 * 4 + 32 * 4;
-#define FD_SEL(PER)                                                                                                                              \
-    hipLaunchKernelGGL(dec_select_reg<PER>, dim3(G), dim3(kSelThreads), lds, stream, keys, vr, vz, vd, vt, c, w.npad, sel_boxes, nms_boxes, sel_scores, \
-                       sel_cell, sel_count)
-        if (c.HW <= 8 * kSelThreads) FD_SEL(8);
-        else FD_SEL(32);
-#undef FD_SEL
-    } else {
+    if (c.HW <= 32 * kSelThreads) {
+        // a group's keys fit the registers of one workgroup: histogram with the keys, selection from the histogram, order by ranking
+        int *hist = (int *)(ws + w.hist);
+        unsigned long long *words = (unsigned long long *)(ws + w.words);
+        const KeyBins kb = make_key_bins(c.thr);
+        hipLaunchKernelGGL(dec_keys_hist, dim3(w.key_blocks, G), dim3(256), 0, stream, vh, vr, vz, c, kb, keys, hist);
+        const size_t sel_lds = 2048 * 4 + (size_t)kMaxCand * 8 + 32 * 4 + (size_t)((c.HW + 4095) & ~4095) * 4;
+        static std::atomic<uint64_t> sel_lds_set{0};
+        if (sel_lds > 65536 && !fd::ensure_dynamic_lds(reinterpret_cast<const void *>(dec_select_hist), 156 * 1024, sel_lds_set)) {
+            fd::set_error("fd_centerpoint_decode: the runtime refused %zu bytes of LDS for the selection", sel_lds);
+            return FD_ELAUNCH;
+        }
+        hipLaunchKernelGGL(dec_select_hist, dim3(G), dim3(kSelThreads), sel_lds, stream, keys, hist, w.key_blocks, c, kb, words, sel_count);
+        hipLaunchKernelGGL(dec_rank_decode, dim3((c.pre_max + kRankElems - 1) / kRankElems, G), dim3(4 * kRankElems), (size_t)((c.pre_max + 31) & ~31) * 8, stream, words, sel_count, vr, vz,
+                           vd, vt, c, G, sel_boxes, foot, sel_scores, sel_cell);
+    } else {  // larger maps (the 270 x 270 map of the 0.05-m grid has 72 keys per thread: spill): keys streamed from memory, LDS bitonic sort
+        hipLaunchKernelGGL(dec_keys, dim3((c.HW + 255) / 256, G), dim3(256), 0, stream, vh, vr, vz, c, keys);
         const size_t lds = (size_t)w.npad * 8 + 4096 * 4 + 32 * 4;
         hipLaunchKernelGGL(dec_select, dim3(G), dim3(kSelThreads), lds, stream, keys, vr, vz, vd, vt, c, w.npad, sel_boxes, nms_boxes, sel_scores, sel_cell,
                            sel_count);
+        hipLaunchKernelGGL(footprint_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, stream, nms_boxes, sel_count, c.pre_max, G, foot);
     }
-    float4 *foot = (float4 *)(ws + w.foot);
-    const int64_t n_total = (int64_t)G * c.pre_max;
-    hipLaunchKernelGGL(footprint_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, stream, nms_boxes, sel_count, c.pre_max, G, foot);
     hipLaunchKernelGGL(nms_mask, dim3((c.pre_max + 3) / 4, w.col_blocks, G), dim3(256), 0, stream, foot, n_total, sel_count, c.pre_max, w.col_blocks,
                        c.iou_thr, mask);
-    hipLaunchKernelGGL(nms_sweep, dim3(G), dim3(64), 0, stream, mask, sel_count, c.pre_max, w.col_blocks, c.post_max, keep, c.post_max, out_count);
-    hipLaunchKernelGGL(dec_gather, dim3(G), dim3(128), 0, stream, keep, out_count, c.post_max, c.pre_max, sel_boxes, sel_scores, sel_cell,
-                       out_boxes7, out_scores, out_cell);
+    // sweep + gather (+ packed assembly) in one launch when the group's mask words fit the LDS; else the round-4 kernels
+    const size_t sweep_lds = (size_t)c.pre_max * w.col_blocks * 8 + 129 * 4 + 12;
+    static std::atomic<uint64_t> lds_set{0};
+    AsmSteps none;
+    none.S = 0;
+    const bool fused = sweep_lds <= 152 * 1024 && (sweep_lds <= 65536 || fd::ensure_dynamic_lds(reinterpret_cast<const void *>(nms_sweep_tail), 152 * 1024, lds_set));
+    if (fused) {
+        hipLaunchKernelGGL(nms_sweep_tail, dim3(G), dim3(1024), sweep_lds, stream, mask, sel_count, c.pre_max, w.col_blocks, c.post_max, sel_boxes, sel_scores,
+                           sel_cell, out_boxes7, out_scores, out_cell, out_count, vel ? as_view(*vel) : MapView{nullptr, 0, 0, 0, 0}, steps ? *steps : none,
+                           B > 0 ? B : 1, vel ? packed : nullptr, counts_out);
+    } else {
+        hipLaunchKernelGGL(nms_sweep, dim3(G), dim3(64), 0, stream, mask, sel_count, c.pre_max, w.col_blocks, c.post_max, keep, c.post_max, out_count);
+        hipLaunchKernelGGL(dec_gather, dim3(G), dim3(128), 0, stream, keep, out_count, c.post_max, c.pre_max, sel_boxes, sel_scores, sel_cell, out_boxes7,
+                           out_scores, out_cell);
+        if (vel)
+            hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(B * steps->S)), dim3(128), 0, stream, out_boxes7, out_scores, out_cell, out_count, as_view(*vel),
+                               *steps, B, c.post_max, packed, counts_out);
+    }
     return fd::check_launch("fd_centerpoint_decode");
+}
+
+int fill_steps(AsmSteps &st, int S, const int32_t *step_group, const int32_t *step_vel_channel, const int32_t *step_label, const char *who) {
+    FD_REQUIRE(step_group && step_vel_channel && step_label, "%s: null step table", who);
+    FD_REQUIRE(S >= 1 && S <= kMaxSteps, "%s: need 1 <= S <= %d", who, kMaxSteps);
+    st.S = S;
+    for (int s = 0; s < S; ++s) {
+        FD_REQUIRE(step_group[s] >= 0 && step_vel_channel[s] >= 0, "%s: negative step entry", who);
+        st.group[s] = step_group[s]; st.vel_channel[s] = step_vel_channel[s]; st.label[s] = step_label[s];
+    }
+    return FD_OK;
+}
+}  // namespace
+
+extern "C" int fd_centerpoint_decode_maps(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view *height, const fd_map_view *dim,
+                                          const fd_map_view *rot, int G, const fd_decode_cfg *cfg, float *out_boxes7, float *out_scores, int32_t *out_cell,
+                                          int32_t *out_count, void *workspace, size_t workspace_bytes, fd_stream_t stream_) {
+    return decode_impl(hm, reg, height, dim, rot, G, cfg, out_boxes7, out_scores, out_cell, out_count, workspace, workspace_bytes, nullptr, 1, nullptr, nullptr,
+                       nullptr, fd::as_stream(stream_));
+}
+
+// fd_centerpoint_decode_maps + fd_assemble_detections in one call (the sweep kernel's tail writes the packed rows)
+extern "C" int fd_centerpoint_decode_packed(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view *height, const fd_map_view *dim,
+                                            const fd_map_view *rot, const fd_map_view *vel, int G, int B, const fd_decode_cfg *cfg, int S,
+                                            const int32_t *step_group, const int32_t *step_vel_channel, const int32_t *step_label, float *out_boxes7,
+                                            float *out_scores, int32_t *out_cell, int32_t *out_count, float *packed, int32_t *counts_out, void *workspace,
+                                            size_t workspace_bytes, fd_stream_t stream_) {
+    FD_REQUIRE(vel && vel->data && packed && counts_out, "fd_centerpoint_decode_packed: null argument");
+    FD_REQUIRE(vel->dtype == 0 || vel->dtype == 1, "fd_centerpoint_decode_packed: map dtype must be 0 (f32) or 1 (bf16)");
+    FD_REQUIRE(B >= 1 && G >= B && G % B == 0, "fd_centerpoint_decode_packed: G must be a multiple of B (decode groups are group-major: g = group * B + sample)");
+    AsmSteps st;
+    const int rc = fill_steps(st, S, step_group, step_vel_channel, step_label, "fd_centerpoint_decode_packed");
+    if (rc != FD_OK) return rc;
+    for (int s = 0; s < S; ++s) FD_REQUIRE(st.group[s] < G / B, "fd_centerpoint_decode_packed: step group out of range");
+    return decode_impl(hm, reg, height, dim, rot, G, cfg, out_boxes7, out_scores, out_cell, out_count, workspace, workspace_bytes, vel, B, &st, packed, counts_out,
+                       fd::as_stream(stream_));
 }
 
 // the round-1 signature: five [G, C, H, W] float32 tensors with their group strides (NCHW planes)
@@ -733,11 +1124,8 @@ extern "C" int fd_assemble_detections(const float *boxes7, const float *scores, 
     FD_REQUIRE(B >= 1 && S >= 1 && S <= kMaxSteps && post_max >= 1 && post_max <= 128, "fd_assemble_detections: need 1 <= S <= %d, 1 <= post_max <= 128", kMaxSteps);
     FD_REQUIRE(vel->dtype == 0 || vel->dtype == 1, "fd_assemble_detections: map dtype must be 0 (f32) or 1 (bf16)");
     AsmSteps st;
-    st.S = S;
-    for (int s = 0; s < S; ++s) {
-        FD_REQUIRE(step_group[s] >= 0 && step_vel_channel[s] >= 0, "fd_assemble_detections: negative step entry");
-        st.group[s] = step_group[s]; st.vel_channel[s] = step_vel_channel[s]; st.label[s] = step_label[s];
-    }
+    const int rc = fill_steps(st, S, step_group, step_vel_channel, step_label, "fd_assemble_detections");
+    if (rc != FD_OK) return rc;
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(B * S)), dim3(128), 0, fd::as_stream(stream), boxes7, scores, cell, count, as_view(*vel), st, B, post_max,
                        packed, counts_out);
     return fd::check_launch("fd_assemble_detections");

@@ -173,8 +173,8 @@ class CenterHead(nn.Module):
     @torch.no_grad()
     def predict_packed(self, preds_dicts, test_cfg):
         """Device-only decode straight from the convolution plan's NHWC output buffer: (packed [B,S,post,11] float32 rows
-        x y z w l h vx vy yaw score label, counts [B,S] int32) -- seven launches (keys, select, footprints, IoU mask, sweep, gather,
-        assembly), no torch kernel in between.  None when the maps did not come from the plan (torch path, bev_map head)."""
+        x y z w l h vx vy yaw score label, counts [B,S] int32) -- five launches (keys + histogram, selection, rank + box decode, IoU mask,
+        sweep + gather + assembly: fd_centerpoint_decode_packed), no torch kernel in between.  None when the maps did not come from the plan (torch path, bev_map head)."""
         raws = [getattr(pd, "raw", None) for pd in preds_dicts]
         if any(r is None for r in raws) or any(r[0] is not raws[0][0] or r[2] != raws[0][2] for r in raws):
             return None
@@ -210,9 +210,7 @@ class CenterHead(nn.Module):
         flat = zbuf[:G].reshape(G * B, H, W, C)
         cfg = hip_ops.make_decode_cfg(H, W, test_cfg, hm_channels=hm_channels)
         views = [hip_ops.nhwc_channel_view(flat, where[k][0]) for k in ("hm", "reg", "height", "dim", "rot")]
-        boxes7, scores, cell, count = hip_ops.centerpoint_decode_views(views, G * B, cfg, zbuf.device)
-        return hip_ops.assemble_detections(boxes7, scores, cell, count, hip_ops.nhwc_channel_view(flat, where["vel"][0]), B, cfg.nms_post_max,
-                                           step_group, step_vel, labels)
+        return hip_ops.centerpoint_decode_packed(views, hip_ops.nhwc_channel_view(flat, where["vel"][0]), G * B, B, cfg, zbuf.device, step_group, step_vel, labels)
 
     @torch.no_grad()
     def predict_padded(self, preds_dicts, test_cfg):

@@ -587,6 +587,26 @@ def centerpoint_decode_views(views, G, cfg, device):
     return boxes, scores, cell, count
 
 
+def centerpoint_decode_packed(views, vel_view, G, B, cfg, device, step_group, step_vel_channel, step_label):
+    """fd_centerpoint_decode_packed: decode + rotated NMS + assembly of the packed result in one call (five launches, the last one
+    sweeps, gathers and writes the packed rows).  views = (hm, reg, height, dim, rot) fd_map_view; decode groups are group-major
+    (g = group * B + sample).  -> (packed [B, S, post, 11] float32 rows x y z w l h vx vy yaw score label, counts [B, S] int32)"""
+    L = _lib.load()
+    post, S = cfg.nms_post_max, len(step_group)
+    boxes = torch.empty((G, post, 7), dtype=torch.float32, device=device)
+    scores = torch.empty((G, post), dtype=torch.float32, device=device)
+    cell = torch.empty((G, post), dtype=torch.int32, device=device)
+    count = torch.empty((G,), dtype=torch.int32, device=device)
+    packed = torch.empty((B, S, post, 11), dtype=torch.float32, device=device)
+    counts = torch.empty((B, S), dtype=torch.int32, device=device)
+    ws = workspace.get("decode", L.fd_decode_workspace_bytes(G, ctypes.byref(cfg)), device)
+    arr = lambda v: (ctypes.c_int32 * S)(*[int(x) for x in v])  # noqa: E731
+    check(L.fd_centerpoint_decode_packed(*[ctypes.byref(v) for v in views], ctypes.byref(vel_view), int(G), int(B), ctypes.byref(cfg), S, arr(step_group),
+                                         arr(step_vel_channel), arr(step_label), _p(boxes), _p(scores), _p(cell), _p(count), _p(packed), _p(counts), _p(ws),
+                                         ws.numel(), _stream()), "fd_centerpoint_decode_packed")
+    return packed, counts
+
+
 def assemble_detections(boxes7, scores, cell, count, vel_view, B, post, step_group, step_vel_channel, step_label):
     """fd_assemble_detections: -> (packed [B, S, post, 11] float32 rows x y z w l h vx vy yaw score label, counts [B, S] int32)"""
     L = _lib.load()

@@ -87,6 +87,8 @@ SIGNATURES = {
                                       c_size_t, c_void_p]),
     "fd_centerpoint_decode_maps": (c_int, [ctypes.POINTER(MapView)] * 5 + [c_int, ctypes.POINTER(DecodeCfg), c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_size_t, c_void_p]),
+    "fd_centerpoint_decode_packed": (c_int, [ctypes.POINTER(MapView)] * 6 + [c_int, c_int, ctypes.POINTER(DecodeCfg), c_int, c_void_p, c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fd_assemble_detections": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(MapView), c_int, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_nms_workspace_bytes": (c_size_t, [c_int]),

@@ -251,6 +251,15 @@ int fd_centerpoint_decode_maps(const fd_map_view *hm, const fd_map_view *reg, co
 int fd_assemble_detections(const float *boxes7, const float *scores, const int32_t *cell, const int32_t *count, const fd_map_view *vel,
                            int B, int post_max, int S, const int32_t *step_group, const int32_t *step_vel_channel,
                            const int32_t *step_label, float *packed, int32_t *counts_out, fd_stream_t stream);
+/* fd_centerpoint_decode_maps + fd_assemble_detections in ONE call: the last kernel of the decode (greedy sweep from LDS, gather of the kept
+ * boxes) also writes the packed rows of every output step (arguments as in the two calls above; G = groups * B, decode group
+ * g = group * B + sample; step_* are HOST arrays, S <= 16).  out_boxes7 / out_scores / out_cell / out_count receive what
+ * fd_centerpoint_decode_maps would write. */
+int fd_centerpoint_decode_packed(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view *height, const fd_map_view *dim,
+                                 const fd_map_view *rot, const fd_map_view *vel, int G, int B, const fd_decode_cfg *cfg_host, int S,
+                                 const int32_t *step_group, const int32_t *step_vel_channel, const int32_t *step_label, float *out_boxes7,
+                                 float *out_scores, int32_t *out_cell, int32_t *out_count, float *packed, int32_t *counts_out, void *workspace,
+                                 size_t workspace_bytes, fd_stream_t stream);
 int fd_centerpoint_decode(const float *hm, int64_t hm_gstride, const float *reg, int64_t reg_gstride,
                           const float *height, int64_t height_gstride, const float *dim, int64_t dim_gstride,
                           const float *rot, int64_t rot_gstride, int G, const fd_decode_cfg *cfg_host,

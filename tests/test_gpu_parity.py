@@ -517,6 +517,51 @@ def test_predict_matches_reference_golden(hip, golden, name, T, dense):
             assert_close("predict golden %s b%d rows in order" % (name, b), got, want, 1e-3)
 
 
+@pytest.mark.parametrize("case", ["ties_across_cut", "all_equal", "pre_max_4096", "tiny_map", "few_valid"])
+def test_decode_selection_edge_cases(hip, case):
+    """The pre-max selection of the decode (dec_keys_hist / dec_select_hist / dec_rank_decode, fd_decode.hip) against the definition --
+    the pre_max best cells by (score descending, cell ascending), box_torch_ops.py:259-261 with a stable order -- on maps built to hit
+    its branches: scores tied across the cut (the threshold bin holds the ties: ranked in LDS), ALL scores equal (32k candidates in one bin:
+    the radix passes), nms_pre_max_size 4096 (the round-4 kernel asked for more than 64 KB of LDS there), a map smaller than
+    one block, fewer valid cells than pre_max.  NMS is switched off by an IoU threshold above 1, post_max = 128: the first 128 selected
+    boxes come back in order and must be the 128 best cells."""
+    rng = np.random.default_rng(len(case))
+    H, W = (12, 20) if case == "tiny_map" else (180, 180)
+    pre = 4096 if case == "pre_max_4096" else 100  # (100 < post_max: every selected cell comes back, so the cut itself is checked)
+    logit = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    if case == "ties_across_cut":
+        logit = np.round(logit * 4) / 4  # ~40 distinct scores: hundreds of exact ties, the cut falls inside one of them
+    elif case == "all_equal":
+        logit[:] = 0.5
+    elif case == "few_valid":
+        logit -= 6.0
+        logit.reshape(-1)[rng.choice(H * W, 60, replace=False)] += 8.0
+    cfg_d = dict(TEST_CFG, score_threshold=0.1, nms=dict(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=pre, nms_post_max_size=128,
+                                                         nms_iou_threshold=1.5))
+    cfg = hip.make_decode_cfg(H, W, cfg_d)
+    reg = rng.uniform(0, 1, (1, 2, H, W)).astype(np.float32)
+    hei = rng.normal(-1, 0.5, (1, 1, H, W)).astype(np.float32)
+    dim = rng.normal(0.5, 0.1, (1, 3, H, W)).astype(np.float32)
+    rot = rng.standard_normal((1, 2, H, W)).astype(np.float32)
+    boxes, scores, cell, count = hip.centerpoint_decode(_dev(logit), _dev(reg), _dev(hei), _dev(dim), _dev(rot), cfg)
+    score = (1.0 / (1.0 + np.exp(-logit.astype(np.float32)))).astype(np.float32).reshape(-1)
+    ys, xs = np.divmod(np.arange(H * W), W)
+    cx = ((xs + reg[0, 0].reshape(-1)) * np.float32(8) * np.float32(0.075) + np.float32(-54)).astype(np.float32)
+    cy = ((ys + reg[0, 1].reshape(-1)) * np.float32(8) * np.float32(0.075) + np.float32(-54)).astype(np.float32)
+    z = hei.reshape(-1)
+    lim = cfg_d["post_center_limit_range"]
+    ok = (score > 0.1) & (cx >= lim[0]) & (cy >= lim[1]) & (z >= lim[2]) & (cx <= lim[3]) & (cy <= lim[4]) & (z <= lim[5])
+    # (equal logits give equal scores on either side, distinct logits differ by far more than an ulp of expf: the order is that of the logits)
+    order = np.lexsort((np.arange(H * W), -logit.reshape(-1).astype(np.float64)))  # score descending, cell ascending
+    order = order[ok[order]][:pre]
+    n = int(count.cpu()[0])
+    assert n == min(128, len(order)), (n, len(order))
+    got_cell, got_score = cell.cpu().numpy()[0, :n], scores.cpu().numpy()[0, :n]
+    assert np.allclose(got_score, score[order[:n]], rtol=0, atol=2e-7)
+    assert np.array_equal(got_cell, order[:n]), case
+    report("decode selection edge case %s: %d selected, first %d in the reference order" % (case, len(order), n), 0.0, 0.0)
+
+
 # ------------------------------------------------------------------------------------------------ end to end
 @pytest.mark.parametrize("variant", ["forecast_n0", "forecast_n3", "pedestrian_n3_fine", "forecast_n3dtfm"])
 def test_voxelnet_end_to_end_vs_oracle(hip, variant):
