@@ -44,8 +44,14 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# The CPU baseline runs two OpenMP runtimes on every logical CPU of the box (torch's and the oracle's libgomp).  With the default
+# active wait policy the idle pool spins on the cores the other one needs: 49.8 s per pass on 256 threads against 1.66 s on 64
+# (round 5, first run).  Passive waiting must be chosen before either runtime is loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

@@ -3,15 +3,19 @@
 // Reproduces the sequential semantics of the reference voxelizer
 // (det3d/ops/point_cloud/point_cloud_ops.py:7-55: first-come voxel ids, first max_voxels voxels, first
 // max_points points per voxel in input order, float32 floor((p-lo)/vs) with a true division) with a
-// deterministic parallel schedule:
-//   K1 hash   : point -> cell key -> open-addressing slot (atomicCAS), atomicMin(first point), atomicAdd(count)
-//   K2-K3 scan: voxel id = rank of the voxel's first point among all first points (exclusive scan over
-//               points); the same scan carries the per-voxel point counts -> CSR bucket offsets
-//   K4 fill   : point index -> its voxel's bucket (order inside a bucket is arbitrary)
-//   K5 emit   : one lane per voxel selects the max_points smallest point indices of its bucket with an
-//               unrolled insertion network, copies / sums the points in ascending order
-// Wave-level ballots/prefix counts keep the atomics to one per wave where possible (the compiler folds the
-// per-lane atomicAdd(…,1) on a uniform address; the hash itself is lane-divergent by nature).
+// deterministic parallel schedule.  Round 5 (the round-1 form moved 210 MB for a 6.3-MB cloud in six launches: three 4-byte tables hit
+// by three atomics per point, two passes over the points for the scan, a fill pass with a fourth atomic):
+//   vox_init   one 16-byte entry per hash slot {key, aux, (first point << 32 | point count)}: the whole record of a voxel in ONE line;
+//              the scan's tile status words
+//   vox_hash   point -> cell key -> slot (atomicCAS on the key), then ONE 64-bit CAS that lowers the first point and raises the count;
+//              the count before the raise is the point's arrival rank in its voxel (kept: it replaces the fill pass's atomic)
+//   vox_scan   single pass with decoupled look-back over the points: voxel id = rank of the voxel's first point among all first
+//              points, bucket offset = running sum of the counts of the voxels with more than one point; per kept voxel its key,
+//              first point, count and offset go to dense arrays (the emit pass never touches the hash table)
+//   vox_place  point -> bucket[offset of its voxel + its arrival rank]: no atomics; skipped outright (device-side flag) when every
+//              voxel holds one point
+//   vox_emit   one lane per voxel: a single-point voxel IS its first point; otherwise the max_points smallest point indices of the
+//              bucket by an unrolled insertion network, summed in ascending order; rows leave through LDS as 16-byte row-contiguous stores
 #include "fd_common.h"
 
 namespace {
@@ -30,11 +34,27 @@ struct VoxParams {
     unsigned mask;  // hash table size - 1
 };
 
+struct __attribute__((aligned(16))) VoxEntry {
+    int key;                  // cell key, -1 = free
+    int aux;                  // after vox_scan: bucket offset of a kept voxel with more than one point, else -1
+    unsigned long long fc;    // first point << 32 | points
+};
+constexpr unsigned long long kFcInit = 0x7fffffffull << 32;
+
 __device__ inline unsigned hash_key(int key) { return (unsigned)key * 2654435761u; }
 
+__global__ void __launch_bounds__(256) vox_init(VoxEntry *__restrict__ table, unsigned n_slots, unsigned long long *__restrict__ status, int n_status) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_slots) {
+        uint4 v;
+        v.x = 0xffffffffu; v.y = 0u; v.z = 0u; v.w = 0x7fffffffu;  // key -1, aux 0, fc = kFcInit (little endian: low word = count)
+        reinterpret_cast<uint4 *>(table)[i] = v;
+    }
+    if (i < (unsigned)n_status) status[i] = 0ull;
+}
+
 __global__ void __launch_bounds__(256) vox_hash(const float *__restrict__ pts, int n, const int *__restrict__ n_dev, VoxParams p,
-                                                int *__restrict__ keys, int *__restrict__ first,
-                                                int *__restrict__ cnt, int *__restrict__ pslot) {
+                                                VoxEntry *__restrict__ table, int *__restrict__ pslot, int *__restrict__ prank) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     n = fd::device_count(n, n_dev);
     if (i >= n) return;
@@ -52,220 +72,271 @@ __global__ void __launch_bounds__(256) vox_hash(const float *__restrict__ pts, i
         pslot[i] = -1;
         return;
     }
-    int key = (c[2] * p.grid[1] + c[1]) * p.grid[0] + c[0];  // (z,y,x) row-major
+    const int key = (c[2] * p.grid[1] + c[1]) * p.grid[0] + c[0];  // (z,y,x) row-major
     unsigned slot = (hash_key(key) >> 7) & p.mask;
+    bool fresh;
     while (true) {
-        int prev = atomicCAS(&keys[slot], -1, key);
-        if (prev == -1 || prev == key) break;
+        const int prev = atomicCAS(&table[slot].key, -1, key);
+        fresh = prev == -1;
+        if (fresh || prev == key) break;
         slot = (slot + 1) & p.mask;
     }
-    atomicMin(&first[slot], i);
-    atomicAdd(&cnt[slot], 1);
+    // (first, count) in one word: a slot this thread has just claimed still holds the initial value (unless a later point of the voxel
+    // got in between: the CAS then returns what is there and the loop retries)
+    unsigned long long *fc = &table[slot].fc;
+    unsigned long long cur = fresh ? kFcInit : __hip_atomic_load(fc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+        const unsigned first = (unsigned)(cur >> 32);
+        const unsigned long long nw = ((unsigned long long)(first < (unsigned)i ? first : (unsigned)i) << 32) | (unsigned)((unsigned)cur + 1u);
+        const unsigned long long prev = atomicCAS(fc, cur, nw);
+        if (prev == cur) break;
+        cur = prev;
+    }
     pslot[i] = (int)slot;
+    prank[i] = (int)(unsigned)cur;  // points of this voxel that arrived before this one
 }
 
-// block-wide exclusive scan of two ints per thread (kScanThreads threads)
-__device__ inline void block_scan2(int &a, int &b, int &ta, int &tb, int *sm /*[2*4+2]*/) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int ia = a, ib = b;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int ua = __shfl_up(ia, off), ub = __shfl_up(ib, off);
-        if (lane >= off) { ia += ua; ib += ub; }
-    }
-    if (lane == 63) { sm[wave] = ia; sm[4 + wave] = ib; }
-    __syncthreads();
-    int wa = 0, wb = 0, sa = 0, sb = 0;
-#pragma unroll
-    for (int w = 0; w < kScanThreads / 64; ++w) {
-        if (w < wave) { wa += sm[w]; wb += sm[4 + w]; }
-        sa += sm[w]; sb += sm[4 + w];
-    }
-    __syncthreads();
-    a = wa + ia - a;  // exclusive
-    b = wb + ib - b;
-    ta = sa; tb = sb;
-}
+// ---- single-pass scan over the points (decoupled look-back).  Item of point i: (1, count of its voxel if > 1 else 0) when i is the first
+//      point of its voxel, else (0, 0).  A tile = 1024 points; status word of a tile = flag << 62 | voxels << 32 | bucket words, written and
+//      read as ONE 8-byte agent-scope access (the value carries its own tag: no fence needed).
+constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagPre = 2ull << 62, kFlagMask = 3ull << 62;
 
-// block-wide sums of two ints per thread, returned to every thread
-__device__ inline void block_sum2(int &a, int &b, int *sm /*[8]*/) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ inline void wave_sum2(int &a, int &b) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         a += __shfl_xor(a, off);
         b += __shfl_xor(b, off);
     }
-    if (lane == 0) { sm[wave] = a; sm[4 + wave] = b; }
-    __syncthreads();
-    a = 0; b = 0;
-#pragma unroll
-    for (int w = 0; w < kScanThreads / 64; ++w) { a += sm[w]; b += sm[4 + w]; }
-    __syncthreads();
 }
 
-__device__ inline void load_flags(const int *pslot, const int *first, const int *cnt, int i, int n, int &f, int &c) {
-    f = 0; c = 0;
-    if (i < n) {
-        int s = pslot[i];
-        if (s >= 0 && first[s] == i) { f = 1; c = cnt[s]; }
-    }
-}
-
-__global__ void __launch_bounds__(kScanThreads) vox_scan1(const int *__restrict__ pslot, const int *__restrict__ first,
-                                                          const int *__restrict__ cnt, int n, const int *__restrict__ n_dev,
-                                                          int *__restrict__ bsum) {
-    __shared__ int sm[10];
+__global__ void __launch_bounds__(kScanThreads) vox_scan(const int *__restrict__ pslot, VoxEntry *__restrict__ table, int n, const int *__restrict__ n_dev,
+                                                         int max_voxels, unsigned long long *__restrict__ status /*[tiles + 1]: [tiles] = tile counter*/,
+                                                         int n_tiles, int *__restrict__ vkey, int *__restrict__ vfirst, int *__restrict__ vcnt,
+                                                         int *__restrict__ voff, int *__restrict__ num_voxels, int *__restrict__ need_place) {
+    __shared__ int sm[2 * (kScanThreads / 64) + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     n = fd::device_count(n, n_dev);
-    int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    if (tid == 0) sm[8] = (int)atomicAdd(reinterpret_cast<unsigned long long *>(status + n_tiles), 1ull);  // tiles are numbered in arrival order
+    __syncthreads();
+    const int tile = sm[8];
+    const int base = tile * kScanTile + tid * kScanItems;
+    int ff[kScanItems], cc[kScanItems], kk[kScanItems], ss[kScanItems];
     int f = 0, c = 0;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
-        int ff, cc;
-        load_flags(pslot, first, cnt, base + k, n, ff, cc);
-        f += ff; c += cc;
+        ff[k] = 0; cc[k] = 0; kk[k] = 0; ss[k] = -1;
+        const int i = base + k;
+        if (i < n) {
+            const int s = pslot[i];
+            if (s >= 0) {
+                const uint4 e = *reinterpret_cast<const uint4 *>(table + s);  // key, aux, count, first
+                if ((int)e.w == i) {
+                    ff[k] = 1; cc[k] = (int)e.z; kk[k] = (int)e.x; ss[k] = s;
+                }
+            }
+        }
+        f += ff[k];
+        c += cc[k] > 1 ? cc[k] : 0;
     }
-    int tf, tc;
-    block_scan2(f, c, tf, tc, sm);
-    if (threadIdx.x == 0) { bsum[2 * blockIdx.x] = tf; bsum[2 * blockIdx.x + 1] = tc; }
-}
-
-// (no second pass over the block sums: a block of the third pass sums the totals of the blocks before it itself -- a few hundred
-// values -- which costs less than the launch it replaces)
-__global__ void __launch_bounds__(kScanThreads) vox_scan3(const int *__restrict__ pslot, const int *__restrict__ first,
-                                                          const int *__restrict__ cnt, int n, const int *__restrict__ n_dev,
-                                                          const int *__restrict__ bsum, int max_voxels, int *__restrict__ vid,
-                                                          int *__restrict__ boff, int *__restrict__ vslot, int *__restrict__ num_voxels) {
-    __shared__ int sm[10];
-    n = fd::device_count(n, n_dev);
-    int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    int ff[kScanItems], cc[kScanItems];
-    int f = 0, c = 0;
+    // exclusive scan inside the tile
+    int iff = f, icc = c;
 #pragma unroll
-    for (int k = 0; k < kScanItems; ++k) {
-        load_flags(pslot, first, cnt, base + k, n, ff[k], cc[k]);
-        f += ff[k]; c += cc[k];
+    for (int off = 1; off < 64; off <<= 1) {
+        const int uf = __shfl_up(iff, off), uc = __shfl_up(icc, off);
+        if (lane >= off) { iff += uf; icc += uc; }
     }
-    int tf, tc;
-    block_scan2(f, c, tf, tc, sm);
-    int pf = 0, pc = 0;  // totals of the blocks in front of this one
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += kScanThreads) { pf += bsum[2 * j]; pc += bsum[2 * j + 1]; }
-    block_sum2(pf, pc, sm);
-    f += pf;
-    c += pc;
+    if (lane == 63) { sm[wave] = iff; sm[4 + wave] = icc; }
+    __syncthreads();
+    int wf = 0, wc = 0, tf = 0, tc = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+        if (w < wave) { wf += sm[w]; wc += sm[4 + w]; }
+        tf += sm[w]; tc += sm[4 + w];
+    }
+    // look-back by the first wave: the totals of all tiles in front of this one
+    if (wave == 0) {
+        int ef = 0, ec = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(status + tile, kFlagAgg | ((unsigned long long)(unsigned)tf << 32) | (unsigned)tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int back = tile - 1;
+            while (true) {
+                const int idx = back - lane;
+                unsigned long long st = kFlagPre;  // (tiles in front of the first: an empty prefix)
+                if (idx >= 0) {
+                    do {
+                        st = __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((st & kFlagMask) == 0ull);
+                }
+                const unsigned long long pre = __ballot((st & kFlagMask) == kFlagPre);
+                const int first_pre = pre ? __builtin_ctzll(pre) : 64;
+                int vf = lane <= first_pre ? (int)((st >> 32) & 0x3fffffffull) : 0, vc = lane <= first_pre ? (int)(unsigned)st : 0;
+                wave_sum2(vf, vc);
+                ef += vf; ec += vc;
+                if (pre) break;
+                back -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(status + tile, kFlagPre | ((unsigned long long)(unsigned)(ef + tf) << 32) | (unsigned)(ec + tc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sm[9] = ef; sm[10] = ec;
+        }
+    }
+    __syncthreads();
+    f = sm[9] + wf + iff - f;   // exclusive over all points in front of this thread's items
+    c = sm[10] + wc + icc - c;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         if (ff[k]) {
-            int s = pslot[base + k];
+            const bool many = cc[k] > 1;
             if (f < max_voxels) {
-                vid[s] = f;
-                boff[f] = c;
-                vslot[f] = s;
+                table[ss[k]].aux = many ? c : -1;
+                vkey[f] = kk[k];
+                vfirst[f] = base + k;
+                vcnt[f] = cc[k];
+                voff[f] = c;
             } else {
-                vid[s] = -1;
+                table[ss[k]].aux = -1;
             }
+            f += 1;
+            c += many ? cc[k] : 0;
         }
-        f += ff[k]; c += cc[k];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kScanThreads - 1) {
+    if (tile == n_tiles - 1 && tid == kScanThreads - 1) {  // (the last tile in arrival order is the last tile of the cloud: ids follow the counter)
         num_voxels[0] = f < max_voxels ? f : max_voxels;
+        need_place[0] = c > 0;
     }
 }
 
-__global__ void __launch_bounds__(256) vox_fill(const int *__restrict__ pslot, int n, const int *__restrict__ n_dev,
-                                                const int *__restrict__ vid, const int *__restrict__ boff, int *__restrict__ cursor,
-                                                int *__restrict__ bucket) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) vox_place(const int *__restrict__ pslot, const int *__restrict__ prank, int n, const int *__restrict__ n_dev,
+                                                 const VoxEntry *__restrict__ table, const int *__restrict__ need_place, int *__restrict__ bucket) {
+    if (!need_place[0]) return;  // every voxel holds one point: vox_emit reads the first points
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     n = fd::device_count(n, n_dev);
     if (i >= n) return;
-    int s = pslot[i];
+    const int s = pslot[i];
     if (s < 0) return;
-    int v = vid[s];
-    if (v < 0) return;
-    int pos = boff[v] + atomicAdd(&cursor[v], 1);
-    bucket[pos] = i;
+    const int off = table[s].aux;
+    if (off < 0) return;
+    bucket[off + prank[i]] = i;
 }
 
 template <int MAXP>
 __global__ void __launch_bounds__(256) vox_emit(const float *__restrict__ pts, VoxParams p, const int *__restrict__ num_voxels,
-                                                const int *__restrict__ keys, const int *__restrict__ vslot,
-                                                const int *__restrict__ boff, const int *__restrict__ cursor,
-                                                const int *__restrict__ bucket, int batch_idx, float *__restrict__ out_voxels,
-                                                float *__restrict__ out_mean, int mean_stride, int *__restrict__ out_coors,
+                                                const int *__restrict__ vkey, const int *__restrict__ vfirst, const int *__restrict__ vcnt,
+                                                const int *__restrict__ voff, const int *__restrict__ bucket, int batch_idx,
+                                                float *__restrict__ out_voxels, float *__restrict__ out_mean, int mean_stride, int *__restrict__ out_coors,
                                                 int coor_cols, int *__restrict__ out_num) {
-    int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= num_voxels[0]) return;
-    const int nv = cursor[v];
-    const int *b = bucket + boff[v];
-    int sel[MAXP];
-#pragma unroll
-    for (int k = 0; k < MAXP; ++k) sel[k] = 0x7fffffff;
-    for (int t = 0; t < nv; ++t) {
-        int x = b[t];
-#pragma unroll
-        for (int k = 0; k < MAXP; ++k) {  // keep sel[] ascending; x carries the displaced larger value
-            int lo = min(sel[k], x), hi = max(sel[k], x);
-            sel[k] = lo; x = hi;
-        }
-    }
-    const int np = nv < p.max_points ? nv : p.max_points;
+    __shared__ __attribute__((aligned(16))) float s_mean[256 * 16];
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nvox = num_voxels[0];
+    const bool live = v < nvox;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool via_lds = out_mean && mean_stride <= 16 && (mean_stride & 3) == 0;
     float sum[kMaxNd];
 #pragma unroll
     for (int d = 0; d < kMaxNd; ++d) sum[d] = 0.0f;
+    int np = 0;
+    if (live) {
+        const int nv = vcnt[v];
+        np = nv < p.max_points ? nv : p.max_points;
+        if (nv == 1 && !out_voxels) {
+            const float *q = pts + (int64_t)vfirst[v] * p.ndim;
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) {
-        if (k < p.max_points) {
-            const bool live = k < np;
-            const float *q = pts + (int64_t)(live ? sel[k] : 0) * p.ndim;
+            for (int d = 0; d < kMaxNd; ++d)
+                if (d < p.ndim) sum[d] = __fadd_rn(0.0f, q[d]);
+        } else {
+            int sel[MAXP];
 #pragma unroll
-            for (int d = 0; d < kMaxNd; ++d) {
-                if (d < p.ndim) {
-                    float val = live ? q[d] : 0.0f;
-                    sum[d] = __fadd_rn(sum[d], val);
-                    if (out_voxels) out_voxels[((int64_t)v * p.max_points + k) * p.ndim + d] = val;
+            for (int k = 0; k < MAXP; ++k) sel[k] = 0x7fffffff;
+            if (nv == 1) {
+                sel[0] = vfirst[v];
+            } else {
+                const int *b = bucket + voff[v];
+                for (int t = 0; t < nv; ++t) {
+                    int x = b[t];
+#pragma unroll
+                    for (int k = 0; k < MAXP; ++k) {  // keep sel[] ascending; x carries the displaced larger value
+                        const int lo = min(sel[k], x), hi = max(sel[k], x);
+                        sel[k] = lo; x = hi;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) {
+                if (k < p.max_points) {
+                    const bool on = k < np;
+                    const float *q = pts + (int64_t)(on ? sel[k] : 0) * p.ndim;
+#pragma unroll
+                    for (int d = 0; d < kMaxNd; ++d) {
+                        if (d < p.ndim) {
+                            const float val = on ? q[d] : 0.0f;
+                            sum[d] = __fadd_rn(sum[d], val);
+                            if (out_voxels) out_voxels[((int64_t)v * p.max_points + k) * p.ndim + d] = val;
+                        }
+                    }
                 }
             }
         }
+        const int key = vkey[v];
+        const int x = key % p.grid[0];
+        const int t = key / p.grid[0];
+        const int y = t % p.grid[1];
+        const int z = t / p.grid[1];
+        if (coor_cols == 4) *reinterpret_cast<int4 *>(out_coors + (int64_t)v * 4) = make_int4(batch_idx, z, y, x);
+        else { int *oc = out_coors + (int64_t)v * 3; oc[0] = z; oc[1] = y; oc[2] = x; }
+        out_num[v] = np;
     }
-    if (out_mean) {
-        const float cntf = (float)np;
+    if (!out_mean) return;
+    const float cntf = (float)np;
+    if (via_lds) {
+        // a wave's 64 rows of mean_stride floats are contiguous in the output: through LDS, then 16-byte stores in address order
+        float *sw = s_mean + wave * 64 * 16;
+        if (live) {
+#pragma unroll
+            for (int d = 0; d < 16; ++d)
+                if (d < mean_stride) sw[lane * mean_stride + d] = (d < p.ndim && d < kMaxNd) ? __fdiv_rn(sum[d < kMaxNd ? d : 0], cntf) : 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int v0 = blockIdx.x * blockDim.x + wave * 64;           // first voxel of this wave
+        const int rows = nvox - v0 < 64 ? nvox - v0 : 64;             // live rows of the wave (<= 0: none)
+        const int n4 = rows > 0 ? rows * mean_stride / 4 : 0;
+        float4 *dst = reinterpret_cast<float4 *>(out_mean + (int64_t)v0 * mean_stride);
+        for (int i = lane; i < n4; i += 64) dst[i] = reinterpret_cast<const float4 *>(sw)[i];
+    } else if (live) {
 #pragma unroll
         for (int d = 0; d < kMaxNd; ++d)
             if (d < p.ndim) out_mean[(int64_t)v * mean_stride + d] = __fdiv_rn(sum[d], cntf);
         for (int d = p.ndim; d < mean_stride; ++d) out_mean[(int64_t)v * mean_stride + d] = 0.0f;
     }
-    int key = keys[vslot[v]];
-    int x = key % p.grid[0];
-    int t = key / p.grid[0];
-    int y = t % p.grid[1];
-    int z = t / p.grid[1];
-    int *oc = out_coors + (int64_t)v * coor_cols;
-    if (coor_cols == 4) { oc[0] = batch_idx; oc[1] = z; oc[2] = y; oc[3] = x; }
-    else { oc[0] = z; oc[1] = y; oc[2] = x; }
-    out_num[v] = np;
 }
 
 struct VoxWs {
-    size_t keys, first, cnt, cursor, vid, pslot, bsum, boff, vslot, bucket, total;
-    unsigned table;
+    size_t table, pslot, prank, status, vkey, vfirst, vcnt, voff, bucket, flags, total;
+    unsigned slots;
+    int tiles;
 };
 
 VoxWs vox_layout(int64_t n, int64_t max_voxels) {
     VoxWs w;
-    unsigned table = 1024;
-    while ((int64_t)table < 2 * n) table <<= 1;
-    w.table = table;
+    unsigned slots = 1024;
+    while ((int64_t)slots * 2 < 3 * n) slots <<= 1;  // >= 1.5 n: load factor <= 0.67 when every point is its own voxel
+    w.slots = slots;
+    w.tiles = (int)((n + kScanTile - 1) / kScanTile);
+    if (w.tiles < 1) w.tiles = 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += fd::align_up(bytes, 256); return o; };
-    w.keys = take(sizeof(int) * table);
-    w.first = take(sizeof(int) * table);
-    w.cnt = take(sizeof(int) * table);
-    w.cursor = take(sizeof(int) * (size_t)(max_voxels + 1));
-    w.vid = take(sizeof(int) * table);
+    w.table = take(sizeof(VoxEntry) * slots);
     w.pslot = take(sizeof(int) * (size_t)(n + 1));
-    w.bsum = take(sizeof(int) * 2 * (size_t)((n + kScanTile - 1) / kScanTile + 1));
-    w.boff = take(sizeof(int) * (size_t)(max_voxels + 1));
-    w.vslot = take(sizeof(int) * (size_t)(max_voxels + 1));
+    w.prank = take(sizeof(int) * (size_t)(n + 1));
+    w.status = take(sizeof(unsigned long long) * (size_t)(w.tiles + 1));
+    w.vkey = take(sizeof(int) * (size_t)(max_voxels + 1));
+    w.vfirst = take(sizeof(int) * (size_t)(max_voxels + 1));
+    w.vcnt = take(sizeof(int) * (size_t)(max_voxels + 1));
+    w.voff = take(sizeof(int) * (size_t)(max_voxels + 1));
     w.bucket = take(sizeof(int) * (size_t)(n + 1));
+    w.flags = take(sizeof(int) * 4);
     w.total = off;
     return w;
 }
@@ -314,27 +385,25 @@ extern "C" int fd_voxelize(const float *points, int64_t n_points, const int32_t 
         fd::set_error("fd_voxelize: workspace %zu < required %zu", workspace_bytes, w.total);
         return FD_EWORKSPACE;
     }
-    p.mask = w.table - 1;
+    FD_REQUIRE(((uintptr_t)workspace & 15) == 0, "fd_voxelize: workspace must be 16-byte aligned");
+    p.mask = w.slots - 1;
     char *ws = (char *)workspace;
-    int *keys = (int *)(ws + w.keys), *first = (int *)(ws + w.first), *cnt = (int *)(ws + w.cnt);
-    int *cursor = (int *)(ws + w.cursor), *vid = (int *)(ws + w.vid), *pslot = (int *)(ws + w.pslot);
-    int *bsum = (int *)(ws + w.bsum), *boff = (int *)(ws + w.boff), *vslot = (int *)(ws + w.vslot);
-    int *bucket = (int *)(ws + w.bucket);
+    VoxEntry *table = (VoxEntry *)(ws + w.table);
+    int *pslot = (int *)(ws + w.pslot), *prank = (int *)(ws + w.prank);
+    unsigned long long *status = (unsigned long long *)(ws + w.status);
+    int *vkey = (int *)(ws + w.vkey), *vfirst = (int *)(ws + w.vfirst), *vcnt = (int *)(ws + w.vcnt), *voff = (int *)(ws + w.voff);
+    int *bucket = (int *)(ws + w.bucket), *flags = (int *)(ws + w.flags);
     const int n = (int)n_points;
-    // (a kernel, not hipMemsetAsync: see fd::fill_words; one launch for the three regions -- cnt + cursor are adjacent)
-    fd::fill_words3(keys, 0xffffffffu, w.table, first, 0x7f7f7f7fu, w.table, cnt, 0u, (w.vid - w.cnt) / sizeof(int), stream);
     const int nb = (n + 255) / 256;
-    const int nsb = (n + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(vox_hash, dim3(nb), dim3(256), 0, stream, points, n, n_points_dev, p, keys, first, cnt, pslot);
-    hipLaunchKernelGGL(vox_scan1, dim3(nsb), dim3(kScanThreads), 0, stream, pslot, first, cnt, n, n_points_dev, bsum);
-    hipLaunchKernelGGL(vox_scan3, dim3(nsb), dim3(kScanThreads), 0, stream, pslot, first, cnt, n, n_points_dev, bsum, p.max_voxels,
-                       vid, boff, vslot, out_num_voxels);
-    hipLaunchKernelGGL(vox_fill, dim3(nb), dim3(256), 0, stream, pslot, n, n_points_dev, vid, boff, cursor, bucket);
+    hipLaunchKernelGGL(vox_init, dim3((w.slots + 255) / 256), dim3(256), 0, stream, table, w.slots, status, w.tiles + 1);
+    hipLaunchKernelGGL(vox_hash, dim3(nb), dim3(256), 0, stream, points, n, n_points_dev, p, table, pslot, prank);
+    hipLaunchKernelGGL(vox_scan, dim3(w.tiles), dim3(kScanThreads), 0, stream, pslot, table, n, n_points_dev, p.max_voxels, status, w.tiles, vkey, vfirst, vcnt,
+                       voff, out_num_voxels, flags);
+    hipLaunchKernelGGL(vox_place, dim3(nb), dim3(256), 0, stream, pslot, prank, n, n_points_dev, table, flags, bucket);
     const int64_t vmax = n_points < max_voxels ? n_points : max_voxels;
-#define FD_EMIT(MP)                                                                                                        \
-    hipLaunchKernelGGL(vox_emit<MP>, dim3((unsigned)((vmax + 255) / 256)), dim3(256), 0, stream, points, p, out_num_voxels, keys, \
-                       vslot, boff, cursor, bucket, batch_idx, out_voxels, out_mean, mean_stride, out_coors, coor_cols,           \
-                       out_num_points)
+#define FD_EMIT(MP)                                                                                                                               \
+    hipLaunchKernelGGL(vox_emit<MP>, dim3((unsigned)((vmax + 255) / 256)), dim3(256), 0, stream, points, p, out_num_voxels, vkey, vfirst, vcnt, voff, bucket, \
+                       batch_idx, out_voxels, out_mean, mean_stride, out_coors, coor_cols, out_num_points)
     if (max_points <= 16) FD_EMIT(16);       // VoxelNet configs: 10
     else if (max_points <= 32) FD_EMIT(32);  // PointPillars configs: 20
     else FD_EMIT(64);                        // points_to_voxel's default of 35
