@@ -27,6 +27,18 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxTaps = 27;
 constexpr int TM = 128, COUT = 32, TS = 4, WR = 1, RW = TM / WR;
 
+// Tuning builds only (tools/probes/build_exp.sh fd_spconv_c32 img -DFD_SKELETON_IMAGE, tools/skeleton_image_bench.py): the stop-rule
+// experiment of the round-4 review.  Mode 1: every (workgroup, chunk) DUMPS what its skeleton phases produce -- the compacted per-tap lists,
+// their counts, the four waves' item lists -- to a global image; mode 2: a launch LOADS that image instead of staging the raw rulebook
+// slice, compacting it and building the item lists, i.e. it runs as if the lists came ready-made with the rulebook of the indice_key
+// (built once, shared by the 4-5 convolutions of a level).  Results of a mode-2 launch are exact.
+#ifdef FD_SKELETON_IMAGE
+__device__ int *g_img;
+__device__ int g_img_mode;
+constexpr int kImgChunks = 4;                                   // chunks per workgroup the image has room for
+constexpr int kImgInts = kMaxTaps * TM + 28 + 64 + 4;           // list, counts (27 x 4 bytes), items (4 x 32 u16), item counts
+#endif
+
 template <int CIN, int DEPTH>
 __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ in, const float4 *__restrict__ wp, const float *__restrict__ bias,
                                                       const float *__restrict__ residual, int relu, const int *__restrict__ nbr, int64_t nbr_stride,
@@ -73,6 +85,10 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
             pre[i] = nbr[(int64_t)k * nbr_stride + o];
         }
     };
+#ifdef FD_SKELETON_IMAGE
+    const bool img_any_load = g_img && g_img_mode == 2;
+    if (!img_any_load)
+#endif
     fetch_slice(r_begin);
 
     const int ln = lane & 31, lh = lane >> 5;
@@ -86,6 +102,15 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
         const int n_rows = (r_end - row0) < chunk_rows ? (r_end - row0) : chunk_rows;
         if (n_rows <= 0) break;
         // ---- stage the prefetched slice, clear the accumulators
+#ifdef FD_SKELETON_IMAGE
+        int *img = g_img ? g_img + ((int64_t)blockIdx.x * kImgChunks + (chunk < kImgChunks ? chunk : kImgChunks - 1)) * kImgInts : nullptr;
+        const bool img_load = img && g_img_mode == 2;
+        if (img_load) {
+            for (int t = tid; t < K * TM / 4; t += 256) reinterpret_cast<int4 *>(s_list)[t] = reinterpret_cast<const int4 *>(img)[t];
+            if (tid < 28) reinterpret_cast<int *>(s_cnt)[tid] = img[kMaxTaps * TM + tid];
+            if (tid < 64) reinterpret_cast<int *>(s_items)[tid] = img[kMaxTaps * TM + 28 + tid];
+        } else
+#endif
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
             const int t = tid + i * 256;
@@ -124,7 +149,11 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
         if (tid < 32) s_pad[tid] = kPad;
         __syncthreads();
         // ---- in-place compaction per (tap, row half): wave w takes taps w, w + 4, ...; tails are filled with kPad
+#ifdef FD_SKELETON_IMAGE
+        for (int k = img_load ? K : wave; k < K; k += 4) {
+#else
         for (int k = wave; k < K; k += 4) {
+#endif
 #pragma unroll
             for (int h = 0; h < WR; ++h) {
                 const int base = k * TM + h * RW;
@@ -145,10 +174,18 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
             }
         }
         __syncthreads();
+#ifdef FD_SKELETON_IMAGE
+        if (!img_any_load)
+#endif
         if (chunk + 1 < n_chunks) fetch_slice(row0 + chunk_rows);  // the next chunk's slice travels while this chunk computes
 
         // ---- work list of this wave: item = 32 compacted pairs of one tap, code = (tap << 3) | group
         int n_items;
+#ifdef FD_SKELETON_IMAGE
+        if (img_load) {
+            n_items = img[kMaxTaps * TM + 28 + 64 + wave];
+        } else
+#endif
         {
             const int ng = (lane < K && (lane % TS) == ts) ? ((int)s_cnt[lane * 4 + wr] + 31) >> 5 : 0;
             int inc = ng;
@@ -163,6 +200,15 @@ __global__ void __launch_bounds__(256) spconv_f32_c32(const float *__restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef FD_SKELETON_IMAGE
+        if (img && g_img_mode == 1 && chunk < kImgChunks) {  // dump: the compacted lists, counts and this wave's items
+            __syncthreads();
+            for (int t = tid; t < K * TM; t += 256) img[t] = s_list[t];
+            if (tid < 28) img[kMaxTaps * TM + tid] = reinterpret_cast<const int *>(s_cnt)[tid];
+            if (tid < 64) img[kMaxTaps * TM + 28 + tid] = reinterpret_cast<const int *>(s_items)[tid];
+            if (lane == 0) img[kMaxTaps * TM + 28 + 64 + wave] = n_items;
+        }
+#endif
 
         // software pipeline as in the v2 kernel: item code one iteration ahead of the list entry, the list entry one ahead
         // of the gather, the gather DEPTH - 1 items ahead of the MFMAs; everything branch-free (a slot past the end of the
@@ -289,6 +335,13 @@ int launch_c32(const float *in, const void *wp, const float *bias, const float *
 }
 
 }  // namespace
+
+#ifdef FD_SKELETON_IMAGE
+extern "C" int fd_debug_set_skeleton_image(void *p, int mode) {
+    return (hipMemcpyToSymbol(HIP_SYMBOL(g_img), &p, sizeof(p)) == hipSuccess && hipMemcpyToSymbol(HIP_SYMBOL(g_img_mode), &mode, sizeof(mode)) == hipSuccess) ? 0 : -1;
+}
+extern "C" int fd_debug_skeleton_image_ints(void) { return kImgChunks * kImgInts; }
+#endif
 
 namespace fd {
 // wp: the 32x32x2 fragment layout ([K][CIN / 8][64 lanes] float4, see fd_spconv_pack_weight).  Returns 1 when launched.

@@ -184,7 +184,8 @@ __global__ void __launch_bounds__(256) spconv_f32_compact(const float *__restric
     __syncthreads();
     if (chunk == 0) FD_T(1);
     // ---- in-place compaction: wave w takes taps w, w+4, ...; tails are filled with kPad
-    for (int k = wave; k < K; k += 4) {
+    for (int k = wave; k < K; k += 4)
+    {
 #pragma unroll
         for (int wr = 0; wr < WR; ++wr) {
             const int base = k * TM + wr * RW;
