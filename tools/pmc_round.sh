@@ -7,7 +7,7 @@ tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py"
+B="python $GRAFT_REPO_ROOT/bench.py --no-also"
 rocprofv3 --kernel-trace --stats -d /tmp/kt_$tag -o kt --output-format csv -- $B "$@" > $out/${tag}_bench_profiled.json 2> /tmp/kt_$tag.err
 cp $(find /tmp/kt_$tag -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
 # one step in isolation: a serial run (--inflight 1).  Forward passes of the trace: 1 set-up + 2 StaticStep warm-up + 1 pre-capture run,

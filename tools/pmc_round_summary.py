@@ -27,7 +27,7 @@ def opt(name, field, default):  # an explicit flag wins over the preset, as in b
 
 
 key = "%s/%s/%s/b%s" % (opt("--variant", "variant", "forecast_n0"), opt("--dtype", "dtype", "fp32"), opt("--points", "points", "300000"),
-                        opt("--batch", "batch", "1"))
+                        opt("--batch", "batch", "2"))
 SIMDS = 1024
 XCCS = 8  # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs; MfmaUtil's denominator is its per-XCD maximum (~ sum / 8)
 
@@ -42,13 +42,14 @@ def family(k):
 
 
 def load(name):
-    """rows of the LAST TWO complete forward passes of the run (a pass starts at its vox_hash launch): the earlier passes
+    """rows of the LAST TWO complete forward passes of the run (a pass starts at its first voxelizer launch): the earlier passes
     contain the plan's one-off timing of every convolution formulation / tile, which is not what a step executes"""
     p = os.path.join(out, "%s_pmc_%s.csv" % (tag, name))
     if not os.path.isfile(p):
         return []
     rows = list(csv.DictReader(open(p)))
-    starts = sorted({int(r["Dispatch_Id"]) for r in rows if "vox_hash" in r["Kernel_Name"]})
+    order = sorted({(int(r["Dispatch_Id"]), r["Kernel_Name"]) for r in rows})  # one entry per dispatch, in dispatch order
+    starts = [d for i, (d, k) in enumerate(order) if "vox_init" in k and (i == 0 or "vox_" not in order[i - 1][1])]  # first voxelizer launch of a pass
     if len(starts) >= 3:
         lo, hi = starts[-3], starts[-1]
         rows = [r for r in rows if lo <= int(r["Dispatch_Id"]) < hi]

@@ -1,15 +1,26 @@
-"""Summarise a rocprofv3 --kernel-trace CSV for the LAST step of bench.py (a step starts at vox_hash)."""
+"""Summarise a rocprofv3 --kernel-trace CSV for the LAST step of bench.py (a step starts at its first voxelizer launch)."""
 import csv
 import sys
 from collections import OrderedDict
 
 
+def pass_starts(rows):
+    """indices of the rows that start a forward pass: the first kernel of a voxelizer call (vox_init) whose predecessor is not a voxelizer
+    kernel -- a pass of B clouds runs B voxelizer calls back to back"""
+    out = []
+    for i, r in enumerate(rows):
+        if "vox_init" in r["Kernel_Name"] and (i == 0 or "vox_" not in rows[i - 1]["Kernel_Name"]):
+            out.append(i)
+    return out
+
+
+
 def main(path, steps_back=1, step_index=None):
-    """step_index = k: the k-th forward pass of the trace (0-based, counted by its vox_hash launch; use with a serial
+    """step_index = k: the k-th forward pass of the trace (0-based, counted by its first voxelizer launch; use with a serial
     --inflight 1 run: passes in flight on two streams interleave in time).  Otherwise the steps_back passes before the last."""
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "vox_hash" in r["Kernel_Name"]]
+    starts = pass_starts(rows)
     # full steps only: from the (steps_back+1)-th last step start up to the start of the last step (the trailing
     # part of the trace also holds bench.py's post-loop pair counting, which is not part of a step)
     if step_index is not None:

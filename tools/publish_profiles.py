@@ -53,7 +53,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
         print("missing", p)
         continue
     rows = list(csv.DictReader(open(p)))
-    starts = sorted({int(r["Dispatch_Id"]) for r in rows if "vox_hash" in r["Kernel_Name"]})
+    order = sorted({(int(r["Dispatch_Id"]), r["Kernel_Name"]) for r in rows})  # one entry per dispatch, in dispatch order
+    starts = [d for i, (d, k) in enumerate(order) if "vox_init" in k and (i == 0 or "vox_" not in order[i - 1][1])]  # first voxelizer launch of a pass
     lo, hi = (starts[-3], starts[-1]) if len(starts) >= 3 else (0, 1 << 62)
     per = collections.OrderedDict()
     for r in rows:
