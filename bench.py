@@ -685,7 +685,7 @@ def measure(args, env):
         out["roofline"] = dict(top, **{
             "hbm_copy_measured_gbs": hbm_copy, "hbm_copy_what": "512 MB device-to-device copy in this run, (read + write bytes) / time; spec peak 8000 GB/s",
             "traffic": traffic, "traffic_source": pmc_src,
-            "kernel": "spconv_f32_compact / spconv_f32_c32 (fp32), spconv_bf16_ws (bf16) behind fd_spconv_apply", "launches_per_step": launches // n_prof_used,
+            "kernel": "spconv_f32_compact / spconv_f32_c32 (fp32), spconv_bf16_win / spconv_bf16_ws (bf16) behind fd_spconv_apply", "launches_per_step": launches // n_prof_used,
             "avg_launch_us": round(avg_us, 2), "measured": "HIP events on the launch stream around every fd_spconv_apply of the instrumented step(s) of the timed "
                                                            "region (run eagerly and alone), this run; the median step of spconv_ms_each_instrumented_step",
             "algorithmic_bytes_per_launch": int(tot_bytes / max(launches, 1)),

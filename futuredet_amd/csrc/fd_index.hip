@@ -383,39 +383,59 @@ __global__ void __launch_bounds__(256) rows_place4(const unsigned long long *__r
     }
 }
 
-// one thread per (output row, (ky,kx) column pair): fills the kz taps of that column from one word load
+// One thread per (FOUR consecutive output rows, ky): it requests the words and prefixes of the (up to three) kx columns of its rows
+// up front and writes the kz taps of each column as 16-byte stores: 37 vector-memory instructions per four rows and ky where the
+// round-1 form (one row and one (ky, kx) per thread, 4-byte stores) issued 72.  Measured neutral (8 launches of a 2-cloud pass: 161 ->
+// 150-160 us): the launches write 27 x rows x 4 bytes at 2.0-2.4 TB/s, so what is left is the size of the table, not its construction.
 __global__ void __launch_bounds__(256) rulebook_kernel(const unsigned long long *__restrict__ in_words, const int *__restrict__ in_prefix,
                                                        IndexGeom gi, const int *__restrict__ out_coords, const int *__restrict__ n_out_dev,
-                                                       int64_t nbr_stride, int64_t out_rows, int fill_tail, DownParams dp, int *__restrict__ nbr) {
+                                                       int64_t nbr_stride, int64_t out_rows, int fill_tail, int vec, DownParams dp, int *__restrict__ nbr) {
     // rows = the device's count clamped to what the coordinate table HOLDS (out_rows), not to the padded row stride of nbr: an
     // overflowing sweep of a capacity-sized level (count > capacity) must not read coordinates past the level's slice
     const int n_out = fd::device_count((int)(out_rows < 0x7fffffff ? out_rows : 0x7fffffff), n_out_dev);
     // rows written: all of the table's row capacity (tail = -1), or only the device's count when the consumers clamp to it
     // themselves (capacity-sized tables of the sync-free step: the launch must not cost what the capacity suggests)
     const int64_t n_rows = fill_tail ? nbr_stride : (int64_t)n_out;
-    // blockIdx.y = (ky, kx); rows grid-stride in x (no 64-bit division per element)
-    const int q = blockIdx.y;
-    const int ky = q / dp.k[2], kx = q - ky * dp.k[2];
-    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_rows; o += (int64_t)gridDim.x * blockDim.x) {
-        if (o >= n_out) {
-            for (int kz = 0; kz < dp.k[0]; ++kz) nbr[((int64_t)(kz * dp.k[1] + ky) * dp.k[2] + kx) * nbr_stride + o] = -1;
-            continue;
+    const int ky = blockIdx.y;  // rows grid-stride in x, four per thread (vec: every tap's row run starts on 16 bytes)
+    for (int64_t o4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; o4 < n_rows; o4 += (int64_t)gridDim.x * blockDim.x * 4) {
+        int4 c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t o = o4 + j < n_out ? o4 + j : (n_out > 0 ? n_out - 1 : 0);  // (clamped address; rows >= n_out are written as -1)
+            c[j] = n_out > 0 ? reinterpret_cast<const int4 *>(out_coords)[o] : make_int4(0, 0, 0, 0);  // (b,z,y,x)
         }
-        const int4 c = reinterpret_cast<const int4 *>(out_coords)[o];  // (b,z,y,x)
-        const int iy = c.z * dp.s[1] - dp.p[1] + ky;
-        const int ix = c.w * dp.s[2] - dp.p[2] + kx;
-        unsigned long long w = 0;
-        int base = 0;
-        if (iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W) {
-            int64_t col = fd::col_of(gi, c.x, iy, ix);
-            w = in_words[col];
-            if (w) base = in_prefix[col];
+        // every word and prefix of the (up to three) kx columns is requested before any is used: two dependent loads per thread, not six
+        unsigned long long w[3][4];
+        int base[3][4];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = c[j].z * dp.s[1] - dp.p[1] + ky;
+                const int ix = c[j].w * dp.s[2] - dp.p[2] + kx;
+                const bool ok = kx < dp.k[2] && o4 + j < n_out && iy >= 0 && iy < gi.H && ix >= 0 && ix < gi.W;
+                const int64_t col = ok ? fd::col_of(gi, c[j].x, iy, ix) : 0;  // (unconditional loads at a clamped address)
+                const unsigned long long wv = in_words[col];
+                base[kx][j] = in_prefix[col];
+                w[kx][j] = ok ? wv : 0ull;
+            }
         }
-        for (int kz = 0; kz < dp.k[0]; ++kz) {
-            int iz = c.y * dp.s[0] - dp.p[0] + kz;
-            int r = -1;
-            if (iz >= 0 && iz < gi.D && ((w >> iz) & 1ull)) r = base + __popcll(w & ((1ull << iz) - 1ull));
-            nbr[((int64_t)(kz * dp.k[1] + ky) * dp.k[2] + kx) * nbr_stride + o] = r;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            if (kx >= dp.k[2]) break;
+            for (int kz = 0; kz < dp.k[0]; ++kz) {
+                int r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int iz = c[j].y * dp.s[0] - dp.p[0] + kz;
+                    const unsigned long long wv = w[kx][j];
+                    r[j] = (iz >= 0 && iz < gi.D && ((wv >> iz) & 1ull)) ? base[kx][j] + __popcll(wv & ((1ull << iz) - 1ull)) : -1;
+                }
+                int *dst = nbr + ((int64_t)(kz * dp.k[1] + ky) * dp.k[2] + kx) * nbr_stride + o4;
+                if (vec && o4 + 3 < n_rows) *reinterpret_cast<int4 *>(dst) = make_int4(r[0], r[1], r[2], r[3]);
+                else
+                    for (int j = 0; j < 4 && o4 + j < n_rows; ++j) dst[j] = r[j];
+            }
         }
     }
 }
@@ -555,13 +575,15 @@ extern "C" int fd_rulebook(const uint64_t *in_words, const int32_t *in_prefix, i
     FD_REQUIRE(fill_dp(dp, ksize3, stride3, pad3) == 0, "fd_rulebook: unsupported kernel/stride/pad");
     if (nbr_stride <= 0) return FD_OK;
     IndexGeom gi = fd::make_geom(B, Din, Hin, Win);
-    // grid: x = rows (grid-stride, bounded whatever the row capacity of the table), y = (ky, kx)
-    const int kyx = dp.k[1] * dp.k[2];
-    int64_t blocks = (nbr_stride + 255) / 256;
-    const int64_t cap = ((int64_t)fd::device_cu_count() * 32 + kyx - 1) / kyx;
+    // grid: x = groups of four rows (grid-stride, bounded whatever the row capacity of the table), y = ky
+    const int kyn = dp.k[1];
+    const int vec = (nbr_stride % 4 == 0) && (reinterpret_cast<uintptr_t>(nbr) % 16 == 0);
+    int64_t blocks = ((nbr_stride + 3) / 4 + 255) / 256;
+    const int64_t cap = ((int64_t)fd::device_cu_count() * 32 + kyn - 1) / kyn;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(rulebook_kernel, dim3((unsigned)blocks, (unsigned)kyx), dim3(256), 0, fd::as_stream(stream),
-                       (const unsigned long long *)in_words, in_prefix, gi, out_coords, n_out_dev, nbr_stride, out_rows, fill_tail, dp, nbr);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rulebook_kernel, dim3((unsigned)blocks, (unsigned)kyn), dim3(256), 0, fd::as_stream(stream),
+                       (const unsigned long long *)in_words, in_prefix, gi, out_coords, n_out_dev, nbr_stride, out_rows, fill_tail, vec, dp, nbr);
     return fd::check_launch("fd_rulebook");
 }
 
