@@ -45,6 +45,9 @@ for lvl in (1, 2, 3):
         raw.fd_debug_set_wintrace(None)
         t = trace.cpu().numpy().reshape(-1, 8)
         t = t[t[:, 3] > 0]
+        if len(t) == 0:
+            print("level %d C=%d rows %d: not on the window kernel of this build" % (lvl, C, ix.n), flush=True)
+            continue
         print("level %d C=%d rows %d rg=%d: %d workgroups, kernel %.1f us; cycles per workgroup (median / max): prologue %d / %d, tap loop %d / %d, epilogue %d / %d, "
               "whole %d / %d, passes %d; inside the tap loop (median): requests %d, MFMA phase %d, hand-over wait + barrier %d" % (
                   lvl, C, ix.n, rg, len(t), 1e3 * e0.elapsed_time(e1), np.median(t[:, 0]), t[:, 0].max(), np.median(t[:, 1]), t[:, 1].max(),
