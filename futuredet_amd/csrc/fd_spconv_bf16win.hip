@@ -11,16 +11,21 @@
 //   (b) LDS bytes per MFMA: a wave owned 16-48 rows and read the whole W[tap] from LDS for them -- eight waves, all at the same
 //       moment behind the tap barrier.
 // Round 4's window kernel removed (a) and made (b) worse (16 rows per wave); this one does both:
-//   * a workgroup = 4 waves (one per SIMD, the whole register file each) owns TM = 128 * RGS consecutive output rows per pass and
-//     stages the input rows [first - HALO, last + HALO] ONCE, by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write), 16-byte
-//     pieces XOR-swizzled by the row.  Rows are spatially sorted (fd_index.hip), so 90 % of all pairs lie inside; a (32-row group,
-//     tap) item with a neighbour outside takes the bounds-checked global gather for its lanes instead (wave-uniform branch) --
-//     correctness never depends on locality;
+//   * a workgroup = NW waves (8: two per SIMD, half the register file each; 4: one per SIMD, "bf16_nw") owns TM = NW * 32 * RGS
+//     consecutive output rows per pass and stages the input rows [first - HALO, last + HALO] ONCE, by LDS-DMA (global_load_lds_dwordx4:
+//     no registers, no ds_write), 16-byte pieces XOR-swizzled by the row.  Rows are spatially sorted (fd_index.hip), so 90 % of all
+//     pairs lie inside; a (32-row group, tap) item with a neighbour outside takes the bounds-checked global gather for its lanes
+//     instead (exec-masked) -- correctness never depends on locality;
 //   * a wave owns 32 * RGS rows and ALL output columns: accumulators in registers over all taps (v_mfma_f32_32x32x16_bf16,
-//     transposed: A = weights), one 1-KB weight fragment read from LDS feeds RGS MFMAs of 32 cycles, one 1-KB row fragment COUT / 32;
-//   * weights travel global -> LDS by DMA through a ring of three (tap, 64-channel) stages, two steps ahead; rulebook entries
-//     come straight from global memory into registers a tap ahead (coalesced 128-byte reads, no LDS slice);
-//   * the B operand of step u + 1 (LDS reads or gathers) is requested before the MFMAs of step u (register double buffer).
+//     transposed: A = weights), one 1-KB weight fragment read from LDS feeds RGS MFMAs of 32 cycles, one 1-KB row fragment COUT / 32.
+//     That is (1 / RGS + 32 / COUT) KB of LDS reads per MFMA, four SIMDs wide: 160 B/clk on 128 -> 128 at RGS = 1, 128 B/clk on
+//     64 -> 64 at RGS = 2, against the port's 128 -- the 128-channel loop is LDS-bound just above its MFMA time (a (tap, 64-channel)
+//     step of the two waves of a SIMD: 1024 cycles of MFMA, 1250 of LDS, measured 1330-1480); RGS = 2 there needs 128 accumulator + 64
+//     operand registers per wave and spills at eight waves, and runs at the in-order issue of a lone wave at four (62 us vs 57-59);
+//   * weights travel global -> registers -> LDS through a ring of three (tap, 64-channel) stages, two steps ahead (plain loads +
+//     ds_write: hipcc answers every wait with vmcnt(0) while an LDS-DMA is pending); rulebook entries come straight from global memory
+//     into registers a tap ahead (coalesced 128-byte reads, no LDS slice);
+//   * the B operand of step u + 1 (LDS reads or gathers) is requested in the gaps behind the MFMAs of step u (register double buffer).
 // Per output element the summation order is fixed (taps ascending, 16-channel MFMA steps ascending), so results do not depend on
 // RGS, on the grid, or on which items took the gather (tested bit for bit); they differ from the RING kernels' by fp32 summation
 // order only (both are checked against the bf16 oracle layer by layer, within one bf16 ulp).
@@ -548,8 +553,10 @@ int spconv_bf16_win_dispatch(const void *in, const void *wp_win, const float *bi
             default: ok = win_launch<64, 64, 4, 128>(a); break;
         }
     }
-    // (32 -> 32 was tried on this formulation -- rows of 64 bytes, 1050 rows per CU, two passes of 768: 66 us against the 42 us of the
-    //  RESIDENT kernel of fd_spconv_bf16.hip, whose whole weight set sits in LDS with no barrier per tap; tools/spconv_bench.py, round 5)
+    // (32 -> 32 on this formulation -- a weight ring with a barrier per tap -- measured 66 us against the 42 us of the RESIDENT kernel of
+    //  fd_spconv_bf16.hip; a second form with the weight set resident in LDS, a sliding window and no barrier inside a pass was built,
+    //  parity-green, and removed: LDS-bound (1.5 KB of operands per 32-cycle MFMA) at the RESIDENT kernel's time -- 45.8 vs 42.3 us, two
+    //  clouds 70 vs 70; profiles/round5_bf16win32_negative.txt)
     return ok ? 1 : 0;
 }
 }  // namespace fd

@@ -234,9 +234,9 @@ def test_spconv_apply_vs_oracle(hip, cin, cout, dtype):
         assert_close("spconv_apply f32 %d->%d pair-compacting kernel vs oracle" % (cin, cout), y_compact, ref_sorted, tol)
 
 
-@pytest.mark.parametrize("c", [64, 128])
+@pytest.mark.parametrize("c", [32, 64, 128])
 def test_bf16_window_kernel_without_locality_multi_pass_and_device_count(hip, c):
-    """fd_spconv_bf16win.hip: correctness must not depend on the rulebook's locality (an item with a neighbour outside the LDS window
+    """fd_spconv_bf16win.hip (64, 128 channels; 32 runs the same checks on the RESIDENT kernel of fd_spconv_bf16.hip): correctness must not depend on the rulebook's locality (an item with a neighbour outside the LDS window
     takes the global gather), on the number of passes of a workgroup, or on where the row count comes from.  (a) a SubM rulebook of a
     sorted index, (b) the same rulebook with its input rows PERMUTED at random (no locality at all: every item gathers), (c) the same with
     the row count read from device memory and a capacity-sized launch -- all against a float64 host evaluation of
