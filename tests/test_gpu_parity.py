@@ -1893,7 +1893,7 @@ def test_two_ranks_weak_scaling_gathers_once_after_the_run(hip, tmp_path):
     assert "after the last step" in line["config"]["parallelism"] and "hipGraph" in line["config"]["workload"]
     g = np.load(dump)
     got = dist_infer.unpack_results(torch.from_numpy(g["packed"]), torch.from_numpy(g["counts"]))
-    B = line["config"]["batch_per_pass"] if "batch_per_pass" in line["config"] else len(got) // 2  # (the bench's default: two clouds per pass)
+    B = len(got) // 2  # clouds per rank and pass (the bench's default: two)
     assert B >= 1 and len(got) == 2 * B
     cfg, net, _ = _build_pair("forecast_n0")
     with torch.no_grad():
@@ -2266,12 +2266,15 @@ def test_eight_ranks_on_one_gpu_weak_scaling(hip, tmp_path):
     assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["steps"] == 3 and line["value"] > 0
     assert "checksum" in line["config"]["replicas"] and "all 8 rank" in line["config"]["replicas"]
     got = dist_infer.unpack_results(torch.from_numpy(g["packed"]), torch.from_numpy(g["counts"]))
-    assert len(got) == 8
+    B = len(got) // 8  # clouds per rank and pass (the bench's default: two)
+    assert B >= 1 and len(got) == 8 * B
     cfg, net, _ = _build_pair("forecast_n0")
     with torch.no_grad():
-        for r in range(8):  # last step (index 2) uses pool slot 0 -> seed (r * pool + 0) * B
-            want = net.forward_points([_dev(synthetic_cloud(seed=r * 2, target_points=20000))], cfg.voxel_generator, padded=False)[0]
-            _attribute("8 ranks weak scaling: rank %d last step vs single process" % r, _rows(got[r]), _rows(want), cfg.test_cfg)
+        for r in range(8):  # last step (index 2) uses pool slot 0 -> seeds (r * pool + 0) * B + b; gathered sample b * W + r
+            for b in range(B):
+                want = net.forward_points([_dev(synthetic_cloud(seed=r * 2 * B + b, target_points=20000))], cfg.voxel_generator, padded=False)[0]
+                _attribute("8 ranks weak scaling: rank %d cloud %d of the last step vs single process" % (r, b), _rows(got[b * 8 + r]), _rows(want),
+                           cfg.test_cfg)
 
 
 def test_eight_ranks_on_one_gpu_config4_strong_scaling(hip, tmp_path):
