@@ -17,6 +17,7 @@
 //     writing interleaved pixels) are expressed without extra passes.
 #include "fd_common.h"
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -34,6 +35,12 @@ constexpr int TH = 8, TW = 16;  // output pixels per workgroup (M = 128)
 // fragment loads inside the step loop, 2 = no A-fragment LDS reads inside the step loop, 4 = no MFMAs
 #ifndef FD_CONV_EXP
 #define FD_CONV_EXP 0
+#endif
+#ifndef FD_CONV_RING  // weight fragments in flight per column block (tuning builds)
+#define FD_CONV_RING 6
+#endif
+#ifndef FD_CONV_WAVES  // waves per SIMD the stride-1 tile kernel is compiled for (tuning builds)
+#define FD_CONV_WAVES 2
 #endif
 #ifdef FD_V2_TRACE
 __device__ unsigned long long *g_ctrace;
@@ -55,6 +62,9 @@ struct ConvParams {
     int osy, osx, ooy, oox;  // output pixel mapping
     int tiles_x, tiles_y;
     unsigned w_bytes;
+    // mixed tiling of a stride-1 layer (GEN instances): fh x fw whole 8 x 16 tiles, then the columns right of them as tiles of th_r x rw
+    // pixels, then the rows below as tiles of bh x tw_b pixels (each <= 128 pixels, sides <= 32); see mixed_tiles()
+    int fh, fw, n_right, th_r, rw, n_bottom, tw_b, bh, tiles_img;
 };
 
 #ifdef FD_V2_TRACE
@@ -151,12 +161,23 @@ __device__ __forceinline__ void conv_bf16_epilogue(const f32x16 (&acc)[WMT][WNT]
 }
 
 // WMT x WNT MFMA tiles (32 x 32) per wave, waves arranged WAVES_M x WAVES_N (product 4); M tile = 128 pixels
-template <int KS, int S, int WMT, int WNT, int WAVES_M, int WAVES_N>
-__global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__restrict__ x, const bf16x8 *__restrict__ wp,
+// GEN (stride 1 only): the workgroup's tile is one of the three shapes of the layer's MIXED tiling (ConvParams::fh ...): 180 x 180 is
+// 23 x 12 = 276 ragged 8 x 16 tiles but 242 whole ones + 6 of 32 x 4 + 6 of 4 x 32 = 254 -- one workgroup per compute unit for one
+// map, 508 for two on the 512 slots two resident workgroups per unit give (the 40 workgroups of 552 that had to wait for a slot made
+// a two-map layer take 28 us instead of 18: start times by s_memrealtime, tools/conv_bf16_trace.py).  The tile's height / width and
+// the patch pitch become run-time values: pixel -> (row, column) by a 16-bit reciprocal, one A-fragment base per kernel ROW (the
+// column and k-half offsets stay immediates), nothing new inside the step loop; the arithmetic order per output pixel is unchanged
+// (bit-identical to the fixed tiling, tested).
+template <int KS>
+constexpr int gen_max_patch() { return KS == 1 ? 128 : 204; }  // (4 x 32 tile: 6 x 34 patch pixels)
+
+template <int KS, int S, int WMT, int WNT, int WAVES_M, int WAVES_N, bool GEN = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 1 ? FD_CONV_WAVES : 2))) conv2d_nhwc_bf16(const unsigned short *__restrict__ x, const bf16x8 *__restrict__ wp,
                                                         const float *__restrict__ bias, unsigned short *__restrict__ y, ConvParams p) {
     static_assert(WAVES_M * WAVES_N == 4 && WMT * WAVES_M * 32 == TH * TW, "tile shape");
-    constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PP = PH * PW;
-    constexpr int NCHUNK16 = PP * 4;                    // 16-byte chunks per 32-channel patch
+    static_assert(!GEN || S == 1, "mixed tiles: stride 1 only");
+    constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS, PP = GEN ? gen_max_patch<KS>() : PH * PW;
+    constexpr int NCHUNK16 = PP * 4;                    // 16-byte chunks per 32-channel patch (GEN: of the largest one)
     constexpr int NLOAD = (NCHUNK16 + 255) / 256;
     constexpr int NT = WNT * WAVES_N * 32;              // output channels per workgroup
     constexpr int PIXB = 80;                            // LDS bytes per patch pixel (see store_slice)
@@ -170,14 +191,36 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
     unsigned long long cacc[6] = {0, 0, 0, 0, 0, 0};
 #endif
     FD_CT(c_start);
+#ifdef FD_V2_TRACE
+    const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one counter for the whole device
+#endif
     const int wm = wave % WAVES_M, wn = wave / WAVES_M;
-    int t = blockIdx.x;
-    const int tx = t % p.tiles_x; t /= p.tiles_x;
-    const int ty = t % p.tiles_y; const int b = t / p.tiles_y;
+    int b, oy0, ox0, th = TH, tw = TW;  // (uniform)
+    if constexpr (GEN) {
+        int t = blockIdx.x % p.tiles_img;
+        b = blockIdx.x / p.tiles_img;
+        const int n_core = p.fh * p.fw;
+        if (t < n_core) {
+            oy0 = (t / p.fw) * TH; ox0 = (t % p.fw) * TW;
+        } else if (t < n_core + p.n_right) {
+            oy0 = (t - n_core) * p.th_r; ox0 = p.fw * TW;
+            th = min(p.th_r, p.fh * TH - oy0); tw = p.rw;
+        } else {
+            oy0 = p.fh * TH; ox0 = (t - n_core - p.n_right) * p.tw_b;
+            th = p.bh; tw = min(p.tw_b, p.Wo - ox0);
+        }
+    } else {
+        int t = blockIdx.x;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y; b = t / p.tiles_y;
+        oy0 = ty * TH; ox0 = tx * TW;
+    }
     const int n0 = blockIdx.y * NT + wn * WNT * 32;     // first output channel of this wave
-    const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
     const int nslices = p.Cin / 32;
+    // GEN: run-time tile and patch shape; x / d for x < 256, d <= 34 as (x * ceil(65536 / d)) >> 16 (exact: x (ceil - 65536 / d) < 65536 / d)
+    const int pw = GEN ? tw + KS - 1 : PW, n_pix = th * tw, n_patch = (th + KS - 1) * pw;
+    const unsigned rcp_tw = (65536u + (unsigned)tw - 1u) / (unsigned)tw, rcp_pw = (65536u + (unsigned)pw - 1u) / (unsigned)pw;
 
     // per-thread patch chunk assignment: chunk id -> (pixel, q)
     uint4 stage[NLOAD];
@@ -188,8 +231,15 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
             stage[i] = make_uint4(0u, 0u, 0u, 0u);
             if (id < NCHUNK16) {
                 const int pix = id >> 2, q = id & 3;
-                const int iy = iy0 + pix / PW, ix = ix0 + pix % PW;
-                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                int py, px;
+                if constexpr (GEN) {
+                    py = (int)(((unsigned)pix * rcp_pw) >> 16);
+                    px = pix - py * pw;
+                } else {
+                    py = pix / PW; px = pix % PW;
+                }
+                const int iy = iy0 + py, ix = ix0 + px;
+                if ((!GEN || pix < n_patch) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
                     stage[i] = *reinterpret_cast<const uint4 *>(x + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + s * 32 + q * 8);
             }
         }
@@ -223,9 +273,15 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
     int prow[WMT], pcol[WMT];
 #pragma unroll
     for (int i = 0; i < WMT; ++i) {
-        const int m = (wm * WMT + i) * 32 + lm;  // pixel index inside the 8 x 16 tile, row-major
-        prow[i] = (m / TW) * S;
-        pcol[i] = (m % TW) * S;
+        int m = (wm * WMT + i) * 32 + lm;  // pixel index inside the tile, row-major
+        if constexpr (GEN) {
+            m = m < n_pix ? m : 0;         // (slots past the tile read pixel 0; their results are not stored)
+            prow[i] = (int)(((unsigned)m * rcp_tw) >> 16);
+            pcol[i] = m - prow[i] * tw;
+        } else {
+            prow[i] = (m / TW) * S;
+            pcol[i] = (m % TW) * S;
+        }
     }
     // packed weights: [Cout_pad/32][slice][tap][ksub][lane] x 16 bytes
     const int64_t w_nt_stride = (int64_t)nslices * KS * KS * 2 * 64;
@@ -237,7 +293,7 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
     // keeps RING fragments in flight ahead of their MFMAs (an L2 hit costs ~1000 cycles, a (tap, k-half) step has only
     // WMT*WNT MFMAs), and the ring keeps running across the slice barrier.
     constexpr int ITERS = KS * KS * 2;
-    constexpr int RING = (ITERS % 6 == 0) ? 6 : 2;
+    constexpr int RING = (ITERS % 6 == 0) ? FD_CONV_RING : 2;
     const int total_iters = nslices * ITERS;
     // fragment loads: buffer loads with the wave-uniform part of the address in the scalar offset (no vector instruction per load)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(wp), 0, (int)p.w_bytes, 0x00020000);
@@ -254,7 +310,8 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
     // per-lane LDS base of the A fragments (tap (0, 0), k-half 0) relative to the slice buffer; a step adds a compile-time offset
     unsigned abase[WMT];
 #pragma unroll
-    for (int i = 0; i < WMT; ++i) abase[i] = (unsigned)((prow[i] * PW + pcol[i]) * PIXB + lk * 16);
+    for (int i = 0; i < WMT; ++i) abase[i] = (unsigned)((prow[i] * pw + pcol[i]) * PIXB + lk * 16);
+    const unsigned row_pitch = (unsigned)(pw * PIXB);  // GEN: the step loop adds it per kernel row (one base register per row)
     if (nslices > 1) load_slice(1);  // registers hold slice s+1 while slice s is computed
     FD_CT(c_pro);
     FD_CADD(0, c_pro - c_start);
@@ -266,14 +323,26 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
         // of a step (fences): an MFMA occupies the pipe for 32 cycles but issues in 4, what is issued in its shadow is free; lumped
         // after the step's MFMAs the same instructions cost ~100 cycles per 128-cycle step (tools/conv_bf16_trace.py: 4870 cycles
         // per slice for 2304 of MFMA before).
-        unsigned ab[WMT];
+        unsigned ab[GEN ? KS : 1][WMT];
 #pragma unroll
-        for (int i = 0; i < WMT; ++i) ab[i] = abase[i] + (unsigned)((s & 1) * (PP * PIXB));
+        for (int i = 0; i < WMT; ++i) {
+            ab[0][i] = abase[i] + (unsigned)((s & 1) * (PP * PIXB));
+            if constexpr (GEN) {
+#pragma unroll
+                for (int ky = 1; ky < KS; ++ky) ab[ky][i] = ab[0][i] + (unsigned)ky * row_pitch;
+            }
+        }
         auto read_a = [&](int it, bf16x8(&a)[WMT]) {
             const int tap = it >> 1, ks = it & 1;
-            const unsigned imm = (unsigned)(((tap / KS) * PW + tap % KS) * PIXB + ks * 32);  // compile-time: the ds_read offset field
+            if constexpr (GEN) {
+                const unsigned imm = (unsigned)((tap % KS) * PIXB + ks * 32);  // compile-time: the ds_read offset field
 #pragma unroll
-            for (int i = 0; i < WMT; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + ab[i] + imm);
+                for (int i = 0; i < WMT; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + ab[tap / KS][i] + imm);
+            } else {
+                const unsigned imm = (unsigned)(((tap / KS) * PW + tap % KS) * PIXB + ks * 32);  // compile-time: the ds_read offset field
+#pragma unroll
+                for (int i = 0; i < WMT; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + ab[0][i] + imm);
+            }
         };
         bf16x8 a[3][WMT];  // ring of three: the fragments of step it + 2 are requested in the middle of step it (1.5 steps = 190 cycles of lead)
         read_a(0, a[0]);
@@ -310,10 +379,17 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
         FD_CADD(1, c1 - c0); FD_CADD(2, c2 - c1); FD_CADD(3, c3 - c2);
     }
     FD_CT(c_epi);
-    const auto out_pixel = [&](int m, int &oy, int &ox) {  // pixel m of the 8 x 16 tile, row-major
-        oy = oy0 + m / TW;
-        ox = ox0 + m % TW;
-        return oy < p.Ho && ox < p.Wo;
+    const auto out_pixel = [&](int m, int &oy, int &ox) {  // pixel m of the tile, row-major
+        if constexpr (GEN) {
+            const int r = (int)(((unsigned)m * rcp_tw) >> 16);
+            oy = oy0 + r;
+            ox = ox0 + (m - r * tw);
+            return m < n_pix;
+        } else {
+            oy = oy0 + m / TW;
+            ox = ox0 + m % TW;
+            return oy < p.Ho && ox < p.Wo;
+        }
     };
     FD_EPI_TRACE_DECL
     conv_bf16_epilogue<WMT, WNT, WAVES_M, WAVES_N>(acc, smem, p, b, bias, y, out_pixel FD_EPI_TRACE_ARG);
@@ -321,21 +397,21 @@ __global__ void __launch_bounds__(256) conv2d_nhwc_bf16(const unsigned short *__
     if (tid == 0 && g_ctrace) {
         const unsigned long long c_end = __builtin_readcyclecounter();
         unsigned long long *o = g_ctrace + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 8;
-        o[0] = cacc[0]; o[1] = cacc[1]; o[2] = cacc[2]; o[3] = cacc[3]; o[4] = c_end - c_epi; o[5] = c_end - c_start; o[6] = c_mid - c_epi; o[7] = c_end;
+        o[0] = cacc[0]; o[1] = cacc[1]; o[2] = cacc[2]; o[3] = cacc[3]; o[4] = c_end - c_epi; o[5] = c_end - c_start; o[6] = c_mid - c_epi; o[7] = rt_start;
     }
 #endif
 }
 
-template <int KS, int S, int WMT, int WNT, int WAVES_M, int WAVES_N>
+template <int KS, int S, int WMT, int WNT, int WAVES_M, int WAVES_N, bool GEN = false>
 void launch_conv(const void *x, const void *wp, const float *bias, void *y, const ConvParams &p, hipStream_t stream) {
     constexpr int PH = (TH - 1) * S + KS, PW = (TW - 1) * S + KS;
     constexpr int NT = WNT * WAVES_N * 32;
-    size_t lds = 2 * (size_t)PH * PW * 80;
+    size_t lds = 2 * (size_t)(GEN ? gen_max_patch<KS>() : PH * PW) * 80;
     if (lds < (size_t)TH * TW * NT * 2) lds = (size_t)TH * TW * NT * 2;  // the epilogue transposes the tile through LDS
-    auto kern = conv2d_nhwc_bf16<KS, S, WMT, WNT, WAVES_M, WAVES_N>;
+    auto kern = conv2d_nhwc_bf16<KS, S, WMT, WNT, WAVES_M, WAVES_N, GEN>;
     static std::atomic<uint64_t> lds_set{0};
     if (lds > 65536) (void)fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_set);
-    dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.B), (unsigned)(p.Cout_pad / NT));
+    dim3 grid((unsigned)((GEN ? p.tiles_img : p.tiles_x * p.tiles_y) * p.B), (unsigned)(p.Cout_pad / NT));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const unsigned short *)x, (const bf16x8 *)wp, bias, (unsigned short *)y, p);
 }
 
@@ -466,7 +542,7 @@ __global__ void __launch_bounds__(256) conv2d_strip_bf16(const unsigned short *_
 
     load_slice(0);
     constexpr int ITERS = KS * KS * 2;
-    constexpr int RING = (ITERS % 6 == 0) ? 6 : 2;
+    constexpr int RING = (ITERS % 6 == 0) ? FD_CONV_RING : 2;
     const int total_iters = nslices * ITERS;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16x8 *>(wp), 0, (int)p.w_bytes, 0x00020000);
     const unsigned lane16 = lane * 16;
@@ -635,10 +711,31 @@ int dispatch_strip(const void *x, const void *wp, const float *bias, void *y, co
 template <int KS, int S>
 int dispatch_nt(const void *x, const void *wp, const float *bias, void *y, const ConvParams &p, hipStream_t stream) {
     const int force = fd::tuning(fd::kTuneConvNT);  // tuning override
+    if constexpr (S == 1) {
+        // the mixed tiling where it has fewer tiles than the ragged grid ("conv_strip" = -1: never -- A/B runs and the identity test)
+        if (p.tiles_img < p.tiles_x * p.tiles_y && fd::tuning(fd::kTuneConvStrip) >= 0) {
+            if (p.Cout_pad % 128 == 0 && force != 64 && force != 32) launch_conv<KS, S, 2, 2, 2, 2, true>(x, wp, bias, y, p, stream);
+            else if (p.Cout_pad % 64 == 0 && force != 32) launch_conv<KS, S, 1, 2, 4, 1, true>(x, wp, bias, y, p, stream);
+            else launch_conv<KS, S, 1, 1, 4, 1, true>(x, wp, bias, y, p, stream);
+            return 1;
+        }
+    }
     if (p.Cout_pad % 128 == 0 && force != 64 && force != 32) launch_conv<KS, S, 2, 2, 2, 2>(x, wp, bias, y, p, stream);
     else if (p.Cout_pad % 64 == 0 && force != 32) launch_conv<KS, S, 1, 2, 4, 1>(x, wp, bias, y, p, stream);
     else launch_conv<KS, S, 1, 1, 4, 1>(x, wp, bias, y, p, stream);
     return 1;
+}
+
+// the mixed tiling of an Ho x Wo map (ConvParams::fh ...): whole 8 x 16 tiles, the columns right of them, the rows below
+void mixed_tiles(ConvParams &p) {
+    p.fh = p.Ho / TH; p.fw = p.Wo / TW;
+    p.rw = p.Wo - p.fw * TW;
+    p.bh = p.Ho - p.fh * TH;
+    p.th_r = p.rw > 0 ? std::min(32, (TH * TW) / p.rw) : 1;
+    p.n_right = (p.rw > 0 && p.fh > 0) ? (p.fh * TH + p.th_r - 1) / p.th_r : 0;
+    p.tw_b = p.bh > 0 ? std::min(32, (TH * TW) / p.bh) : 1;
+    p.n_bottom = p.bh > 0 ? (p.Wo + p.tw_b - 1) / p.tw_b : 0;
+    p.tiles_img = p.fh * p.fw + p.n_right + p.n_bottom;
 }
 
 }  // namespace
@@ -703,6 +800,7 @@ extern "C" int fd_conv2d_nhwc_bf16(const void *x, int B, int H, int W, int cin, 
     }
     p.tiles_x = (p.Wo + TW - 1) / TW;
     p.tiles_y = (p.Ho + TH - 1) / TH;
+    mixed_tiles(p);
     hipStream_t s = fd::as_stream(stream);
     if (ks == 3 && stride == 1) {
         if (!dispatch_strip<3>(x, wpacked, bias, y, p, s)) dispatch_nt<3, 1>(x, wpacked, bias, y, p, s);

@@ -665,7 +665,9 @@ STRIP_CASES = [(3, 64, 128, 1, 180, 180), (3, 128, 64, 2, 90, 90), (3, 32, 32, 1
 def test_conv2d_bf16_strip_kernel_matches_tile_kernel_and_torch(hip, cfg):
     """Stride-1 bf16 layers on images at least 64 pixels wide can run on strips of 128 consecutive pixels (one workgroup per compute
     unit at 180 x 180 instead of 276 tiles for 256 units; opt-in, conv_strip = 1: faster alone, slower with sweeps in flight).  Same
-    summation order as the 8 x 16-tile kernel: the two must agree BIT FOR BIT (conv_strip <= 0 selects the tile kernel) for every channel block width, on shapes whose strips touch one, two
+    summation order as the 8 x 16-tile kernel: the two must agree BIT FOR BIT (conv_strip = 0, the default, selects the tile kernel on its
+    MIXED tiling -- whole 8 x 16 tiles, then tiles of other shapes for the columns right of them and the rows below: 254 workgroups
+    instead of 276 at 180 x 180 -- and -1 the ragged 8 x 16 grid; all three are compared) for every channel block width, on shapes whose strips touch one, two
     and three image rows, end in a partial strip, cross no image boundary in a batch, with a channel-offset output window and
     the pixel-shuffle placement of the 2 x 2 transposed convolution; and both match torch on the bf16-rounded operands."""
     ks, cin, cout, B, H, W = cfg
@@ -678,7 +680,7 @@ def test_conv2d_bf16_strip_kernel_matches_tile_kernel_and_torch(hip, cfg):
     xn = x.cuda().permute(0, 2, 3, 1).contiguous()
     outs = {}
     try:
-        for strip in (1, -1):
+        for strip in (1, 0, -1):  # strips / the default (mixed tiling: whole 8 x 16 tiles + edge tiles of other shapes) / ragged 8 x 16 tiles only
             hip.set_tuning("conv_strip", strip)
             for nt in (0, 64, 32):
                 hip.set_tuning("conv_nt", nt)

@@ -37,6 +37,10 @@ for (cin, cout, hw) in ((128, 128, 180), (256, 128, 180), (256, 256, 90), (512, 
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
     ns = cin // 32
+    # o[7] = s_memrealtime at the workgroup's start (100 MHz, device-wide): who starts late = who had to wait for a slot
+    rt = (t[:, 7] - t[:, 7].min()) * 0.01  # us
     span = 0.0
+    print("   workgroup start times (us after the first): median %.2f, p75 %.2f, p90 %.2f, p95 %.2f, max %.2f; started after 2 us: %d of %d" % (
+        np.median(rt), np.percentile(rt, 75), np.percentile(rt, 90), np.percentile(rt, 95), rt.max(), int((rt > 2.0).sum()), len(rt)))
     print("B=%d " % NB + "%d->%d @%d: %.1f us back to back, %d workgroups, %d slices; span %.0f cycles (%.2f GHz); life mean %.0f max %.0f; prologue %.0f; per slice: steps %.0f (MFMA %d), hand-over %.0f, barrier %.0f; epilogue %.0f (of it transpose into LDS + barrier %.0f)" % (cin, cout, hw, us, len(t), ns, span, span / us / 1e3, t[:, 5].mean(), t[:, 5].max(), t[:, 0].mean(), t[:, 1].mean() / ns, 18 * 4 * 32,
                                                    t[:, 2].mean() / ns, t[:, 3].mean() / ns, t[:, 4].mean(), t[:, 6].mean()), flush=True)
