@@ -1,9 +1,10 @@
 #!/bin/bash
-# Tuning build: the product sources with -DFD_V2_TRACE (phase timeline of the fp32 sparse conv) -> tools/probes/libfd_trace.so
-# Use with FD_LIB_PATH=tools/probes/libfd_trace.so python tools/spconv_trace.py
+# Tuning build: ALL product sources with -DFD_V2_TRACE (phase timelines of the fp32 sparse conv, the Winograd and the bf16 dense kernels)
+# -> tools/probes/libfd_trace.so.  Use with FD_LIB_PATH=tools/probes/libfd_trace.so python tools/spconv_trace.py
+# (one source only: tools/probes/build_exp.sh <src> <tag> -DFD_V2_TRACE)
 set -e
 cd "$(dirname "$0")/../.."
-srcs="fd_error fd_voxelize fd_index fd_spconv fd_spconv_v2 fd_spconv_c32 fd_spconv_bf16 fd_densify fd_conv2d fd_conv2d_f32 fd_conv2d_wino fd_conv2d_wino_pc fd_decode fd_sweeps fd_pillars fd_forecast"
+srcs=$(python -c "import sys; sys.path.insert(0, 'futuredet_amd'); import build; print(' '.join(s[:-4] for s in build.SOURCES))")
 objs=""
 mkdir -p tools/probes/_obj
 for s in $srcs; do
