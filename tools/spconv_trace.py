@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--levels", default="0,1,2,3")
 ap.add_argument("--mode", default="balanced")
 ap.add_argument("--rpc", type=int, default=0)
+ap.add_argument("--down", action="store_true", help="the strided convolution leaving each level (16 -> 32, 32 -> 64, 64 -> 128) instead of its SubM layers")
 args = ap.parse_args()
 L = lib.load()
 L.fd_debug_set_trace.restype = ctypes.c_int
@@ -36,14 +37,23 @@ for lvl in [int(v) for v in args.levels.split(",")]:
     C = [16, 32, 64, 128][lvl]
     ix = idx[lvl]
     x = torch.randn((ix.n, C), device=dev)
-    wpk = hip_ops.pack_spconv_weight(torch.randn((27, C, C)) * 0.05).to(dev)
-    nbr = ix.rulebook(ix, [3, 3, 3], [1, 1, 1], [1, 1, 1])
+    if args.down:
+        if lvl > 2:
+            continue
+        ox, CO = idx[lvl + 1], 2 * C
+        wpk = hip_ops.pack_spconv_weight(torch.randn((27, C, CO)) * 0.05).to(dev)
+        nbr = ix.rulebook(ox, [3, 3, 3], [2, 2, 2], [1, 1, 1] if lvl < 2 else [0, 1, 1])
+        run = lambda: hip_ops.spconv_apply(x, wpk, None, nbr, ox.n, CO, relu=True, balanced=MODE[args.mode])  # noqa: E731
+    else:
+        wpk = hip_ops.pack_spconv_weight(torch.randn((27, C, C)) * 0.05).to(dev)
+        nbr = ix.rulebook(ix, [3, 3, 3], [1, 1, 1], [1, 1, 1])
+        run = lambda: hip_ops.spconv_apply(x, wpk, None, nbr, ix.n, C, residual=x, relu=True, balanced=MODE[args.mode])  # noqa: E731
     trace = torch.zeros((4096 * 16,), dtype=torch.int64, device=dev)
     for _ in range(3):
-        hip_ops.spconv_apply(x, wpk, None, nbr, ix.n, C, residual=x, relu=True, balanced=MODE[args.mode])
+        run()
     torch.cuda.synchronize()
     assert L.fd_debug_set_trace(trace.data_ptr()) == 0
-    hip_ops.spconv_apply(x, wpk, None, nbr, ix.n, C, residual=x, relu=True, balanced=MODE[args.mode])
+    run()
     torch.cuda.synchronize()
     L.fd_debug_set_trace(None)
     t = trace.cpu().numpy().reshape(-1, 16)
