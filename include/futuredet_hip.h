@@ -39,7 +39,8 @@ const char *fd_last_error(void);
  * kernels), "bf16_win" (-1: the 64 -> 64 / 128 -> 128 bf16 layers on the RING / RESIDENT kernels instead of the LDS-window
  * kernel of round 5), "f32_res_rg" (-1: 16-channel fp32 layers on the
  * pair-compacting kernel instead of the resident-weights one), "conv_strip" (1: stride-1 bf16 dense layers on strips of 128
- * consecutive pixels instead of 8 x 16 tiles: faster alone, slower with several sweeps in flight; results identical).  Initial
+ * consecutive pixels instead of 8 x 16 tiles: faster alone, slower with several sweeps in flight; -1: the ragged grid of 8 x 16
+ * tiles instead of the default mixed tiling -- whole 8 x 16 tiles plus edge tiles of other shapes; results identical in all three).  Initial
  * values come from the FD_SPCONV_RG, FD_SPCONV_V1, ... environment variables (FD_ + the upper-case name), read once when the
  * library is loaded; nothing on the launch path calls getenv(). */
 int fd_tuning_set(const char *name, int value);
