@@ -23,14 +23,16 @@ reference's eval loop does), per step in the strong-scaling mode.
 Rank 0 prints ONE JSON line.  Every number in it is either measured in this run or carries its provenance:
   value              sweeps/s, clouds resident in HBM when the clock starts -> detections on the host (the bench contract's
                      definition of `value`): the MEDIAN of --reps (5) repetitions of the K-step timed region, each with its own
-                     barrier + synchronize + clock; `repetitions` carries min / median / max and every repetition's ms_per_step
+                     barrier + synchronize + clock; `repetitions` carries min / median / max and every repetition's ms_per_step.
+                     The LAST (R - 1) // 2 repetitions carry the instrumented step of the roofline measurement (an eager pass run
+                     alone: 1.6 % of a 20-step fp32 region, 5.3 % of a bf16 one), so the median repetition is one without it
   value_host_to_host the same K steps with every cloud starting in pinned host memory (H2D inside the timed region):
                      SURVEY 8(d)'s "points on host -> boxes on host"
   latency_ms_inflight1  a third leg with ONE pass in flight: a sweep's latency
   roofline           dominant kernel = sparse conv apply, timed with HIP events on the launch stream in this run.  `bound` says
                      what binds (fp32: the matrix pipe; bf16: the L1 gather path, reported in the contract's algorithmic-byte
                      accounting); `hbm_algorithmic` and `mfma` carry both views.  traffic / mfma.busy_pmc / dense are PMC
-                     figures looked up from profiles/round3_pmc.json for THIS workload and only when the kernel sources are
+                     figures looked up from profiles/round5_pmc.json for THIS workload and only when the kernel sources are
                      the ones they were measured on (else null with the reason in *_source); hbm_copy_measured_gbs is a 512-MB
                      device copy timed in this run (next to the 8 TB/s spec figure the fractions use)
   cpu_baseline       the CPU oracle on ALL logical CPUs of the box (value_all_cores: up to 20 passes after 3 warm-ups, ~40 s) and on 64 threads
@@ -470,12 +472,21 @@ def measure(args, env):
     # last step costs the run only its own un-overlapped time, whatever K the caller asks for
     prof_steps = {si for si in range(args.steps) if (args.steps - 1 - si) % PROF_EVERY == 0}
 
+    # Repetitions whose timed region carries the instrumented step(s): the LAST (R - 1) // 2 of the R repetitions (R = 5: two, R = 3:
+    # one; a single repetition: that one).  An instrumented step costs its region the difference between an eager pass run alone and
+    # the period of the pipelined graph replays -- 1.6 % of a 20-step fp32 region, 5.3 % of a bf16 one, where the eager pass is
+    # host-bound (measured with the driver's command, round 5) -- so `value`, the MEDIAN repetition, is one without it; the
+    # instrumented repetitions are listed with the others in repetitions.ms_per_step_each (they are the last ones).
+    n_reps = max(1, args.reps)
+    n_instr_reps = max(1, (n_reps - 1) // 2)
+    cur_rep = [0]
+
     def set_prof(si):
         # The per-launch HIP events of the roofline measurement are taken on the last step of the timed region (and every PROF_EVERY-th before it).
         # Such a step runs ALONE (the passes in flight are retired first, the next one starts after it): with two sweeps
         # sharing the GPU a launch's elapsed time contains the other sweep's kernels, which is not the kernel's duration.
-        # The drain and the event pairs (~5 us of queue time per launch) are charged to the headline number.
-        prof.enabled = si in prof_steps
+        # The drain and the event pairs (~5 us of queue time per launch) are charged to that repetition's time.
+        prof.enabled = si in prof_steps and cur_rep[0] >= n_reps - n_instr_reps
         return prof.enabled and len(streams) > 1
 
     with torch.no_grad():
@@ -506,10 +517,22 @@ def measure(args, env):
         prof.enabled = False
         del prof.records[:]
         del stage_events[:]
+        # ... and once more, warm: this pass's launch times are kept as an UNTIMED extra sample (used only when the timed regions hold
+        # fewer than three instrumented steps: the figures come from the median step, which one descheduled host thread cannot move)
+        prof.enabled = True
+        with torch.cuda.stream(streams[0]):
+            prof.begin(schedule(0)[0])
+            forward([resident[s] for s in seeds[schedule(0)[0]]])
+        torch.cuda.synchronize()
+        prof.enabled = False
+        rehearsal_records = list(prof.records)
+        del prof.records[:]
+        del stage_events[:]
         # R repetitions of the K-step region, each bracketed by barrier + synchronize and its own clock; every repetition is the same
         # program (incl. its instrumented last step).  `value` is the MEDIAN repetition.
         rep_dt = []
-        for rep in range(max(1, args.reps)):
+        for rep in range(n_reps):
+            cur_rep[0] = rep
             sync_all()
             t0 = time.perf_counter()
             kept = []
@@ -603,6 +626,9 @@ def measure(args, env):
         # ---- roofline of the dominant kernel (sparse conv apply), from the events recorded in the timed region
         torch.cuda.synchronize()
         with torch.no_grad():
+            n_timed_steps = sum(1 for r in prof.records if r[5] == 0)
+            if n_timed_steps < 3:  # (the untimed warm rehearsal as an extra sample; the list below marks it)
+                prof.records.extend(rehearsal_records)
             ms = [(tag, info, e0.elapsed_time(e1)) for tag, info, e0, e1, _, _ in prof.records]
             # pair counts of those launches: one untimed pass per distinct micro-batch (consecutive steps ran different clouds)
             prof.mode, prof.enabled = "count", True
@@ -611,7 +637,7 @@ def measure(args, env):
                 forward([resident[s] for s in seeds[mb]])
             prof.enabled = False
             pairs = [prof.pairs[(key, i)] for _, _, _, _, key, i in prof.records]
-        n_prof = len(prof_steps) * max(1, args.reps)  # instrumented steps (the last step of every repetition, and every PROF_EVERY-th before it)
+        n_prof = len(prof_steps) * n_instr_reps  # instrumented steps of the timed regions (the last step of the last n_instr_reps repetitions, and every PROF_EVERY-th before it)
         # The figures below come from the MEDIAN instrumented step (by its summed launch time), not from the mean over all of them:
         # an event pair also spans whatever the host did between recording the first event and enqueueing the kernel, so one step
         # in which the launching thread was descheduled inflates every launch of that step (seen once: 176 us per launch on a box
@@ -696,7 +722,9 @@ def measure(args, env):
             "dense": dense, "dense_source": pmc_src,
             "pair_gflop_per_step": round(tot_flops / n_prof_used / 1e9, 2),
             "spconv_ms_per_step": round(tot_ms / n_prof_used, 3), "instrumented_steps": n_prof,
-            "spconv_ms_each_instrumented_step": [round(v, 3) for v in step_ms[:16]]})
+            "instrumented_repetitions": "the last %d of %d (value = the median repetition: one without the instrumented step)" % (n_instr_reps, n_reps),
+            "spconv_ms_each_instrumented_step": [round(v, 3) for v in step_ms[:16]],
+            "spconv_ms_untimed_rehearsal_included": bool(n_timed_steps < 3)})
         if args.stage_times:
             st = {}
             for (n0, e0), (n1, e1) in zip(stage_events[:-1], stage_events[1:]):
