@@ -658,7 +658,9 @@ def test_conv2d_nhwc_bf16_vs_torch(hip, cfg):
 
 
 STRIP_CASES = [(3, 64, 128, 1, 180, 180), (3, 128, 64, 2, 90, 90), (3, 32, 32, 1, 66, 64), (3, 96, 11, 2, 5, 127), (3, 64, 256, 1, 17, 129),
-               (1, 128, 256, 2, 23, 70), (1, 64, 40, 1, 9, 300), (3, 32, 128, 1, 1, 128), (3, 64, 64, 3, 2, 65), (3, 32, 70, 1, 40, 270)]
+               (1, 128, 256, 2, 23, 70), (1, 64, 40, 1, 9, 300), (3, 32, 128, 1, 1, 128), (3, 64, 64, 3, 2, 65), (3, 32, 70, 1, 40, 270),
+               # narrower than a strip (tile kernels only): maps smaller than one 8 x 16 tile in either direction, exact multiples, one-pixel edges
+               (3, 32, 32, 1, 40, 9), (3, 32, 64, 2, 3, 5), (1, 64, 64, 1, 16, 32), (3, 32, 128, 1, 15, 31), (3, 64, 32, 1, 33, 47), (3, 32, 32, 1, 9, 17)]
 
 
 @pytest.mark.parametrize("cfg", STRIP_CASES, ids=lambda c: "k%d_%d-%d_b%d_%dx%d" % c)
