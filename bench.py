@@ -68,7 +68,7 @@ PRESETS = {  # BASELINE.json configs[1..4]
     2: dict(variant="forecast_n0", dtype="fp32", points=300000, batch=2),
     3: dict(variant="forecast_n3", dtype="bf16", points=300000, batch=2),
     4: dict(variant="forecast_n3", dtype="bf16", points=300000, batch=8, global_batch=64),
-    5: dict(variant="forecast_n3", dtype="bf16", points=500000, batch=1, class_name="pedestrian", voxel_xy=0.05, max_voxels=400000),
+    5: dict(variant="forecast_n3", dtype="bf16", points=500000, batch=2, class_name="pedestrian", voxel_xy=0.05, max_voxels=400000),
 }
 
 
