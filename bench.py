@@ -16,7 +16,7 @@ partial rounds of workgroups, single-workgroup kernels).  Every step still runs 
 ms_per_step is the throughput figure (time / steps), a single sweep's latency is that of --inflight 1.
 Samples are independent, so ranks shard them with no data-path collective: by default every rank processes --batch
 clouds per step (weak scaling); ``--config 4`` is BASELINE configs[3], a global batch of 64 clouds (seeds 0..63) split
-rank-strided like DistributedSampler(shuffle=False) and run in micro-batches of 8 (strong scaling).  Detections reach
+rank-strided like DistributedSampler(shuffle=False) and run in micro-batches of 4 (strong scaling).  Detections reach
 all ranks through one fixed-shape all_gather inside the timed region: after the last step in the weak-scaling mode (as the
 reference's eval loop does), per step in the strong-scaling mode.
 
@@ -67,7 +67,7 @@ MFMA_PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}
 PRESETS = {  # BASELINE.json configs[1..4]
     2: dict(variant="forecast_n0", dtype="fp32", points=300000, batch=2),
     3: dict(variant="forecast_n3", dtype="bf16", points=300000, batch=2),
-    4: dict(variant="forecast_n3", dtype="bf16", points=300000, batch=8, global_batch=64),
+    4: dict(variant="forecast_n3", dtype="bf16", points=300000, batch=4, global_batch=64),
     5: dict(variant="forecast_n3", dtype="bf16", points=500000, batch=2, class_name="pedestrian", voxel_xy=0.05, max_voxels=400000),
 }
 

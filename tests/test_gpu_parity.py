@@ -2283,7 +2283,7 @@ def test_eight_ranks_on_one_gpu_weak_scaling(hip, tmp_path):
 
 def test_eight_ranks_on_one_gpu_config4_strong_scaling(hip, tmp_path):
     """BASELINE configs[3] in the shape the driver would launch it (`--config 4 --gpus 8`: forecast_n3 bf16, global batch 64 = seeds
-    0..63 split rank-strided, micro-batches of 8 per rank, per-step gather), with smaller clouds so that eight processes share one
+    0..63 split rank-strided, micro-batches of 4 per rank, per-step gather), with smaller clouds so that eight processes share one
     GPU: the 64 gathered samples come back in global order and equal a single-process bf16 run of the same seeds."""
     from futuredet_amd import dist_infer
     from futuredet_amd.synth import synthetic_cloud
