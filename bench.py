@@ -51,6 +51,9 @@ import time
 # (round 5, first run).  Passive waiting must be chosen before either runtime is loaded.
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 os.environ.setdefault("GOMP_SPINCOUNT", "0")
+# RCCL (and any device-tensor sharing) across processes needs dmabuf IPC on this host driver.  Set here, before torch / the HIP runtime
+# load, so that ranks started by ANY launcher (torchrun, the driver's torch.distributed.run, self_launch) have it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -568,9 +571,11 @@ def measure(args, env):
             sync_all()
             dt_host = time.perf_counter() - t1
 
-        # ---- third leg: one pass in flight (strictly serial sweeps): a sweep's latency, cloud resident in HBM -> detections on the host
-        dt_lat, n_lat = None, 0
-        if len(streams) > 1 and not args.no_host_leg:
+        # ---- third leg: one pass in flight (strictly serial sweeps): a pass's latency, clouds resident in HBM -> detections on the host;
+        #      and the same with every cloud starting in pinned host memory -- with one cloud per pass that is the figure the reference's
+        #      eval loop prints ("Total time per frame", tools/dist_test.py:204-217,240: a serial loop at samples_per_gpu = 1)
+        dt_lat, dt_lat_h2h, n_lat = None, None, 0
+        if not args.no_host_leg:
             spare = streams[1:]
             del streams[1:]
             n_lat = max(1, min(args.steps, 30))
@@ -580,11 +585,26 @@ def measure(args, env):
             run_steps(0, n_lat)
             sync_all()
             dt_lat = time.perf_counter() - t2
+            run_steps(0, 2, from_host)
+            sync_all()
+            t3 = time.perf_counter()
+            run_steps(0, n_lat, from_host)
+            sync_all()
+            dt_lat_h2h = time.perf_counter() - t3
             streams.extend(spare)
 
     t = torch.tensor(rep_dt + [dt_host if dt_host is not None else 0.0], dtype=torch.float64, device="cpu" if one_dev else dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)  # per repetition: the slowest rank's time
+    own_ms = 1e3 * float(np.median(rep_dt)) / args.steps   # this rank's own clock (before the MAX over ranks)
+    rank_ms = None
+    if world > 1:
+        # every rank's OWN median ms per step, gathered after the clock: a sub-linear scaling point can then be attributed to a rank
+        # (a slow GPU, a rank on the far socket) instead of guessed
+        mine_t = torch.tensor([own_ms], dtype=torch.float64, device="cpu" if one_dev else dev)
+        all_t = [torch.empty_like(mine_t) for _ in range(world)]
+        torch.distributed.all_gather(all_t, mine_t)
+        rank_ms = [round(float(v), 4) for v in all_t]
     rep_dt, dt_host = [float(v) for v in t[:-1]], (float(t[-1]) if dt_host is not None else None)
     dt = float(np.median(rep_dt))
 
@@ -605,6 +625,10 @@ def measure(args, env):
                                 "repetition); value = the median repetition" % (len(rep_dt), args.steps)},
         "value_host_to_host": round(sweeps / dt_host, 3) if dt_host else None,
         "latency_ms_inflight1": round(1e3 * dt_lat / (n_lat * len(schedule(0))), 4) if dt_lat else None,
+        "latency_ms_inflight1_host_to_host": round(1e3 * dt_lat_h2h / (n_lat * len(schedule(0))), 4) if dt_lat_h2h else None,
+        "latency_is": "per forward pass of %d cloud(s) with ONE pass in flight (strictly serial passes): clouds resident in HBM -> detections on the host; "
+                      "_host_to_host: clouds start in pinned host memory (H2D inside the clock)" % B,
+        "rank_ms_per_step": rank_ms,
         "config": {"workload": ("%s %ss, %d-pt synthetic 10-sweep clouds" + (" (street profile)" if args.scene == "street" else "") +
                                 ", %s, %s+RPN+CenterHead, %s; timed region = clouds resident in HBM -> "
                                 "detections on the host (value_host_to_host: clouds start in pinned host memory)")
@@ -679,9 +703,11 @@ def measure(args, env):
             pmc_src = "no PMC profile (%r)" % (e,)
         avg_us = 1e3 * tot_ms / max(launches, 1)
         peak_t = MFMA_PEAK_TFLOPS[args.dtype]
-        hbm = {"achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+        over = ach > HBM_PEAK_GBS  # the gathers of these launches are served from LDS / L2 / MALL: algorithmic bytes can exceed what HBM could move
+        hbm = {"achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if over else round(ach / HBM_PEAK_GBS, 4),
                "what": "ALGORITHMIC gather/scatter bytes B_gs (SURVEY 8d) / launch time: the contract's `achieved` for an HBM-bound path; not physical "
-                       "HBM bytes (see traffic)"}
+                       "HBM bytes (see traffic)" + ("; above the HBM peak because the gathered rows come from LDS windows and the caches, so no "
+                                                    "fraction of an HBM roofline is stated for it" if over else "")}
         mf = {"achieved": round(tfl, 2), "peak": peak_t, "unit": "TFLOP/s", "frac": round(tfl / peak_t, 4),
               "what": "2*pairs*Cin*Cout of the same launches / their time vs the dense %s MFMA peak" % args.dtype}
         if args.dtype == "fp32":  # fp32 MFMA runs at the vector rate: the matrix pipe is what binds these launches
@@ -789,38 +815,71 @@ def main():
     cpus = dist_infer.pin_rank_cpus(local if not one_dev else rank, world)  # 256 logical CPUs / 8 ranks = 32 per rank
     env = dict(rank=rank, world=world, dev=dev, one_dev=one_dev, cpus=cpus)
     out = measure(args, env)
-    # The default run (BASELINE configs[1], fp32, one GPU) also measures BASELINE configs[2] -- forecast_n3, bf16 conv features, the
-    # same clouds -- in this process, after the headline's legs, and attaches it under "also": three of the five BASELINE
-    # configurations are bf16 and would otherwise never be seen by the driver's run.  value / dtype / config stay the fp32 headline's.
+    # The default run (BASELINE configs[1], fp32, one GPU) also measures, in this process and with the same program (set-up, warm-up,
+    # repetitions of the K-step timed region, host leg, one-in-flight latency legs, per-launch HIP events), the shapes the driver's one
+    # command would otherwise never see, and attaches them under "also" (value / dtype / config stay the fp32 headline's):
+    #   batch1          the headline workload with ONE cloud per pass, four passes in flight -- the shape of the round 1-4 series and of
+    #                   the reference's eval loop (samples_per_gpu = 1); top-level value_batch1 / latency_ms_sweep are taken from it
+    #   config3         BASELINE configs[2]: forecast_n3, bf16 conv features, the same clouds (+ config3_batch1: its one-cloud shape)
+    #   config4_rank    BASELINE configs[3] as ONE rank of the 8 sees it: forecast_n3 bf16, its share (8 clouds) of the global batch of 64
+    #                   per step, micro-batches of 4
+    #   config5         BASELINE configs[4] on one GPU: pedestrian forecast_n3 bf16, 500k-point clouds, 0.05 m grid
+    #   street_fp32 / street_bf16   the motion-compensated street profile (~60k voxels per 300k points, a few dozen detections)
     is_default = (world == 1 and args.dtype == "fp32" and args.variant == "forecast_n0" and args.points == 300000 and args.batch == 2 and
                   args.global_batch == 0 and args.scene == "dense" and args.class_name == "car" and not args.no_also)
     if is_default and out is not None:
         import copy
         import gc
 
-        gc.collect()
-        torch.cuda.empty_cache()
-        t_also = time.perf_counter()
-        try:
-            a3 = copy.copy(args)
-            for k, v in PRESETS[3].items():
-                setattr(a3, k, v)
-            a3.no_cpu_baseline, a3.reps, a3.dump, a3.stage_times = True, min(args.reps, 3), "", False
-            o3 = measure(a3, env)
-            r3 = o3.get("roofline") or {}
-            out["also"] = {"config3": {
-                "workload": o3["config"]["workload"], "dtype": o3["dtype"], "value": o3["value"], "unit": o3["unit"], "ms_per_step": o3["ms_per_step"],
-                "steps": o3["steps"], "warmup": o3["warmup"], "value_host_to_host": o3["value_host_to_host"],
-                "latency_ms_inflight1": o3["latency_ms_inflight1"], "repetitions": o3["repetitions"],
-                "roofline": {k: r3.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step", "spconv_ms_per_step",
-                                                    "traffic", "traffic_source")},
-                "hbm_algorithmic": r3.get("hbm_algorithmic"), "detections_last_step": o3["config"]["detections_last_step"],
-                "what": "BASELINE configs[2] (forecast_n3, bf16 conv features, fp32 accumulate; the same 317k-point clouds) measured by this process right "
-                        "after the fp32 headline's legs with the same program (set-up, %d warm-up steps, %d repetitions of the %d-step timed region, "
-                        "host leg, one-in-flight latency leg, per-launch HIP events); parity of this configuration: tests/test_gpu_parity.py "
-                        "(teacher-forced layers within one bf16 ulp); %.0f s of wall time" % (a3.warmup, a3.reps, a3.steps, time.perf_counter() - t_also)}}
-        except Exception as e:  # extra context, never a reason to lose the headline
-            out["also"] = {"config3": {"value": None, "failed": repr(e)}}
+        extras = [
+            ("batch1", dict(batch=1), "BASELINE configs[1] with one cloud per forward pass (the reference's samples_per_gpu = 1)"),
+            ("config3", dict(PRESETS[3]), "BASELINE configs[2]: forecast_n3, bf16 conv features, fp32 accumulate; the same 317k-point clouds"),
+            ("config3_batch1", dict(PRESETS[3], batch=1), "BASELINE configs[2] with one cloud per forward pass"),
+            ("config4_rank", dict(PRESETS[4], global_batch=8), "BASELINE configs[3] as one of its 8 ranks runs it: 8 of the 64 clouds per step, micro-batches of 4 (strong-scaling "
+                                                              "mode, one rank here)"),
+            ("config5", dict(PRESETS[5]), "BASELINE configs[4] on ONE GPU: pedestrian forecast_n3, bf16, 500k-point clouds, 0.05 m x/y voxels, max_voxels 400k"),
+            ("street_fp32", dict(scene="street"), "the headline workload on the street scene profile (fp32)"),
+            ("street_bf16", dict(PRESETS[3], scene="street"), "BASELINE configs[2] on the street scene profile (bf16)"),
+        ]
+        only = os.environ.get("FD_BENCH_ALSO")  # comma-separated subset (tools / tests); unset = all of them
+        if only is not None:
+            extras = [e for e in extras if e[0] in only.split(",")]
+        out["also"] = {}
+        for name, over, what in extras:
+            gc.collect()
+            torch.cuda.empty_cache()
+            t_also = time.perf_counter()
+            try:
+                ax = copy.copy(args)
+                for k, v in over.items():
+                    setattr(ax, k, v)
+                ax.no_cpu_baseline, ax.reps, ax.dump, ax.stage_times = True, min(args.reps, 3), "", False
+                ox = measure(ax, env)
+                rx = ox.get("roofline") or {}
+                out["also"][name] = {
+                    "workload": ox["config"]["workload"], "dtype": ox["dtype"], "value": ox["value"], "unit": ox["unit"], "ms_per_step": ox["ms_per_step"],
+                    "scaling": ox["scaling"], "steps": ox["steps"], "warmup": ox["warmup"], "value_host_to_host": ox["value_host_to_host"],
+                    "latency_ms_inflight1": ox["latency_ms_inflight1"], "latency_ms_inflight1_host_to_host": ox["latency_ms_inflight1_host_to_host"],
+                    "latency_is": ox["latency_is"], "repetitions": ox["repetitions"],
+                    "roofline": {k: rx.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step", "spconv_ms_per_step",
+                                                        "traffic", "traffic_source")},
+                    "hbm_algorithmic": rx.get("hbm_algorithmic"), "detections_last_step": ox["config"]["detections_last_step"],
+                    "graph_overflows": ox["config"]["graph_overflows"],
+                    "what": "%s; measured by this process after the headline's legs with the same program (%d warm-up steps, %d repetitions of the %d-step "
+                            "timed region, host leg, one-in-flight latency legs, per-launch HIP events); %.0f s of wall time"
+                            % (what, ax.warmup, ax.reps, ax.steps, time.perf_counter() - t_also)}
+            except Exception as e:  # extra context, never a reason to lose the headline
+                out["also"][name] = {"value": None, "failed": repr(e)}
+        b1 = out["also"].get("batch1") or {}
+        # like for like with rounds 1-4 and with the reference's own speed figure
+        out["value_batch1"] = b1.get("value")
+        out["value_batch1_is"] = "sweeps/s with ONE cloud per forward pass and %d passes in flight (also.batch1): the shape `value` had in rounds 1-4" % max(1, args.inflight)
+        out["latency_ms_sweep"] = b1.get("latency_ms_inflight1_host_to_host")
+        out["latency_ms_sweep_is"] = ("one cloud, one pass in flight, pinned host memory -> detections on the host (also.batch1): what the reference's serial "
+                                      "eval loop prints as 'Total time per frame' (tools/dist_test.py:204-217,240)")
+        c3, c31 = out["also"].get("config3") or {}, out["also"].get("config3_batch1") or {}
+        if c3.get("value") is not None:
+            c3["value_batch1"], c3["latency_ms_sweep"] = c31.get("value"), c31.get("latency_ms_inflight1_host_to_host")
     if rank == 0 and out is not None:
         print(json.dumps(out))
     if world > 1:

@@ -1001,6 +1001,12 @@ int decode_impl(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view
     FD_REQUIRE(G > 0 && cfg->H > 0 && cfg->W > 0, "fd_centerpoint_decode: bad shape");
     FD_REQUIRE(cfg->nms_pre_max >= 1 && cfg->nms_pre_max <= kMaxPre, "fd_centerpoint_decode: nms_pre_max must be in [1,%d]", kMaxPre);
     FD_REQUIRE(cfg->nms_post_max >= 1 && cfg->nms_post_max <= 128, "fd_centerpoint_decode: nms_post_max must be in [1,128]");
+    // key 0 means "no candidate" and make_key_bins() starts the bins at the threshold's bit pattern: with a negative threshold a score
+    // that underflowed to exactly 0.0f would be dropped although `score > threshold` keeps it (center_head.py:666).  Not representable -> refused.
+    FD_REQUIRE(cfg->score_threshold >= 0.f, "fd_centerpoint_decode: score_threshold must be >= 0 (got %g)", (double)cfg->score_threshold);
+    // the in-register selection (dec_select_hist) rests on three limits; the dispatch condition below (HW <= 32 * kSelThreads) implies all of them
+    static_assert(32 * kSelThreads == 8 * 4096, "dec_select_hist walks a group's keys in 8 rounds of 4096 (4 per thread)");
+    static_assert(32 * kSelThreads <= (1 << 17), "a cell index must fit the 17-bit field of the 49-bit ranking word");
     DecCfg c;
     c.H = cfg->H; c.W = cfg->W; c.HW = cfg->H * cfg->W;
     c.osf = cfg->out_size_factor; c.vx = cfg->voxel_x; c.vy = cfg->voxel_y; c.px = cfg->pc_x; c.py = cfg->pc_y;

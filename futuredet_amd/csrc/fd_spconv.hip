@@ -377,7 +377,11 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
         const void *w = cin == 16 ? (const void *)((const char *)wpacked + (size_t)K * cin * cout * 2) : wpacked;
         // 64 -> 64, 128 -> 128 (the SubM layers of levels 2 and 3): LDS window of input rows + 32-row register tiles
         // (fd_spconv_bf16win.hip); "bf16_win" = -1 keeps the RING / RESIDENT kernels (A/B runs, variant tests)
-        if (fd::tuning(fd::kTuneBf16Win) >= 0 && fd::spconv_bf16_win_weight_bytes(K, cin, cout) &&
+        // The window [row - HALO, row + TM + HALO] only holds the neighbours when input rows lie around the output rows, i.e. for a SubM
+        // convolution (27 taps over the SAME row set).  The strided 128 -> 128 extra_conv (K = 3, stride (2,1,1)) has the shape but not the
+        // property: every lane would take the exec-masked global gather next to a window staged for nothing -> RING kernel.
+        const bool subm_like = K == 27 && n_in == n_out;
+        if (fd::tuning(fd::kTuneBf16Win) >= 0 && subm_like && fd::spconv_bf16_win_weight_bytes(K, cin, cout) &&
             fd::spconv_bf16_win_dispatch(in_feats, (const char *)wpacked + (size_t)K * cin * cout * 2, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out,
                                          n_out_dev, n_expected, cin, cout, out_feats, fd::as_stream(stream)))
             return fd::check_launch("fd_spconv_apply(bf16 window)");

@@ -359,6 +359,11 @@ extern "C" int fd_voxelize(const float *points, int64_t n_points, const int32_t 
     FD_REQUIRE(max_voxels >= 0 && max_voxels < (1ll << 30), "fd_voxelize: max_voxels out of range");
     FD_REQUIRE(coor_cols == 3 || coor_cols == 4, "fd_voxelize: coor_cols must be 3 or 4");
     FD_REQUIRE(!out_mean || mean_stride >= ndim, "fd_voxelize: mean_stride < ndim");
+    // vox_emit writes 4-column coordinate rows as one int4 and, when mean rows leave through LDS (mean_stride a multiple of 4, <= 16), the
+    // mean rows as float4: a caller's sliced / offset buffer must keep the 16-byte alignment those stores assume
+    FD_REQUIRE(coor_cols != 4 || ((uintptr_t)out_coors & 15) == 0, "fd_voxelize: out_coors must be 16-byte aligned when coor_cols == 4");
+    FD_REQUIRE(!(out_mean && mean_stride <= 16 && (mean_stride & 3) == 0) || ((uintptr_t)out_mean & 15) == 0,
+               "fd_voxelize: out_mean must be 16-byte aligned when mean_stride is a multiple of 4 (<= 16)");
     hipStream_t stream = fd::as_stream(stream_);
     VoxParams p;
     int64_t cells = 1;

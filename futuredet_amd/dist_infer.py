@@ -28,15 +28,69 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def pin_rank_cpus(local_rank, local_world):
-    """Gives every rank of a node its own contiguous slice of the logical CPUs (e.g. 256 / 8 = 32 per rank) and sizes torch's
-    intra-op pool to it: the host side of a rank is one launch thread + the pinned-memory copies, and 8 ranks that each start
-    256 OpenMP / torch threads oversubscribe the box.  Returns the CPU ids (None when the platform has no affinity call)."""
+def _parse_cpulist(text):
+    """'0-31,128-159' -> [0..31, 128..159]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_node(index, sysfs="/sys"):
+    """NUMA node of GPU ``index`` from its PCI function's sysfs entry (None when unknown: no such device, the kernel reports -1, or
+    the torch build does not expose the PCI address)."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", bdf, "numa_node")).read())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def rank_cpu_slices(cpus, local_world, gpu_nodes=None, node_cpus=None):
+    """CPU ids per local rank.  With the GPUs' NUMA nodes known (``gpu_nodes[r]``) and the nodes' CPU lists (``node_cpus[n]``), the ranks
+    whose GPUs hang off one node share THAT node's allowed CPUs in equal contiguous slices (the launch thread and the pinned result buffers
+    stay next to the GPU's root complex); a rank whose node is unknown, or whose node has no allowed CPU, takes its contiguous slice of all
+    CPUs -- the rule used when nothing is known.  Pure function (tested on CPU with made-up topologies)."""
+    cpus = sorted(cpus)
+    per = max(1, len(cpus) // local_world)
+    out = [cpus[r * per:(r + 1) * per] or cpus for r in range(local_world)]
+    if not gpu_nodes or not node_cpus:
+        return out
+    allowed = set(cpus)
+    for node in sorted({n for n in gpu_nodes if n is not None}):
+        mine = [c for c in node_cpus.get(node, []) if c in allowed]
+        ranks = [r for r in range(local_world) if gpu_nodes[r] == node]
+        if not mine or len(mine) < len(ranks):
+            continue
+        k = len(mine) // len(ranks)
+        for j, r in enumerate(ranks):
+            out[r] = mine[j * k:(j + 1) * k]
+    return out
+
+
+def pin_rank_cpus(local_rank, local_world, sysfs="/sys"):
+    """Gives every rank of a node its own slice of the logical CPUs (e.g. 256 / 8 = 32 per rank), taken from the NUMA node its GPU is
+    attached to when sysfs tells (rank_cpu_slices), and sizes torch's intra-op pool to it: the host side of a rank is one launch thread +
+    the pinned-memory copies, and 8 ranks that each start 256 OpenMP / torch threads oversubscribe the box.  Returns the CPU ids (None
+    when the platform has no affinity call)."""
     if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
     cpus = sorted(os.sched_getaffinity(0))
-    per = max(1, len(cpus) // local_world)
-    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+    gpu_nodes, node_cpus = None, None
+    if torch.cuda.is_available() and torch.cuda.device_count() >= local_world:
+        gpu_nodes = [gpu_numa_node(r, sysfs) for r in range(local_world)]
+        node_cpus = {}
+        for n in {g for g in gpu_nodes if g is not None}:
+            try:
+                node_cpus[n] = _parse_cpulist(open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % n)).read())
+            except Exception:
+                pass
+    mine = rank_cpu_slices(cpus, local_world, gpu_nodes, node_cpus)[local_rank]
     os.sched_setaffinity(0, mine)
     torch.set_num_threads(max(1, min(len(mine), 8)))
     return mine

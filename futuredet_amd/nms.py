@@ -24,15 +24,20 @@ def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
 
 
 def rotate_nms_pcdet(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
-    boxes = boxes[:, [0, 1, 2, 4, 3, 5, -1]]
-    boxes[:, -1] = -boxes[:, -1] - np.pi / 2
-    order = scores.sort(0, descending=True)[1]
-    if pre_maxsize is not None:
-        order = order[:pre_maxsize]
-    boxes = boxes[order].contiguous()
-    keep = torch.zeros(boxes.size(0), dtype=torch.long)
-    num_out = 0 if len(boxes) == 0 else nms_gpu(boxes, keep, thresh)
-    selected = order[keep[:num_out].to(order.device)].contiguous()
-    if post_max_size is not None:
-        selected = selected[:post_max_size]
-    return selected
+    """Entry point of det3d/core/bbox/box_torch_ops.py:248-277 on the device NMS: ``boxes`` [N, >= 7] in the head's layout
+    (x, y, z, w, l, h, ..., yaw), ``scores`` [N]; returns the indices (into ``boxes``) of the survivors, best first, at most
+    ``post_max_size`` of them.  The candidates, their order and the keep list stay on the device; the one host read is the survivor count
+    that sizes the returned tensor.  (CenterHead.predict does not come through here: it runs fd_centerpoint_decode_packed.)"""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.long, device=boxes.device)
+    n_cand = n if pre_maxsize is None else min(n, int(pre_maxsize))
+    # best n_cand candidates, descending (the reference's full sort + cut; ties have no defined order there either)
+    rank = torch.topk(scores, n_cand, dim=0, largest=True, sorted=True).indices
+    cand = boxes.index_select(0, rank)
+    # the kernel's box layout (pcdet): (x, y, z, l, w, h, heading) with heading = -yaw - pi/2
+    footprint = torch.stack([cand[:, 0], cand[:, 1], cand[:, 2], cand[:, 4], cand[:, 3], cand[:, 5], -cand[:, -1] - np.pi / 2], dim=1)
+    kept, count = hip_ops.rotated_nms(footprint.float().contiguous(), float(thresh))
+    limit = count[0].long() if post_max_size is None else count[0].long().clamp(max=int(post_max_size))
+    survivors = rank.index_select(0, kept[:n_cand])        # fixed shape; entries past `count` are padding
+    return survivors[: int(limit)].contiguous()
