@@ -101,6 +101,12 @@ def parse():
     ap.add_argument("--scene", default="dense", choices=["dense", "street"], help="synthetic scene profile (synth.synthetic_cloud): dense = every "
                     "point its own voxel, the 160k-voxel cap is hit, all 7 x 83 detection slots taken (the headline stress case); street = "
                     "motion-compensated static scene, ~60k voxels for 300k points, heat-map head tamed to a few dozen detections")
+    ap.add_argument("--pipeline", default="plain", choices=["plain", "full", "assembled"],
+                    help="plain: the merged 10-sweep cloud resident in HBM -> detections on the host (the headline).  full: FutureDet end to end -- the ten RAW sweeps "
+                         "(sensor-frame rows) + their 4x4 transforms / time lags resident in HBM -> fd_sweep_assemble -> the same sweep -> "
+                         "fd_forecast_from_detections (global-frame boxes, chains, trajectories, forecast ids) -> detections AND trajectories on the host, "
+                         "one hipGraph replay per pass (detectors.FullSweepStep).  assembled: the plain pipeline on the clouds `full` assembles (the "
+                         "like-for-like partner of `full`)")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the K-step timed region inside one run (each with its own barriers and clock); "
                     "`value` is the MEDIAN repetition, min / max are reported next to it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -321,8 +327,36 @@ def measure(args, env):
         seeds = [[(rank * n_pool + p) * B + i for i in range(B)] for p in range(n_pool)]  # distinct seeds per rank and pool slot
         schedule = lambda si: [si % n_pool]  # noqa: E731
     uniq = sorted({s for mb in seeds for s in mb})
-    host = {s: torch.from_numpy(synthetic_cloud(seed=s, target_points=args.points, profile=args.scene)).pin_memory() for s in uniq}
-    resident = {s: host[s].to(dev) for s in uniq}      # inputs resident in HBM before the clock starts
+    pipe = args.pipeline
+    if is_pp and pipe != "plain":
+        raise SystemExit("--pipeline %s is built on the VoxelNet step" % pipe)
+    N_SWEEPS = 10
+    if pipe == "plain":
+        host = {s: torch.from_numpy(synthetic_cloud(seed=s, target_points=args.points, profile=args.scene)).pin_memory() for s in uniq}
+        resident = {s: host[s].to(dev) for s in uniq}      # inputs resident in HBM before the clock starts
+    else:
+        # the same scenes one step earlier in the reference's pipeline (loading.py:100-141): raw sensor-frame rows of the key frame and
+        # nine sweeps + per-sweep transform / time lag; per sample also the two pose records and the step times the forecast needs
+        from futuredet_amd import hip_ops
+        from futuredet_amd.synth import synthetic_sweeps
+
+        host, host_desc, resident = {}, {}, {}
+        for s in uniq:
+            raw, rows, mats, lags, close = synthetic_sweeps(seed=s, target_points=args.points, n_sweeps=N_SWEEPS, profile=args.scene)
+            desc = hip_ops.sweep_descriptors(rows, mats, lags, close)
+            rng = np.random.default_rng([s, 99])
+            q1, q2 = rng.normal(0, 1, 4), rng.normal(0, 1, 4)
+            rec = np.concatenate([q1 / np.linalg.norm(q1), rng.normal(0, 2, 3), q2 / np.linalg.norm(q2), rng.normal(0, 300, 3)])
+            raw_dev = torch.from_numpy(raw).to(dev)
+            if pipe == "assembled":   # the merged cloud, assembled outside the clock: the plain pipeline's input
+                pts, cnt = hip_ops.assemble_sweeps(raw_dev, desc)
+                resident[s] = pts[: int(cnt.cpu()[0])].contiguous()
+                host[s] = resident[s].cpu().pin_memory()
+            else:
+                host[s] = torch.from_numpy(raw).pin_memory()
+                host_desc[s] = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).pin_memory()
+                resident[s] = dict(raw=raw_dev, desc=host_desc[s].to(dev), time=torch.full((6,), 0.5, dtype=torch.float64, device=dev),
+                                   records=torch.from_numpy(rec).to(dev))
     n_pts = int(np.mean([len(host[s]) for s in uniq]))
     bev = None
     if net.bbox_head.bev_map:
@@ -350,13 +384,36 @@ def measure(args, env):
     n_overflow = [0]       # sweeps whose row counts exceeded the captured capacities and were re-run on the eager path
     capacity = (max(len(host[s]) for s in uniq) + 4095) // 4096 * 4096
 
+    last_forecast = [None]  # --pipeline full: the ForecastOutputs the last forward() wrote (a step's static buffers, or the eager path's)
+    eager_forecast = {}
+
+    def eager(clouds):
+        """eager launches of one pass (instrumented steps, overflow re-runs, set-up)"""
+        if pipe != "full":
+            return net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded="packed")
+        from futuredet_amd import hip_ops
+        from futuredet_amd.forecast import sweep_forecast
+
+        merged = []
+        for smp in clouds:
+            pts, cnt = hip_ops.assemble_sweeps(smp["raw"], smp["desc"], n_sweeps=N_SWEEPS)
+            merged.append((pts, cnt))
+        p, c = net.forward_points([m[0] for m in merged], cfg.voxel_generator, bev_map=bev, padded="packed", counts=[m[1] for m in merged])
+        key = torch.cuda.current_stream(dev).cuda_stream
+        eager_forecast[key] = sweep_forecast(p, c, torch.stack([smp["time"] for smp in clouds]), torch.stack([smp["records"] for smp in clouds]),
+                                             args.class_name, out=eager_forecast.get(key))
+        last_forecast[0] = eager_forecast[key]
+        return p, c
+
     def forward(clouds):
         step = static_steps.get(torch.cuda.current_stream(dev).cuda_stream) if (use_graph and not prof.enabled) else None
         if step is not None:
             last_static[0] = step
-            return step(clouds, bev_map=bev, check=False)  # overflow is checked from the copied level counts in retire_step; (packed [B,S,post,11], counts [B,S]) written by the decode's last kernel
+            out_ = step(clouds, bev_map=bev, check=False)  # overflow is checked from the copied level counts in retire_step; (packed [B,S,post,11], counts [B,S]) written by the decode's last kernel
+            last_forecast[0] = getattr(step, "forecast", None)
+            return out_
         last_static[0] = None
-        return net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded="packed")
+        return eager(clouds)
 
     def sync_all():
         if world > 1:
@@ -368,6 +425,7 @@ def measure(args, env):
     per_step_gather = world > 1 and strong
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))]
     n_fwd = [0]
+    last_blob = [None]  # (pinned copy of the last pass's forecast blob, its ForecastOutputs layout)
     pinned = {}  # ring of pinned result buffers (a slot is free again long before the ring wraps: results are retired in order)
     ring = 2 * (len(schedule(0)) + len(streams))
 
@@ -382,6 +440,12 @@ def measure(args, env):
                 clouds = [resident[s] for s in seeds[mb]] if from_host is None else from_host(si, mb, st)
                 prof.begin(mb)
                 p, c = forward(clouds)
+                if pipe == "full" and last_forecast[0] is not None:  # trajectories to the host with the detections: one copy of the result blob
+                    fslot = ("fc", n_fwd[0] % ring)
+                    if fslot not in pinned:
+                        pinned[fslot] = torch.empty(last_forecast[0].blob.shape, dtype=torch.uint8, pin_memory=True)
+                    pinned[fslot].copy_(last_forecast[0].blob, non_blocking=True)
+                    last_blob[0] = (pinned[fslot], last_forecast[0])
                 chk = None
                 stp = last_static[0]
                 if stp is not None and stp.caps is not None:  # capacities from a high-water mark: the level counts travel with the result
@@ -420,7 +484,7 @@ def measure(args, env):
                 if stp.overflowed(lc.tolist()):  # rare: this sweep needs more rows than the captured step holds -> eager launches
                     n_overflow[0] += 1
                     with torch.cuda.stream(st):
-                        p, c = net.forward_points(clouds, cfg.voxel_generator, bev_map=bev, padded="packed")
+                        p, c = eager(clouds)
                         if ev is not None:
                             p, c = p.cpu(), c.cpu()
                     st.synchronize()
@@ -499,8 +563,12 @@ def measure(args, env):
                 if use_graph:
                     from futuredet_amd.detectors import StaticStep
                     try:
-                        step = StaticStep(net, cfg.voxel_generator, capacity, batch_size=B, ndim=host[uniq[0]].shape[1], packed=True,
-                                          row_caps="datafree" if is_pp else "auto")
+                        if pipe == "full":
+                            from futuredet_amd.detectors import FullSweepStep
+                            step = FullSweepStep(net, cfg.voxel_generator, capacity, n_sweeps=N_SWEEPS, batch_size=B, classname=args.class_name, row_caps="auto")
+                        else:
+                            step = StaticStep(net, cfg.voxel_generator, capacity, batch_size=B, ndim=host[uniq[0]].shape[1], packed=True,
+                                              row_caps="datafree" if is_pp else "auto")
                         step.warm_up([resident[s] for s in seeds[0]], bev_map=bev)
                         step.capture()
                         static_steps[st.cuda_stream] = step
@@ -559,7 +627,14 @@ def measure(args, env):
                     if key not in staging or staging[key].shape != host[s].shape:
                         staging[key] = torch.empty_like(host[s], device=dev)
                     staging[key].copy_(host[s], non_blocking=True)
-                    row.append(staging[key])
+                    if pipe == "full":  # raw rows and their descriptors start on the host
+                        dkey = (st.cuda_stream, j, "desc")
+                        if dkey not in staging:
+                            staging[dkey] = torch.empty_like(host_desc[s], device=dev)
+                        staging[dkey].copy_(host_desc[s], non_blocking=True)
+                        row.append(dict(resident[s], raw=staging[key], desc=staging[dkey]))
+                    else:
+                        row.append(staging[key])
                 return row
 
             run_steps(0, min(2, args.steps), from_host)  # allocate the staging buffers outside the clock
@@ -644,6 +719,53 @@ def measure(args, env):
                    "host": "%s logical CPUs pinned per rank; pinned host memory per rank: %.1f MB of clouds + result ring"
                            % (len(cpus) if cpus else "all", sum(h.numel() * 4 for h in host.values()) / 1e6)},
     }
+    if pipe != "plain":
+        out["config"]["pipeline"] = ("full: ten raw sweeps + transforms resident in HBM -> fd_sweep_assemble -> sweep -> fd_forecast_from_detections -> detections and "
+                                     "trajectories on the host (one graph replay per pass)") if pipe == "full" else \
+                                    "assembled: the plain pipeline on the clouds the full pipeline assembles (its like-for-like partner)"
+    if rank == 0 and pipe == "full":
+        # the stages the full pipeline adds, each timed alone with HIP events (50 launches back to back after 5 warm-ups)
+        from futuredet_amd import hip_ops
+        from futuredet_amd.forecast import sweep_forecast
+
+        def timed_us(fn, iters=50, warm=5):
+            for _ in range(warm):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / iters
+
+        with torch.no_grad():
+            smp = resident[seeds[0][0]]
+            R = int(smp["raw"].shape[0])
+            pts_buf, cnt_buf = torch.empty((R, 5), device=dev), torch.empty((1,), dtype=torch.int32, device=dev)
+            us_asm = timed_us(lambda: hip_ops.assemble_sweeps(smp["raw"], smp["desc"], n_sweeps=N_SWEEPS, out=pts_buf, count=cnt_buf))
+            kept_rows = int(cnt_buf.cpu()[0])
+            batch = [resident[s_] for s_ in seeds[0]]
+            p_, c_ = eager(batch)
+            tm_, rec_ = torch.stack([b_["time"] for b_ in batch]), torch.stack([b_["records"] for b_ in batch])
+            fo_ = sweep_forecast(p_, c_, tm_, rec_, args.class_name)
+            us_fc = timed_us(lambda: sweep_forecast(p_, c_, tm_, rec_, args.class_name, out=fo_))
+            fh = fo_.host()
+        traj_last = None
+        if last_blob[0] is not None:  # what the timed loop brought to the host with its last pass
+            traj_last = int(last_blob[0][1].views_of(last_blob[0][0])["n_traj"].sum())
+        out["full_pipeline"] = {
+            "raw_rows_per_cloud": R, "kept_rows_per_cloud": kept_rows, "sweeps_per_cloud": N_SWEEPS,
+            "assemble_us_per_cloud": round(us_asm, 2),
+            "assemble_algorithmic_bytes": 60 * R, "assemble_gbs": round(60.0 * R / us_asm / 1e3, 1), "assemble_frac_of_hbm_peak": round(60.0 * R / us_asm / 1e3 / HBM_PEAK_GBS, 4),
+            "assemble_what": "fd_sweep_assemble (sweep_count + sweep_scan + sweep_write) on one cloud's raw rows, alone; bytes = 2 x 20 B read + 20 B written per raw "
+                             "row (DESIGN 3); HBM-bound",
+            "forecast_us_per_pass": round(us_fc, 2), "forecast_clouds_per_pass": B,
+            "forecast_what": "fd_forecast_from_detections (det_to_global_packed + forecast_chains + forecast_traj_groups: three launches, one workgroup per "
+                             "sweep in two of them) on a pass's packed detections, alone; latency-bound, <= 7 x 83 boxes per sweep",
+            "trajectories_of_that_pass": int(fh["n_traj"].sum()), "trajectories_last_timed_pass": traj_last,
+            "result_blob_bytes_per_pass": int(fo_.blob.numel())}
     if rank == 0 and is_pp:
         out["roofline"] = None
     elif rank == 0:
@@ -838,6 +960,11 @@ def main():
             ("config4_rank", dict(PRESETS[4], global_batch=8), "BASELINE configs[3] as one of its 8 ranks runs it: 8 of the 64 clouds per step, micro-batches of 4 (strong-scaling "
                                                               "mode, one rank here)"),
             ("config5", dict(PRESETS[5]), "BASELINE configs[4] on ONE GPU: pedestrian forecast_n3, bf16, 500k-point clouds, 0.05 m x/y voxels, max_voxels 400k"),
+            ("full_pipeline", dict(pipeline="full"), "FutureDet end to end on the headline configuration: raw sweeps + transforms -> sweep assembly -> the sweep -> "
+                                                      "forecast association -> detections and trajectories on the host"),
+            ("full_pipeline_plain", dict(pipeline="assembled"), "the plain pipeline on the clouds full_pipeline assembles (like-for-like partner: the difference is "
+                                                                 "what assembly + forecast + the larger result copy cost)"),
+            ("full_pipeline_bf16", dict(PRESETS[3], pipeline="full"), "FutureDet end to end on BASELINE configs[2] (forecast_n3, bf16)"),
             ("street_fp32", dict(scene="street"), "the headline workload on the street scene profile (fp32)"),
             ("street_bf16", dict(PRESETS[3], scene="street"), "BASELINE configs[2] on the street scene profile (bf16)"),
         ]
@@ -865,6 +992,7 @@ def main():
                                                         "traffic", "traffic_source")},
                     "hbm_algorithmic": rx.get("hbm_algorithmic"), "detections_last_step": ox["config"]["detections_last_step"],
                     "graph_overflows": ox["config"]["graph_overflows"],
+                    **({"stages": ox["full_pipeline"]} if ox.get("full_pipeline") else {}),
                     "what": "%s; measured by this process after the headline's legs with the same program (%d warm-up steps, %d repetitions of the %d-step "
                             "timed region, host leg, one-in-flight latency legs, per-launch HIP events); %.0f s of wall time"
                             % (what, ax.warmup, ax.reps, ax.steps, time.perf_counter() - t_also)}
@@ -877,6 +1005,10 @@ def main():
         out["latency_ms_sweep"] = b1.get("latency_ms_inflight1_host_to_host")
         out["latency_ms_sweep_is"] = ("one cloud, one pass in flight, pinned host memory -> detections on the host (also.batch1): what the reference's serial "
                                       "eval loop prints as 'Total time per frame' (tools/dist_test.py:204-217,240)")
+        fp_, fpp = out["also"].get("full_pipeline") or {}, out["also"].get("full_pipeline_plain") or {}
+        if fp_.get("value") and fpp.get("value"):
+            fp_["overhead_vs_plain_same_clouds"] = round(1.0 - fp_["value"] / fpp["value"], 4)
+            fp_["overhead_is"] = "1 - value / also.full_pipeline_plain.value: the throughput the added stages cost (VERDICT r5 #3 asks <= 0.03)"
         c3, c31 = out["also"].get("config3") or {}, out["also"].get("config3_batch1") or {}
         if c3.get("value") is not None:
             c3["value_batch1"], c3["latency_ms_sweep"] = c31.get("value"), c31.get("latency_ms_inflight1_host_to_host")

@@ -32,12 +32,20 @@ struct FcArgs {
     double *cv_centers;
 };
 
+// One workgroup per sweep (blockIdx.x = sample of a batch; every array of FcArgs is the first sample's, the others follow at the
+// array's own size).
 __global__ void __launch_bounds__(256) forecast_chains(FcArgs a) {
     __shared__ int s_idx[2][kMaxT - 1][kMaxN];
     __shared__ double s_dist[2][kMaxT - 1][kMaxN];
     __shared__ int s_cnt[kMaxT];
     __shared__ int s_empty;
     const int T = a.T, N = a.n_max, tid = threadIdx.x;
+    {
+        const size_t b = blockIdx.x;
+        a.centers += b * T * N * 3; a.velocity += b * T * N * 3; a.counts += b * T; a.time += b * (T - 1);
+        a.fwd_idx += b * N * T; a.bwd_idx += b * N * T; a.fwd_ok += b * N; a.bwd_ok += b * N; a.match_idx += b * T * N;
+        a.status += b; a.cv_centers += b * N * T * 3;
+    }
     if (tid < T) s_cnt[tid] = min(a.counts[tid], N);
     if (tid == 0) s_empty = 0;
     __syncthreads();
@@ -142,18 +150,17 @@ __device__ inline void quat_matrix(const double *q, double R[3][3]) {
         }
 }
 
-__global__ void __launch_bounds__(128) det_to_global_kernel(DetArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
-    const float *b = a.box3d + (size_t)i * 9;
+// one box: head row b9 = (x,y,z,w,l,h,vx,vy,yaw) -> center / quat / velocity / size of box i of the output arrays
+__device__ inline void det_to_global_one(const float *__restrict__ b, const Rigid (&step)[2], size_t i, double *__restrict__ center,
+                                         double *__restrict__ quat, double *__restrict__ velocity, float *__restrict__ size) {
     const float yaw = __fsub_rn(-b[8], 1.5707963267948966f);  // float32: -box3d[:, -1] - np.pi / 2
     const double half = (double)yaw / 2.0;
     double o[4] = {cos(half), 0.0, 0.0, sin(half)};
     double c[3] = {(double)b[0], (double)b[1], (double)b[2]};
     double v[3] = {(double)b[6], (double)b[7], 0.0};
     for (int s = 0; s < 2; ++s) {
-        if (!a.step[s].on) continue;
-        double q[4] = {a.step[s].q[0], a.step[s].q[1], a.step[s].q[2], a.step[s].q[3]};
+        if (!step[s].on) continue;
+        double q[4] = {step[s].q[0], step[s].q[1], step[s].q[2], step[s].q[3]};
         const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
         if (fabs(1.0 - n2) >= 1e-14 && n2 > 0.0) {
             const double nn = sqrt(n2);
@@ -169,15 +176,41 @@ __global__ void __launch_bounds__(128) det_to_global_kernel(DetArgs a) {
         const double w = q[0], x = q[1], y = q[2], z = q[3];
         const double o2[4] = {w * o[0] - x * o[1] - y * o[2] - z * o[3], x * o[0] + w * o[1] - z * o[2] + y * o[3],
                               y * o[0] + z * o[1] + w * o[2] - x * o[3], z * o[0] - y * o[1] + x * o[2] + w * o[3]};
-        for (int r = 0; r < 3; ++r) { c[r] = c2[r] + a.step[s].t[r]; v[r] = v2[r]; }
+        for (int r = 0; r < 3; ++r) { c[r] = c2[r] + step[s].t[r]; v[r] = v2[r]; }
         for (int k = 0; k < 4; ++k) o[k] = o2[k];
     }
     for (int r = 0; r < 3; ++r) {
-        a.center[(size_t)i * 3 + r] = c[r];
-        a.velocity[(size_t)i * 3 + r] = v[r];
-        a.size[(size_t)i * 3 + r] = b[3 + r];
+        center[i * 3 + r] = c[r];
+        velocity[i * 3 + r] = v[r];
+        size[i * 3 + r] = b[3 + r];
     }
-    for (int k = 0; k < 4; ++k) a.quat[(size_t)i * 4 + k] = o[k];
+    for (int k = 0; k < 4; ++k) quat[i * 4 + k] = o[k];
+}
+
+__global__ void __launch_bounds__(128) det_to_global_kernel(DetArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    det_to_global_one(a.box3d + (size_t)i * 9, a.step, (size_t)i, a.center, a.quat, a.velocity, a.size);
+}
+
+// The same per box, straight from the head's packed output [B, T, post, row_floats] (row = box 9 + score + label) with the two records
+// of every sample in DEVICE memory ([B][14] = calibrated_sensor rotation wxyz, translation xyz, ego_pose rotation, translation; NULL:
+// the boxes stay in the lidar frame): nothing of a sample is a kernel argument, so the launch can sit in a captured graph that is replayed
+// for other samples.  Slots past a step's count are computed like any other row (their inputs are the decode's padding) and never read
+// by the association.
+__global__ void __launch_bounds__(128) det_to_global_packed_kernel(const float *__restrict__ packed, int row_floats, int rows_per_sample, int n_total,
+                                                                   const double *__restrict__ records, double *__restrict__ center,
+                                                                   double *__restrict__ quat, double *__restrict__ velocity, float *__restrict__ size) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    Rigid step[2];
+    const double *rec = records ? records + (size_t)(i / rows_per_sample) * 14 : nullptr;
+    for (int s = 0; s < 2; ++s) {
+        step[s].on = rec != nullptr;
+        for (int k = 0; k < 4; ++k) step[s].q[k] = rec ? rec[7 * s + k] : (k == 0 ? 1.0 : 0.0);
+        for (int k = 0; k < 3; ++k) step[s].t[k] = rec ? rec[7 * s + 4 + k] : 0.0;
+    }
+    det_to_global_one(packed + (size_t)i * row_floats, step, (size_t)i, center, quat, velocity, size);
 }
 
 // ---------------------------------------------------------------------------------------------- multi_future groups
@@ -227,6 +260,74 @@ __global__ void __launch_bounds__(1024) forecast_groups_kernel(const double *__r
         int rank = 0;
         for (int r = 0; r < lab; ++r) rank += (s_label[r] == r);
         ids[i] = rank;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- trajectories of a sweep + their groups
+// What `tracker` returns for one sweep, as arrays (nuscenes.py:160-241): the trajectories in the reference's order -- forward chains of the
+// step-0 boxes that are not void, then the constant-velocity roll-out of EVERY step-0 box, then the back-cast chains of the last step's
+// boxes that are not void (reversed, so they too start at step 0) -- and multi_future's forecast_id of each (nuscenes.py:299-339: connected
+// components of "first boxes closer than match_thresh", numbered by their smallest member).  One workgroup per sweep.
+//   kind  0 = forward chain, 1 = constant velocity, 2 = back-cast chain;  src = the box the trajectory was started from (step 0 for
+//   kinds 0 / 1, last step for kind 2);  first = the step-0 box it begins with (kind 2: bwd_idx[src][T-1]).
+constexpr int kMaxTraj = 3 * kMaxN;
+__global__ void __launch_bounds__(1024) forecast_traj_groups_kernel(const double *__restrict__ centers, const int *__restrict__ counts, const int *__restrict__ fwd_ok,
+                                                                    const int *__restrict__ bwd_ok, const int *__restrict__ bwd_idx, const int *__restrict__ status,
+                                                                    int T, int N, double thresh, int *__restrict__ traj_kind, int *__restrict__ traj_src,
+                                                                    int *__restrict__ traj_first, int *__restrict__ traj_group, int *__restrict__ n_traj) {
+    __shared__ int s_label[kMaxTraj];
+    __shared__ int s_first[kMaxTraj];
+    __shared__ int s_scan[kMaxN + 1];
+    __shared__ int s_n[3];
+    const size_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    centers += b * T * N * 3; counts += b * T; fwd_ok += b * N; bwd_ok += b * N; bwd_idx += b * N * T; status += b;
+    traj_kind += b * 3 * N; traj_src += b * 3 * N; traj_first += b * 3 * N; traj_group += b * 3 * N; n_traj += b;
+    const int n0 = status[0] ? 0 : min(counts[0], N), nl = status[0] ? 0 : min(counts[T - 1], N);
+    // stable compaction of the two flag vectors (<= 256 entries each): thread 0 scans; the lists are tiny
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < n0; ++i) { s_scan[i] = run; run += fwd_ok[i] ? 1 : 0; }
+        s_n[0] = run;
+    }
+    __syncthreads();
+    const int nf = s_n[0];
+    for (int i = tid; i < n0; i += 1024) {
+        if (fwd_ok[i]) { const int p = s_scan[i]; traj_kind[p] = 0; traj_src[p] = i; s_first[p] = i; }
+        const int p = nf + i;
+        traj_kind[p] = 1; traj_src[p] = i; s_first[p] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < nl; ++i) { s_scan[i] = run; run += bwd_ok[i] ? 1 : 0; }
+        s_n[1] = run;
+    }
+    __syncthreads();
+    const int n = nf + n0 + s_n[1];
+    for (int i = tid; i < nl; i += 1024)
+        if (bwd_ok[i]) { const int p = nf + n0 + s_scan[i]; traj_kind[p] = 2; traj_src[p] = i; s_first[p] = bwd_idx[(size_t)i * T + T - 1]; }
+    __syncthreads();
+    if (tid == 0) n_traj[0] = n;
+    for (int i = tid; i < n; i += 1024) { traj_first[i] = s_first[i]; s_label[i] = i; }
+    for (int i = n + tid; i < 3 * N; i += 1024) { traj_kind[i] = -1; traj_src[i] = -1; traj_first[i] = -1; traj_group[i] = -1; }
+    __syncthreads();
+    // min-label propagation over the "closer than thresh" graph of the first boxes' centres (all three coordinates), as in forecast_groups_kernel
+    for (int it = 0; it < n; ++it) {
+        int best = tid < n ? s_label[tid] : 0;
+        if (tid < n)
+            for (int j = 0; j < n; ++j)
+                if (s_label[j] < best && dist3d(centers + (size_t)s_first[tid] * 3, centers + (size_t)s_first[j] * 3) < thresh) best = s_label[j];
+        __syncthreads();
+        int changed = 0;
+        if (tid < n && best != s_label[tid]) { s_label[tid] = best; changed = 1; }
+        if (!__syncthreads_or(changed)) break;
+    }
+    if (tid < n) {
+        const int lab = s_label[tid];
+        int rank = 0;
+        for (int r = 0; r < lab; ++r) rank += (s_label[r] == r);
+        traj_group[tid] = rank;
     }
 }
 
@@ -312,4 +413,34 @@ extern "C" int fd_forecast_chains(const double *centers, const double *velocity,
     FcArgs a{centers, velocity, counts, time_dev, T, n_max, reject_thresh, fwd_idx, fwd_ok, bwd_idx, bwd_ok, match_idx, status, cv_centers};
     hipLaunchKernelGGL(forecast_chains, dim3(1), dim3(256), 0, fd::as_stream(stream), a);
     return fd::check_launch("fd_forecast_chains");
+}
+
+// Head output of a batch -> global-frame boxes -> association -> trajectories and their groups: three launches, no host data of a sample
+// among the kernel arguments (see include/futuredet_hip.h).
+extern "C" int fd_forecast_from_detections(const float *packed, const int32_t *counts, int B, int T, int post, int row_floats, const double *records_dev,
+                                           const double *time_dev, double reject_thresh, double match_thresh, const fd_forecast_buffers *out,
+                                           fd_stream_t stream_) {
+    FD_REQUIRE(B >= 0, "fd_forecast_from_detections: negative batch");
+    if (B == 0) return FD_OK;
+    FD_REQUIRE(packed && counts && time_dev && out, "fd_forecast_from_detections: null argument");
+    FD_REQUIRE(T >= 2 && T <= kMaxT, "fd_forecast_from_detections: T must be in [2,%d]", kMaxT);
+    FD_REQUIRE(post >= 1 && post <= kMaxN, "fd_forecast_from_detections: post must be in [1,%d]", kMaxN);
+    FD_REQUIRE(row_floats >= 9, "fd_forecast_from_detections: a row holds at least the 9 box values");
+    FD_REQUIRE(out->center && out->quat && out->velocity && out->size && out->fwd_idx && out->fwd_ok && out->bwd_idx && out->bwd_ok && out->match_idx &&
+                   out->cv_centers && out->status,
+               "fd_forecast_from_detections: null output buffer");
+    const bool groups = out->traj_kind || out->traj_src || out->traj_first || out->traj_group || out->n_traj;
+    FD_REQUIRE(!groups || (out->traj_kind && out->traj_src && out->traj_first && out->traj_group && out->n_traj),
+               "fd_forecast_from_detections: the five trajectory buffers come together (or all NULL)");
+    hipStream_t stream = fd::as_stream(stream_);
+    const int rows = T * post, n_total = B * rows;
+    hipLaunchKernelGGL(det_to_global_packed_kernel, dim3((unsigned)((n_total + 127) / 128)), dim3(128), 0, stream, packed, row_floats, rows, n_total, records_dev,
+                       out->center, out->quat, out->velocity, out->size);
+    FcArgs a{out->center, out->velocity, counts, time_dev, T, post, reject_thresh, out->fwd_idx, out->fwd_ok, out->bwd_idx, out->bwd_ok, out->match_idx,
+             out->status, out->cv_centers};
+    hipLaunchKernelGGL(forecast_chains, dim3((unsigned)B), dim3(256), 0, stream, a);
+    if (groups)
+        hipLaunchKernelGGL(forecast_traj_groups_kernel, dim3((unsigned)B), dim3(1024), 0, stream, out->center, counts, out->fwd_ok, out->bwd_ok, out->bwd_idx,
+                           out->status, T, post, match_thresh, out->traj_kind, out->traj_src, out->traj_first, out->traj_group, out->n_traj);
+    return fd::check_launch("fd_forecast_from_detections");
 }

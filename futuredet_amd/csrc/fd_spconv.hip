@@ -380,7 +380,8 @@ extern "C" int fd_spconv_apply(const void *in_feats, int64_t n_in, const void *w
         // The window [row - HALO, row + TM + HALO] only holds the neighbours when input rows lie around the output rows, i.e. for a SubM
         // convolution (27 taps over the SAME row set).  The strided 128 -> 128 extra_conv (K = 3, stride (2,1,1)) has the shape but not the
         // property: every lane would take the exec-masked global gather next to a window staged for nothing -> RING kernel.
-        const bool subm_like = K == 27 && n_in == n_out;
+        // ("bf16_win" = 2 / FD_BF16_WIN=2 sends such a layer to the window kernel all the same: the A/B of this rule)
+        const bool subm_like = (K == 27 && n_in == n_out) || fd::tuning(fd::kTuneBf16Win) == 2;
         if (fd::tuning(fd::kTuneBf16Win) >= 0 && subm_like && fd::spconv_bf16_win_weight_bytes(K, cin, cout) &&
             fd::spconv_bf16_win_dispatch(in_feats, (const char *)wpacked + (size_t)K * cin * cout * 2, bias, residual, relu, nbr, nbr_stride, K, n_in, (int)n_out,
                                          n_out_dev, n_expected, cin, cout, out_feats, fd::as_stream(stream)))

@@ -21,11 +21,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kMaxTaps = 27;
 
-template <int COUT, int RG, int DEPTH>
-__global__ void __launch_bounds__(1024) spconv_f32_res16(const float *__restrict__ in, const f32x4 *__restrict__ wp, const float *__restrict__ bias,
+template <int COUT, int RG, int DEPTH, int NW>
+__global__ void __launch_bounds__(NW * 64) spconv_f32_res16(const float *__restrict__ in, const f32x4 *__restrict__ wp, const float *__restrict__ bias,
                                                          const float *__restrict__ residual, int relu, const int *__restrict__ nbr, int64_t nbr_stride,
                                                          int K, int n_out, const int *__restrict__ n_out_dev, float *__restrict__ out, unsigned in_bytes) {
-    constexpr int NW = 16, NB = COUT / 16, ROWS = 16 * RG;
+    constexpr int NB = COUT / 16, ROWS = 16 * RG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4 *s_w = reinterpret_cast<f32x4 *>(smem);                              // [K][NB][64]: fd_spconv_pack_weight's fp32 fragment order
     constexpr int kSliceInts = (kMaxTaps + 1) * ROWS;
@@ -174,20 +174,21 @@ __global__ void __launch_bounds__(1024) spconv_f32_res16(const float *__restrict
     }
 }
 
-template <int COUT, int RG, int DEPTH>
+template <int COUT, int RG, int DEPTH, int NW>
 int launch_res16(const float *in, const void *wp, const float *bias, const float *residual, int relu, const int *nbr, int64_t nbr_stride, int K, int n_out,
                  const int *n_out_dev, int64_t n_expected, float *out, unsigned in_bytes, hipStream_t stream) {
-    constexpr size_t lds = (size_t)kMaxTaps * (COUT / 16) * 1024 + (size_t)16 * (2 * (kMaxTaps + 1) + 1) * 16 * RG * 4;
+    constexpr size_t lds = (size_t)kMaxTaps * (COUT / 16) * 1024 + (size_t)NW * (2 * (kMaxTaps + 1) + 1) * 16 * RG * 4;
     static_assert(lds <= 160 * 1024, "LDS request");
-    auto kern = spconv_f32_res16<COUT, RG, DEPTH>;
+    constexpr int per_cu = (int)((160 * 1024) / lds) < 32 / NW ? (int)((160 * 1024) / lds) : 32 / NW;  // resident workgroups per CU (LDS, 32 waves)
+    auto kern = spconv_f32_res16<COUT, RG, DEPTH, NW>;
     static std::atomic<uint64_t> lds_set{0};
     if (lds > 65536 && !fd::ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, lds_set)) return 0;
-    constexpr int64_t wg_rows = 16 * 16 * RG;
+    constexpr int64_t wg_rows = NW * 16 * RG;
     int64_t grid = (n_expected + wg_rows - 1) / wg_rows;
-    const int64_t cap = fd::device_cu_count();  // persistent workgroups, one per CU
+    const int64_t cap = (int64_t)fd::device_cu_count() * (per_cu > 0 ? per_cu : 1);  // persistent workgroups, every resident slot of every CU
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), lds, stream, in, (const f32x4 *)wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, in, (const f32x4 *)wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev,
                        out, in_bytes);
     return 1;
 }
@@ -204,10 +205,16 @@ int spconv_f32_res16_dispatch(const float *in, const void *wp, const float *bias
     if (cout == 32 && fd::tuning(fd::kTuneF32ResRG) < 32) return 0;
     const unsigned in_bytes = (unsigned)(n_in_bound * 64);
     const int rg = fd::tuning(fd::kTuneF32ResRG);
+    const int nw = fd::tuning(fd::kTuneF32ResNW);  // 16: one 1024-thread workgroup per CU (round 3-5); default 14: two per CU (LDS 78.7 KB each)
+#define FD_RES(CO, RGV, NWV) launch_res16<CO, RGV, 4, NWV>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, n_expected, out, in_bytes, stream)
     if (cout == 16) {
-        if (rg >= 2) return launch_res16<16, 2, 4>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, n_expected, out, in_bytes, stream);
-        return launch_res16<16, 1, 4>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, n_expected, out, in_bytes, stream);
+        if (rg >= 2) return FD_RES(16, 2, 16);
+        if (nw == 16) return FD_RES(16, 1, 16);
+        if (nw == 12) return FD_RES(16, 1, 12);
+        if (nw == 8) return FD_RES(16, 1, 8);
+        return FD_RES(16, 1, 14);
     }
-    return launch_res16<32, 1, 4>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, n_expected, out, in_bytes, stream);
+    return FD_RES(32, 1, 16);
+#undef FD_RES
 }
 }  // namespace fd

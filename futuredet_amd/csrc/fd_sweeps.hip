@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(kBlock) sweep_count(const float *__restrict__ 
     load_sweeps(s, sweeps, n_sweeps);
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     bool keep = false;
-    if (i < n_rows) keep = row_kept(sweeps[find_sweep(s, n_sweeps, i)], raw + i * raw_cols, radius);
+    if (i < n_rows && i < s.row_begin[n_sweeps]) keep = row_kept(sweeps[find_sweep(s, n_sweeps, i)], raw + i * raw_cols, radius);
     const unsigned long long m = __ballot(keep);
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
     __syncthreads();
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(kBlock) sweep_write(const float *__restrict__ 
     const int oc = keep_cols + 1;
     bool keep = false;
     int sw = 0;
-    if (i < n_rows) {
+    if (i < n_rows && i < s.row_begin[n_sweeps]) {  // n_rows is an upper bound (a fixed-capacity buffer): the descriptors say where the rows end
         sw = find_sweep(s, n_sweeps, i);
         keep = row_kept(sweeps[sw], raw + i * raw_cols, radius);
     }

@@ -418,6 +418,85 @@ class StaticStep(object):
         return self(clouds, check=True)
 
 
+class FullSweepStep(StaticStep):
+    """FutureDet end to end as ONE hipGraph replay (SURVEY 8f-2 + A15 + 8f-3):
+
+        raw sweeps [R,5] + per-sweep 4x4 transforms / time lags (HBM)  --fd_sweep_assemble-->  the 10-sweep cloud
+        --StaticStep's sweep (voxelizer ... rotated NMS)-->  packed detections
+        --fd_forecast_from_detections-->  global-frame boxes, forward / back-cast chains, constant-velocity roll-outs, trajectory list
+                                          + forecast ids (hip_ops.ForecastOutputs, device buffers)
+
+    i.e. det3d/datasets/pipelines/loading.py:100-141 in front of the detector and det3d/datasets/nuscenes/nuscenes.py:384-494 (forecast_mode
+    "velocity_dense": tracker, :125-257) + multi_future (:299-339) behind it.  File reading and the devkit's token / pose look-ups stay
+    with the caller: the raw rows, the descriptors (hip_ops.sweep_descriptors), ``time`` and the two pose records come in as arrays.
+
+        step = FullSweepStep(model, voxel_cfg, capacity=400000, n_sweeps=10)
+        step.warm_up(samples); step.capture()
+        packed, counts = step(samples)        # samples: one dict per cloud with device tensors raw [R,5] f32, desc uint8 (descriptor
+        step.forecast.host()                  # records), optional time [T-1] f64 and records [14] f64
+    """
+
+    def __init__(self, model, voxel_cfg, capacity, n_sweeps=10, batch_size=1, keep_cols=4, raw_cols=5, classname="car", min_distance=1.0, **kw):
+        super().__init__(model, voxel_cfg, capacity, batch_size=batch_size, ndim=keep_cols + 1, packed=True, **kw)
+        dev = self.points.device
+        head = model.bbox_head
+        self.T = int(head.timesteps if getattr(head, "timesteps", 1) > 1 else getattr(head, "target_timesteps", 7))
+        self.n_sweeps, self.keep_cols, self.classname, self.min_distance = int(n_sweeps), int(keep_cols), classname, float(min_distance)
+        self.raw = torch.zeros((self.B, self.capacity, raw_cols), dtype=torch.float32, device=dev)
+        self.desc = torch.zeros((self.B, self.n_sweeps * hip_ops.SWEEP_DESC.itemsize), dtype=torch.uint8, device=dev)
+        self.time = torch.full((self.B, max(self.T - 1, 1)), 0.5, dtype=torch.float64, device=dev)
+        ident = torch.tensor([1.0, 0, 0, 0, 0, 0, 0] * 2, dtype=torch.float64, device=dev)
+        self.records = ident.repeat(self.B, 1).contiguous()
+        self.forecast = None
+
+    def _load(self, samples):
+        assert len(samples) == self.B
+        for b, smp in enumerate(samples):
+            raw, desc = smp["raw"], smp["desc"]
+            n = int(raw.shape[0])
+            if n > self.capacity or raw.shape[1] != self.raw.shape[2]:
+                raise ValueError("%d x %d raw rows do not fit the step's %d x %d buffer" % (n, raw.shape[1], self.capacity, self.raw.shape[2]))
+            if desc.numel() != self.desc.shape[1]:
+                raise ValueError("the step was built for %d sweeps per cloud" % self.n_sweeps)
+            self.raw[b, :n].copy_(raw, non_blocking=True)   # (rows past the last descriptor's row_end are ignored by the assembly)
+            self.desc[b].copy_(desc.reshape(-1), non_blocking=True)
+            if smp.get("time") is not None:
+                self.time[b].copy_(smp["time"], non_blocking=True)
+            if smp.get("records") is not None:
+                self.records[b].copy_(smp["records"], non_blocking=True)
+
+    def _run(self, static):
+        import contextlib
+
+        from .forecast import sweep_forecast
+
+        scope = (lambda: hip_ops.workspace.scope(id(self))) if static else contextlib.nullcontext
+        with scope():
+            for b in range(self.B):  # the cloud and its row count are born in the sweep's static input buffers
+                hip_ops.assemble_sweeps(self.raw[b], self.desc[b], keep_cols=self.keep_cols, min_distance=self.min_distance, out=self.points[b],
+                                        count=self.counts[b:b + 1], n_sweeps=self.n_sweeps)
+        outs = StaticStep._run(self, static)
+        if self.T >= 2:
+            packed, counts = outs
+            self.forecast = sweep_forecast(packed, counts, self.time[:, :self.T - 1].contiguous() if self.time.shape[1] != self.T - 1 else self.time,
+                                           self.records, self.classname, out=self.forecast)
+        return outs
+
+    def __call__(self, samples, bev_map=None, check=True):
+        self._set_bev(bev_map)
+        if self.graph is None or self.version != self._version_key():
+            if self.expected is None:
+                self.warm_up(samples)
+            self.capture()
+        self._load(samples)
+        self.graph.replay()
+        if check and self.caps is not None and self.overflowed():  # rare: more rows than the captured capacities -> eager launches
+            redo = self._run(False)
+            for dst, src in zip(self.outputs, redo):
+                dst.copy_(src)
+        return self.outputs
+
+
 @DETECTORS.register_module
 class PointPillars(SingleStageDetector):
     """det3d/models/detectors/point_pillars.py:5-50 (the two *_pp_* configs).  Same contract as VoxelNet: forward(example)

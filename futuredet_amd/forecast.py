@@ -240,3 +240,29 @@ def multi_future(forecast_boxes, classname):
                 sub["forecast_id"] = int(fid)
         forecast_boxes[sample_token] = boxes
     return forecast_boxes
+
+
+# ------------------------------------------------------------------------------------------------ whole batch, device-resident
+def sweep_forecast(packed, counts, time, records=None, classname="car", out=None):
+    """The device part of forecast_boxes(..., forecast_mode="velocity_dense") + multi_future for a batch: the head's packed output
+    (``packed`` [B,T,post,11], ``counts`` [B,T], device tensors as CenterHead.predict / StaticStep return them) -> global-frame boxes ->
+    chains -> trajectories and their forecast ids, all in HBM (hip_ops.ForecastOutputs; fd_forecast_from_detections, three launches,
+    no synchronisation, capturable).  ``time`` [B,T-1] float64 and ``records`` [B,14] float64 (calibrated_sensor + ego_pose, see the
+    header) are device tensors: the devkit look-ups that produce them are the caller's (nuscenes.py:385-406)."""
+    reject = 2.0 if classname == "car" else 1.0  # nuscenes.py:126-132
+    return hip_ops.forecast_from_detections(packed, counts, time, records, reject_thresh=reject, match_thresh=0.25, out=out)
+
+
+def trajectories_from_arrays(h, b):
+    """Rebuilds, from the host copy ``h`` of a ForecastOutputs (``.host()``), sample ``b``'s trajectories the way ``tracker`` returns them:
+    a list of (kind, forecast_id, centres [T,3] float64, box index per step [T] or None for the constant-velocity roll-outs)."""
+    T = h["center"].shape[1]
+    out = []
+    for j in range(int(h["n_traj"][b])):
+        kind, src = int(h["traj_kind"][b, j]), int(h["traj_src"][b, j])
+        if kind == 1:
+            out.append((1, int(h["traj_group"][b, j]), h["cv_centers"][b, src].copy(), None))
+            continue
+        idx = h["fwd_idx"][b, src] if kind == 0 else h["bwd_idx"][b, src][::-1]
+        out.append((kind, int(h["traj_group"][b, j]), np.stack([h["center"][b, t, int(idx[t])] for t in range(T)]), idx.copy()))
+    return out

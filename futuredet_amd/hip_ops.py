@@ -667,21 +667,34 @@ def sweep_descriptors(rows, transforms, time_lags, remove_close):
     return d
 
 
-def assemble_sweeps(raw, desc, keep_cols=4, min_distance=1.0):
-    """Runs fd_sweep_assemble on device rows ``raw`` [R, raw_cols] float32 with host descriptors ``desc``
-    (sweep_descriptors).  Returns (points [R, keep_cols+1] padded with +inf past the count, count int32[1]); no sync."""
+def assemble_sweeps(raw, desc, keep_cols=4, min_distance=1.0, out=None, count=None, n_sweeps=None):
+    """Runs fd_sweep_assemble on device rows ``raw`` [R, raw_cols] float32.  ``desc``: host descriptors (sweep_descriptors; uploaded
+    here) or a device uint8 tensor already holding ``n_sweeps`` fd_sweep_desc records (the static form: a captured launch reads
+    whatever the caller last copied there; R is then an upper bound, rows past the last descriptor's row_end are dropped).
+    Returns (points [R, keep_cols+1] padded with +inf past the count, count int32[1]); ``out`` / ``count`` may be given; no sync."""
     L = _lib.load()
     raw = _dev(raw, "raw", torch.float32)
     R, raw_cols = raw.shape
     dev = raw.device
-    desc = np.ascontiguousarray(desc)
-    assert desc.dtype == SWEEP_DESC
-    desc_dev = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev, non_blocking=True)
-    out = torch.empty((R, keep_cols + 1), dtype=torch.float32, device=dev)
-    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    if isinstance(desc, torch.Tensor):
+        desc_dev = _dev(desc, "desc", torch.uint8)
+        n_desc = int(n_sweeps) if n_sweeps is not None else desc_dev.numel() // SWEEP_DESC.itemsize
+        assert desc_dev.numel() >= n_desc * SWEEP_DESC.itemsize
+    else:
+        desc = np.ascontiguousarray(desc)
+        assert desc.dtype == SWEEP_DESC
+        desc_dev = torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).to(dev, non_blocking=True)
+        n_desc = len(desc)
+    if out is None:
+        out = torch.empty((R, keep_cols + 1), dtype=torch.float32, device=dev)
+    else:
+        out = _dev(out, "out", torch.float32)
+        assert out.shape[0] >= R and out.shape[1] == keep_cols + 1
+    if count is None:
+        count = torch.empty((1,), dtype=torch.int32, device=dev)
     ws_bytes = L.fd_sweep_assemble_workspace_bytes(R)
     ws = workspace.get("sweeps", ws_bytes, dev)
-    check(L.fd_sweep_assemble(_p(raw), raw_cols, int(keep_cols), R, _p(desc_dev), len(desc), float(min_distance), _p(out),
+    check(L.fd_sweep_assemble(_p(raw), raw_cols, int(keep_cols), R, _p(desc_dev), n_desc, float(min_distance), _p(out),
                               _p(count), _p(ws), ws.numel(), _stream()), "fd_sweep_assemble")
     return out, count
 
@@ -781,3 +794,62 @@ def forecast_groups(centers, match_thresh):
     ids = torch.zeros((max(n, 1),), dtype=torch.int32, device=centers.device)[:n]
     check(L.fd_forecast_groups(_p(centers), n, float(match_thresh), _p(ids), _stream()), "fd_forecast_groups")
     return ids
+
+
+class ForecastOutputs(object):
+    """The device buffers of fd_forecast_from_detections for a batch of B sweeps with T steps of up to ``post`` boxes: allocated once,
+    written by every call (fixed shapes: they can be the static outputs of a captured graph).  ``host()`` copies them to numpy."""
+
+    FIELDS = (("center", (-1, -2, 3), torch.float64), ("quat", (-1, -2, 4), torch.float64), ("velocity", (-1, -2, 3), torch.float64),
+              ("size", (-1, -2, 3), torch.float32), ("fwd_idx", (-3, -1), torch.int32), ("fwd_ok", (-3,), torch.int32),
+              ("bwd_idx", (-3, -1), torch.int32), ("bwd_ok", (-3,), torch.int32), ("match_idx", (-1, -3), torch.int32),
+              ("cv_centers", (-3, -1, 3), torch.float64), ("status", (), torch.int32), ("traj_kind", (-4,), torch.int32),
+              ("traj_src", (-4,), torch.int32), ("traj_first", (-4,), torch.int32), ("traj_group", (-4,), torch.int32), ("n_traj", (), torch.int32))
+
+    def __init__(self, B, T, post, device):
+        self.B, self.T, self.post = int(B), int(T), int(post)
+        sub = {-1: self.T, -2: self.post, -3: self.post, -4: 3 * self.post}
+        # ONE allocation, every array a 16-byte aligned view of it: the whole result goes to the host in one copy (``blob``)
+        layout, off = [], 0
+        for name, shape, dt in self.FIELDS:
+            shape = (self.B,) + tuple(sub.get(d, d) for d in shape)
+            nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            layout.append((name, shape, dt, off, nbytes))
+            off = (off + nbytes + 15) & ~15
+        self.layout = layout
+        self.blob = torch.zeros((off,), dtype=torch.uint8, device=device)
+        for name, shape, dt, o, nbytes in layout:
+            setattr(self, name, self.blob[o:o + nbytes].view(dt).view(shape))
+        self.c_struct = _lib.ForecastBuffers(**{name: getattr(self, name).data_ptr() for name, _, _ in self.FIELDS})
+
+    def tensors(self):
+        return [getattr(self, name) for name, _, _ in self.FIELDS]
+
+    def views_of(self, blob_host):
+        """the named arrays of a HOST copy of ``blob`` (numpy views, no copy)"""
+        a = blob_host.numpy() if isinstance(blob_host, torch.Tensor) else np.asarray(blob_host)
+        npdt = {torch.float64: np.float64, torch.float32: np.float32, torch.int32: np.int32}
+        return {name: a[o:o + nbytes].view(npdt[dt]).reshape(shape) for name, shape, dt, o, nbytes in self.layout}
+
+    def host(self):
+        return self.views_of(self.blob.cpu())
+
+
+def forecast_from_detections(packed, counts, time, records=None, reject_thresh=2.0, match_thresh=0.25, out=None):
+    """fd_forecast_from_detections: packed [B,T,post,F>=9] float32, counts [B,T] int32, time [B,T-1] float64, records [B,14] float64 or
+    None (all device tensors) -> ForecastOutputs (``out`` is reused when given).  Three launches, no synchronisation."""
+    L = _lib.load()
+    packed = _dev(packed, "packed", torch.float32)
+    counts = _dev(counts, "counts", torch.int32)
+    time = _dev(time, "time", torch.float64)
+    B, T, post, F = packed.shape
+    assert tuple(counts.shape) == (B, T) and tuple(time.shape) == (B, T - 1)
+    if records is not None:
+        records = _dev(records, "records", torch.float64)
+        assert tuple(records.shape) == (B, 14)
+    if out is None:
+        out = ForecastOutputs(B, T, post, packed.device)
+    assert (out.B, out.T, out.post) == (B, T, post)
+    check(L.fd_forecast_from_detections(_p(packed), _p(counts), B, T, post, F, _p(records), _p(time), float(reject_thresh), float(match_thresh),
+                                        ctypes.byref(out.c_struct), _stream()), "fd_forecast_from_detections")
+    return out

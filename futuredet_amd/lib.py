@@ -35,6 +35,11 @@ class IndexLevel(ctypes.Structure):  # struct fd_index_level
                 ("coords", c_void_p), ("coords_rows", ctypes.c_int64)]
 
 
+class ForecastBuffers(ctypes.Structure):  # struct fd_forecast_buffers
+    _fields_ = [(n, c_void_p) for n in ("center", "quat", "velocity", "size", "fwd_idx", "fwd_ok", "bwd_idx", "bwd_ok", "match_idx", "cv_centers",
+                                        "status", "traj_kind", "traj_src", "traj_first", "traj_group", "n_traj")]
+
+
 # name -> (restype, argtypes); this table is checked against include/futuredet_hip.h by the tests
 SIGNATURES = {
     "fd_abi_version": (c_int, []),
@@ -103,6 +108,8 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_det_to_global_boxes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fd_forecast_groups": (c_int, [c_void_p, c_int, ctypes.c_double, c_void_p, c_void_p]),
+    "fd_forecast_from_detections": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double,
+                                            ctypes.POINTER(ForecastBuffers), c_void_p]),
     "fd_nearest_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "fd_index_pyramid": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, ctypes.POINTER(IndexLevel), c_void_p, c_void_p, c_size_t,
                                  c_void_p]),

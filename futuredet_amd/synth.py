@@ -55,6 +55,35 @@ def synthetic_cloud(seed=0, target_points=300000, n_sweeps=10, n_beams=32, profi
     return np.ascontiguousarray(np.concatenate(sweeps, axis=0))
 
 
+def synthetic_sweeps(seed=0, target_points=300000, n_sweeps=10, profile="dense"):
+    """The same scene as ``synthetic_cloud`` one step earlier in the reference's pipeline: what LoadPointCloudFromFile reads
+    (det3d/datasets/pipelines/loading.py:100-141) -- the key frame and ``n_sweeps - 1`` sweeps as RAW sensor-frame rows [x, y, z,
+    intensity, ring] with, per sweep, the 4x4 ``transform_matrix`` into the key frame (a small yaw + the ego shift, float64) and its
+    ``time_lag``.  Returns (raw [R,5] float32, rows int64 [n_sweeps+1], transforms (None for the key frame), time_lags, remove_close flags):
+    the arguments of hip_ops.sweep_descriptors.  Sweep s of the cloud is recognised by its time column (0.05 s)."""
+    cloud = synthetic_cloud(seed, target_points, n_sweeps=n_sweeps, profile=profile)
+    rng = np.random.default_rng([seed, 4242])
+    sweep_of = np.rint(cloud[:, 4] / 0.05).astype(np.int64)
+    chunks, transforms, lags, close = [], [], [], []
+    for s in range(n_sweeps):
+        pts = cloud[sweep_of == s].astype(np.float64)
+        if s == 0:
+            transforms.append(None)
+        else:
+            yaw, t = rng.normal(0, 0.01) * s, np.array([rng.normal(0, 0.3) * s, rng.normal(0, 0.3) * s, rng.normal(0, 0.01)])
+            M = np.eye(4)
+            M[:2, :2] = [[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]]
+            M[:3, 3] = t
+            pts[:, :3] = (pts[:, :3] - t) @ M[:3, :3]  # sensor-frame rows: M^-1 applied (row vectors: (R^T (p - t))^T = (p - t)^T R)
+            transforms.append(M)
+        raw = np.concatenate([pts[:, :4], rng.integers(0, 32, (len(pts), 1)).astype(np.float64)], 1).astype(np.float32)
+        chunks.append(raw)
+        lags.append(0.05 * s)
+        close.append(s > 0)
+    rows = np.cumsum([0] + [len(c) for c in chunks]).astype(np.int64)
+    return np.ascontiguousarray(np.concatenate(chunks, 0)), rows, transforms, lags, close
+
+
 def _street_cloud(seed, target_points, n_sweeps, n_beams):
     rng = np.random.default_rng([seed, 77])
     n_az = max(8, int(round(target_points / 0.95 / 0.94 / (n_sweeps * n_beams))))

@@ -28,8 +28,8 @@ extern "C" {
 
 typedef void *fd_stream_t; /* hipStream_t */
 
-int fd_abi_version(void); /* 6 (round 5: the split-operand dtypes 2-4, fd_rows_to_planes / fd_planes_to_rows and the two
-                             * MIOpen-epilogue helpers of ABI 5 are gone; fd_decode_cfg gained hm_channels) */
+int fd_abi_version(void); /* 7 (round 6: + fd_forecast_from_detections / fd_forecast_buffers; fd_sweep_assemble takes n_rows as an upper
+                             * bound -- rows past the last descriptor's row_end are dropped; fd_rulebook_compress ... see INTEGRATION.md) */
 const char *fd_last_error(void);
 /* Tuning / test knobs (no reference counterpart).  0 = built-in heuristic.  Names: "spconv_rg" (rows per wave of the
  * register sparse-conv kernel: 1|2|4), "spconv_v1" (1: fp32 on the register kernel instead of the compacting one),
@@ -283,7 +283,9 @@ int fd_boxes_iou_bev(const float *a7, int na, const float *b7, int nb, float *ou
  * sweeps (in the order the reference visits them) are filtered, moved into the key frame's coordinates and
  * given their time column, in input order.
  *   raw          [n_rows, raw_cols] float32, the concatenated contents of the .bin files (raw_cols = 5)
- *   sweeps_dev   [n_sweeps] descriptors IN DEVICE MEMORY, consecutive row ranges covering [0, n_rows)
+ *   sweeps_dev   [n_sweeps] descriptors IN DEVICE MEMORY, consecutive row ranges starting at row 0.  n_rows is an UPPER BOUND
+ *                (ABI 7): rows at or past the last descriptor's row_end are dropped, so a fixed-capacity buffer whose fill is only
+ *                known to the descriptors can be assembled by a launch captured once (FullSweepStep, detectors.py)
  *                m = transform_matrix (row-major 4x4, float64 as the reference's np.dot evaluates it; ignored
  *                unless FD_SWEEP_HAS_TRANSFORM), time = float32(time_lag) (0 for the key frame)
  *   out_points   [n_rows, keep_cols + 1] float32; rows [0, *out_count) are the reference's
@@ -358,6 +360,36 @@ int fd_det_to_global_boxes(const float *box3d9, int n, const double *cs_rotation
  * (all three coordinates, distance_matrix :100-110) are closer than match_thresh are linked; ids[i] = index of box i's
  * connected component, components numbered by their smallest member (networkx's enumeration order).  n <= 8192. */
 int fd_forecast_groups(const double *centers3, int n, double match_thresh, int32_t *ids, fd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The three calls above for a whole batch, device-resident and capturable (ABI 7): from the head's packed output
+ * (fd_centerpoint_decode_packed: packed [B, T, post, row_floats] float32 rows = box 9 + score + label, counts [B, T]) to what
+ * `forecast_boxes` + `tracker` + `multi_future` produce for each sweep (det3d/datasets/nuscenes/nuscenes.py:384-494 with
+ * forecast_mode "velocity_dense", :125-257, :299-339; nusc_common.py:167-216), as arrays:
+ *   records_dev  [B][14] float64 in DEVICE memory: calibrated_sensor rotation (w,x,y,z), translation (x,y,z), ego_pose rotation,
+ *                translation of every sample (the devkit look-ups of nuscenes.py:385-398 are the caller's); NULL = lidar frame.
+ *                Device memory, because a captured graph is replayed for other samples: nothing of a sample is a kernel argument
+ *   time_dev     [B][T-1] float64: seconds between consecutive forecast steps (get_time, nuscenes.py:399-406)
+ *   out->center / quat / velocity [B,T,post,3|4|3] float64, size [B,T,post,3] float32: every slot's global-frame box
+ *   out->fwd_idx ... status: fd_forecast_chains' outputs per sample ([B, ...] in front of the shapes documented there, n_max = post)
+ *   out->traj_kind / traj_src / traj_first / traj_group [B, 3*post] int32, n_traj [B] (all five or none): the sweep's trajectories in
+ *                tracker's order -- kind 0 = forward chain of step-0 box src (fwd_idx[src][:]), 1 = constant-velocity roll-out of
+ *                step-0 box src (cv_centers[src][:]), 2 = back-cast chain of last-step box src (bwd_idx[src][::-1]); first = the
+ *                step-0 box the trajectory begins with; group = multi_future's forecast_id among the sweep's trajectories (components
+ *                of "first boxes closer than match_thresh", numbered by their smallest member).  Entries past n_traj are -1.
+ * Three launches (boxes, association, trajectories); bit-identical to the three single-sweep calls.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct fd_forecast_buffers {
+    double *center, *quat, *velocity;
+    float *size;
+    int32_t *fwd_idx, *fwd_ok, *bwd_idx, *bwd_ok, *match_idx;
+    double *cv_centers;
+    int32_t *status;
+    int32_t *traj_kind, *traj_src, *traj_first, *traj_group, *n_traj;
+} fd_forecast_buffers;
+int fd_forecast_from_detections(const float *packed, const int32_t *counts, int B, int T, int post, int row_floats,
+                                const double *records_dev, const double *time_dev, double reject_thresh, double match_thresh,
+                                const fd_forecast_buffers *out, fd_stream_t stream);
 
 /* The search of process_trajectories (det3d/datasets/nuscenes/nuscenes.py:341-382, forecast_boxes with postprocess=True :465-467):
  * idx[i] = argmin_j || library[j] - queries[i] || over the rows of a trajectory library [n_library, dim] (float64, row =

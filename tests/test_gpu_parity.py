@@ -2481,3 +2481,127 @@ def test_street_scene_with_few_detections(hip, precision):
     assert not step.overflowed()
     k = int(want_p[3].max())
     assert torch.equal(want_p[3], got_p[3]) and torch.equal(want_p[0][:, :, :k], got_p[0][:, :, :k]) and torch.equal(want_p[1][:, :, :k], got_p[1][:, :, :k])
+
+
+# ------------------------------------------------------------------------------------------------ FutureDet end to end (8f-2 + A15 + 8f-3)
+def _random_packed(rng, B, T, post, counts):
+    packed = np.zeros((B, T, post, 11), np.float32)
+    for b in range(B):
+        base = rng.uniform(-40, 40, (post, 2))
+        for t in range(T):
+            n = int(counts[b, t])
+            xy = base[rng.permutation(post)[:n]] + rng.normal(0, 0.4, (n, 2)) + 0.3 * t
+            packed[b, t, :n, :2] = xy
+            packed[b, t, :n, 2] = rng.normal(-1, 0.3, n)
+            packed[b, t, :n, 3:6] = rng.uniform(0.5, 5, (n, 3))
+            packed[b, t, :n, 6:8] = rng.normal(0, 3, (n, 2))
+            packed[b, t, :n, 8] = rng.uniform(-4, 4, n)
+            packed[b, t, :n, 9] = rng.uniform(0.1, 1, n)
+            packed[b, t, :n, 10] = t
+    return packed
+
+
+@pytest.mark.gpu
+def test_forecast_from_detections_equals_the_single_sweep_calls_and_the_oracle(hip):
+    """fd_forecast_from_detections (one call per batch, everything of a sample in device memory) against (a) the three single-sweep entry
+    points it batches -- fd_det_to_global_boxes, fd_forecast_chains, fd_forecast_groups, each pinned by the reference's goldens above --
+    bit for bit, and (b) the CPU restatement (oracle/forecast.py: tracker's trajectory list and order, multi_future's ids).  Cases: full
+    steps, ragged steps, a sample with an empty step (tracker returns no trajectory), duplicated first boxes (one forecast group)."""
+    from futuredet_amd import forecast, hip_ops
+    from oracle import forecast as oforecast
+
+    rng = np.random.default_rng(5)
+    B, T, post = 4, 7, 83
+    counts = np.array([[83] * T, list(rng.integers(20, 83, T)), [30, 31, 0, 29, 30, 31, 32], [40] * T], np.int32)
+    packed = _random_packed(rng, B, T, post, counts)
+    packed[3, 0, 1, :3] = packed[3, 0, 0, :3] + np.float32(0.05)   # two first boxes closer than 0.25 m: one forecast id
+    time = rng.uniform(0.4, 0.6, (B, T - 1))
+    rec = np.zeros((B, 14))
+    for b in range(B):
+        q1, q2 = rng.normal(0, 1, 4), rng.normal(0, 1, 4)
+        rec[b] = np.concatenate([q1 / np.linalg.norm(q1) * (1.0 if b else 1.0 + 1e-9), rng.normal(0, 2, 3), q2 / np.linalg.norm(q2), rng.normal(0, 300, 3)])
+    out = forecast.sweep_forecast(_dev(packed), _dev(counts), _dev(time), _dev(rec), classname="car")
+    out = forecast.sweep_forecast(_dev(packed), _dev(counts), _dev(time), _dev(rec), classname="car", out=out)  # (buffers are reused)
+    h = out.host()
+    n_traj_total = 0
+    for b in range(B):
+        cs, pose = (rec[b, :4], rec[b, 4:7]), (rec[b, 7:11], rec[b, 11:14])
+        c, q, v, s = hip_ops.det_to_global_boxes(_dev(packed[b].reshape(-1, 11)[:, :9].copy()), cs, pose)
+        for name, t_ in (("center", c), ("quat", q), ("velocity", v), ("size", s)):
+            assert np.array_equal(h[name][b].reshape(t_.shape), t_.cpu().numpy()), (b, name)
+        single = hip_ops.forecast_chains(c.reshape(T, post, 3), v.reshape(T, post, 3), _dev(counts[b]), _dev(time[b]), 2.0)
+        for name in ("fwd_idx", "fwd_ok", "bwd_idx", "bwd_ok", "match_idx", "cv_centers"):
+            assert np.array_equal(h[name][b], single[name].cpu().numpy()), (b, name)
+        assert int(h["status"][b]) == int(single["status"].cpu()[0]) == int((counts[b] == 0).any())
+        # the oracle's tracker on the same global boxes: trajectory list, order, centres
+        cen = [h["center"][b, t, :counts[b, t]] for t in range(T)]
+        vel = [h["velocity"][b, t, :counts[b, t]] for t in range(T)]
+        want = oforecast.tracker("car", list(time[b]), cen, vel)
+        got = forecast.trajectories_from_arrays(h, b)
+        if want is None:
+            assert got == [] and int(h["n_traj"][b]) == 0 and (h["traj_kind"][b] == -1).all()
+            continue
+        fwd, cv, bwd = want
+        assert [k for k, _, _, _ in got] == [0] * len(fwd) + [1] * len(cv) + [2] * len(bwd), b
+        for (kind, gid, centres, idx), ref in zip(got, list(fwd) + [None] * len(cv) + list(bwd)):
+            if ref is not None:
+                assert list(idx) == list(ref)
+        for j, i in enumerate(range(len(fwd), len(fwd) + len(cv))):
+            assert np.array_equal(got[i][2], cv[j]), (b, j)
+        firsts = np.stack([tr[2][0] for tr in got])
+        ids = oforecast.forecast_ids(firsts)
+        assert np.array_equal(np.array([tr[1] for tr in got]), ids), b
+        assert np.array_equal(hip_ops.forecast_groups(_dev(firsts), 0.25).cpu().numpy(), ids)
+        if b == 3:
+            assert got[len(fwd)][1] == got[len(fwd) + 1][1], "the two near-identical first boxes share a forecast id"
+        n_traj_total += len(got)
+    report("forecast from detections: %d sweeps, %d trajectories, boxes / chains / ids identical to the single-sweep calls and the oracle" % (B, n_traj_total), 0.0, 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,precision", [("forecast_n0", "fp32"), ("forecast_n3", "bf16")])
+def test_full_sweep_step_equals_assembly_plus_sweep_plus_forecast(hip, variant, precision):
+    """FullSweepStep -- raw sweeps + transforms -> fd_sweep_assemble -> whole sweep -> fd_forecast_from_detections as ONE captured
+    graph -- against the same three stages run one by one (eager assembly of the same raw rows, forward_points on the assembled cloud,
+    the forecast call on its detections): detections and every forecast array bit-identical, for two clouds per pass, replayed on clouds
+    other than the one it was captured with (different raw row counts, different descriptors)."""
+    from futuredet_amd import forecast, hip_ops
+    from futuredet_amd.detectors import FullSweepStep
+    from futuredet_amd.synth import synthetic_sweeps
+
+    cfg, net, _ = _build_pair(variant)
+    if precision == "bf16":
+        net.set_precision(torch.bfloat16)
+
+    def sample(seed, n):
+        raw, rows, mats, lags, close = synthetic_sweeps(seed=seed, target_points=n)
+        desc = hip_ops.sweep_descriptors(rows, mats, lags, close)
+        rng = np.random.default_rng(seed)
+        q1, q2 = rng.normal(0, 1, 4), rng.normal(0, 1, 4)
+        rec = np.concatenate([q1 / np.linalg.norm(q1), rng.normal(0, 2, 3), q2 / np.linalg.norm(q2), rng.normal(0, 300, 3)])
+        return dict(raw=_dev(raw), desc=torch.from_numpy(desc.view(np.uint8).reshape(-1).copy()).cuda(), time=_dev(rng.uniform(0.4, 0.6, 6)),
+                    records=_dev(rec), host_desc=desc)
+
+    samples = [sample(s, n) for s, n in ((11, 40000), (12, 60000), (13, 25000), (14, 52000))]
+    step = FullSweepStep(net, cfg.voxel_generator, capacity=70000, n_sweeps=10, batch_size=2)
+    with torch.no_grad():
+        step.warm_up(samples[:2])
+        for pair in (samples[:2], samples[2:], [samples[3], samples[0]]):
+            packed, counts = [t.clone() for t in step(pair)]
+            got = step.forecast.host()
+            clouds = []
+            for smp in pair:
+                pts, cnt = hip_ops.assemble_sweeps(smp["raw"], smp["host_desc"])
+                clouds.append(pts[: int(cnt.cpu()[0])].contiguous())
+            want_p, want_c = net.forward_points(clouds, cfg.voxel_generator, padded="packed")
+            assert torch.equal(want_c, counts)
+            for b in range(2):
+                for t in range(counts.shape[1]):
+                    k = int(counts[b, t])
+                    assert torch.equal(want_p[b, t, :k], packed[b, t, :k]), (b, t)
+            want = forecast.sweep_forecast(packed, counts, torch.stack([s["time"] for s in pair]), torch.stack([s["records"] for s in pair]), "car").host()
+            for name in want:
+                assert np.array_equal(want[name], got[name], equal_nan=True), name
+            assert int(counts.sum()) > 0 and int(got["n_traj"].sum()) > 0
+    report("full sweep step (%s %s): detections and forecast arrays bit-identical to assembly + sweep + forecast run one by one" % (variant, precision), 0.0, 0.0,
+           "(%d detections, %d trajectories in the last pass)" % (int(counts.sum()), int(got["n_traj"].sum())))

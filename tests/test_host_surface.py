@@ -191,7 +191,7 @@ def test_c_abi_exports_every_declared_symbol():
     nm = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (fd_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
-    assert L.fd_abi_version() == 6
+    assert L.fd_abi_version() == 7
     assert L.fd_index_num_cols(2, 180, 180) == 2 * 23 * 23 * 64
     assert L.fd_voxelize_workspace_bytes(1000, 100) > 0 and L.fd_nms_workspace_bytes(1000) >= 1000 * 16 * 8
 
