@@ -34,7 +34,7 @@ struct FcArgs {
 
 // One workgroup per sweep (blockIdx.x = sample of a batch; every array of FcArgs is the first sample's, the others follow at the
 // array's own size).
-__global__ void __launch_bounds__(256) forecast_chains(FcArgs a) {
+__global__ void __launch_bounds__(1024) forecast_chains(FcArgs a) {
     __shared__ int s_idx[2][kMaxT - 1][kMaxN];
     __shared__ double s_dist[2][kMaxT - 1][kMaxN];
     __shared__ int s_cnt[kMaxT];
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) forecast_chains(FcArgs a) {
     __syncthreads();
     if (tid < T && s_cnt[tid] == 0) s_empty = 1;  // tracker returns [] when any step is empty (nuscenes.py:150-158)
     // ---- all nearest-centre matchings: dir 0 = forward (curr + tm*v -> next), dir 1 = back-cast (curr - tm*v -> previous)
-    for (int w = tid; w < 2 * (T - 1) * N; w += 256) {
+    for (int w = tid; w < 2 * (T - 1) * N; w += (int)blockDim.x) {
         const int dir = w / ((T - 1) * N), r = w % ((T - 1) * N), s = r / N, i = r % N;
         // forward step s: current = t_s, other = t_{s+1}, tm = time[s]; backward step s: current = t_{T-1-s}, other = t_{T-2-s}, tm = time[T-2-s]
         const int tc = dir == 0 ? s : T - 1 - s, to = dir == 0 ? s + 1 : T - 2 - s;
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) forecast_chains(FcArgs a) {
         s_dist[dir][s][i] = bd;
     }
     // ---- match_boxes (nuscenes.py:112-123): every step's boxes re-ordered by nearest centre to the step-0 boxes
-    for (int w = tid; w < T * N; w += 256) {
+    for (int w = tid; w < T * N; w += (int)blockDim.x) {
         const int t = w / N, i = w % N;
         int best = 0;
         if (i < s_cnt[0] && s_cnt[t] > 0) {
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) forecast_chains(FcArgs a) {
     __syncthreads();
     if (tid == 0) a.status[0] = s_empty;
     // ---- chains (nuscenes.py:160-173, 222-237): follow the matches, void when a hop is farther than the reject threshold
-    for (int w = tid; w < 2 * N; w += 256) {
+    for (int w = tid; w < 2 * N; w += (int)blockDim.x) {
         const int dir = w / N, i = w % N;
         const int tstart = dir == 0 ? 0 : T - 1;
         int *out = (dir == 0 ? a.fwd_idx : a.bwd_idx) + (size_t)i * T;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) forecast_chains(FcArgs a) {
         (dir == 0 ? a.fwd_ok : a.bwd_ok)[i] = ok;
     }
     // ---- constant velocity forward (nuscenes.py:183-193): center_{s+1} = center_s + time[s] * velocity(step-0 box), all 3 axes
-    for (int w = tid; w < N * 3; w += 256) {
+    for (int w = tid; w < N * 3; w += (int)blockDim.x) {
         const int i = w / 3, ax = w % 3;
         double c = a.centers[(size_t)i * 3 + ax];
         const double v = a.velocity[(size_t)i * 3 + ax];
@@ -279,6 +279,7 @@ __global__ void __launch_bounds__(1024) forecast_traj_groups_kernel(const double
     __shared__ int s_first[kMaxTraj];
     __shared__ int s_scan[kMaxN + 1];
     __shared__ int s_n[3];
+    extern __shared__ unsigned s_adj[];  // [n][ceil(n / 32)] adjacency bits, n <= 3 N
     const size_t b = blockIdx.x;
     const int tid = threadIdx.x;
     centers += b * T * N * 3; counts += b * T; fwd_ok += b * N; bwd_ok += b * N; bwd_idx += b * N * T; status += b;
@@ -312,12 +313,28 @@ __global__ void __launch_bounds__(1024) forecast_traj_groups_kernel(const double
     for (int i = tid; i < n; i += 1024) { traj_first[i] = s_first[i]; s_label[i] = i; }
     for (int i = n + tid; i < 3 * N; i += 1024) { traj_kind[i] = -1; traj_src[i] = -1; traj_first[i] = -1; traj_group[i] = -1; }
     __syncthreads();
-    // min-label propagation over the "closer than thresh" graph of the first boxes' centres (all three coordinates), as in forecast_groups_kernel
+    // adjacency of the "closer than thresh" graph of the first boxes' centres (all three coordinates), one bit per ordered pair, computed ONCE
+    // by all threads (n^2 float64 distances: the label sweeps below then only walk bits); then min-label propagation as in
+    // forecast_groups_kernel
+    const int nw = (n + 31) >> 5;
+    for (int t = tid; t < n * nw; t += 1024) s_adj[t] = 0u;
+    __syncthreads();
+    for (int t = tid; t < n * n; t += 1024) {
+        const int i = t / n, j = t - i * n;
+        if (dist3d(centers + (size_t)s_first[i] * 3, centers + (size_t)s_first[j] * 3) < thresh) atomicOr(&s_adj[i * nw + (j >> 5)], 1u << (j & 31));
+    }
+    __syncthreads();
     for (int it = 0; it < n; ++it) {
         int best = tid < n ? s_label[tid] : 0;
         if (tid < n)
-            for (int j = 0; j < n; ++j)
-                if (s_label[j] < best && dist3d(centers + (size_t)s_first[tid] * 3, centers + (size_t)s_first[j] * 3) < thresh) best = s_label[j];
+            for (int w = 0; w < nw; ++w) {
+                unsigned m = s_adj[tid * nw + w];
+                while (m) {
+                    const int j = (w << 5) + __builtin_ctz(m);
+                    m &= m - 1u;
+                    best = min(best, s_label[j]);
+                }
+            }
         __syncthreads();
         int changed = 0;
         if (tid < n && best != s_label[tid]) { s_label[tid] = best; changed = 1; }
@@ -411,7 +428,7 @@ extern "C" int fd_forecast_chains(const double *centers, const double *velocity,
     FD_REQUIRE(T >= 2 && T <= kMaxT, "fd_forecast_chains: T must be in [2,%d]", kMaxT);
     FD_REQUIRE(n_max >= 1 && n_max <= kMaxN, "fd_forecast_chains: n_max must be in [1,%d]", kMaxN);
     FcArgs a{centers, velocity, counts, time_dev, T, n_max, reject_thresh, fwd_idx, fwd_ok, bwd_idx, bwd_ok, match_idx, status, cv_centers};
-    hipLaunchKernelGGL(forecast_chains, dim3(1), dim3(256), 0, fd::as_stream(stream), a);
+    hipLaunchKernelGGL(forecast_chains, dim3(1), dim3(1024), 0, fd::as_stream(stream), a);
     return fd::check_launch("fd_forecast_chains");
 }
 
@@ -438,9 +455,16 @@ extern "C" int fd_forecast_from_detections(const float *packed, const int32_t *c
                        out->center, out->quat, out->velocity, out->size);
     FcArgs a{out->center, out->velocity, counts, time_dev, T, post, reject_thresh, out->fwd_idx, out->fwd_ok, out->bwd_idx, out->bwd_ok, out->match_idx,
              out->status, out->cv_centers};
-    hipLaunchKernelGGL(forecast_chains, dim3((unsigned)B), dim3(256), 0, stream, a);
-    if (groups)
-        hipLaunchKernelGGL(forecast_traj_groups_kernel, dim3((unsigned)B), dim3(1024), 0, stream, out->center, counts, out->fwd_ok, out->bwd_ok, out->bwd_idx,
+    hipLaunchKernelGGL(forecast_chains, dim3((unsigned)B), dim3(1024), 0, stream, a);
+    if (groups) {
+        const size_t adj = (size_t)(3 * post) * ((3 * post + 31) / 32) * sizeof(unsigned);  // 8 KB at post = 83, 72 KB at the 256-box limit
+        static std::atomic<uint64_t> lds_set{0};
+        if (adj + 8 * 1024 > 65536 && !fd::ensure_dynamic_lds(reinterpret_cast<const void *>(forecast_traj_groups_kernel), adj, lds_set)) {
+            fd::set_error("fd_forecast_from_detections: the runtime refused %zu bytes of LDS for the trajectory groups", adj);
+            return FD_ELAUNCH;
+        }
+        hipLaunchKernelGGL(forecast_traj_groups_kernel, dim3((unsigned)B), dim3(1024), adj, stream, out->center, counts, out->fwd_ok, out->bwd_ok, out->bwd_idx,
                            out->status, T, post, match_thresh, out->traj_kind, out->traj_src, out->traj_first, out->traj_group, out->n_traj);
+    }
     return fd::check_launch("fd_forecast_from_detections");
 }

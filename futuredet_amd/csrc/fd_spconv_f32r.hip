@@ -38,8 +38,6 @@ __global__ void __launch_bounds__(NW * 64) spconv_f32_res16(const float *__restr
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in), 0, (int)in_bytes, 0x00020000);
     const unsigned lane_off = (unsigned)(lq * 16);  // channels 4 lq .. + 3 of a 64-byte row
 
-    for (int i = tid; i < K * NB * 64; i += NW * 64) s_w[i] = wp[i];
-    __syncthreads();
     // a contiguous chunk of tiles per workgroup (XCD-contiguous eighths, see fd_spconv_bf16.hip), walked NW tiles at a time
     const unsigned lb = fd::xcd_swizzle(blockIdx.x, gridDim.x);
     const int n_tiles = (n_out + ROWS - 1) / ROWS;
@@ -68,15 +66,47 @@ __global__ void __launch_bounds__(NW * 64) spconv_f32_res16(const float *__restr
         }
     };
     for (int r = lane; r < ROWS; r += 64) s[2 * kSliceInts + r] = -1;  // the 'no neighbour' row
-    if (n_iter > 0) request_slice(0);
+    // The residual rows of a tile are requested ONE TILE AHEAD, together with its rulebook slice, and the accumulators start from
+    // bias + residual: the epilogue has no global load left.  (Round 3-5 loaded them in the epilogue: one exposed memory round trip per
+    // 16-row tile of a wave whose whole tile takes ~5 us.)
+    f32x4 r_next[RG][NB];
+    auto request_residual = [&](int it) {
+        const int row0 = (tile_first + it * NW) * ROWS;
+#pragma unroll
+        for (int g = 0; g < RG; ++g) {
+            const int row = row0 + 16 * g + lrow;
+            const int64_t rb = (int64_t)(row < n_out ? row : 0) * COUT;  // (clamped address; rows past the end are never stored)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) r_next[g][nb] = *reinterpret_cast<const f32x4 *>(residual + rb + 16 * nb + 4 * lq);
+        }
+    };
+    if (n_iter > 0) {
+        request_slice(0);
+        if (residual) request_residual(0);
+    }
+    // the weights travel together with the first slice (one round trip at the start of a workgroup's life instead of two)
+    for (int i = tid; i < K * NB * 64; i += NW * 64) s_w[i] = wp[i];
+    __syncthreads();
 
     for (int it = 0; it < n_iter; ++it) {
         const int row0 = (tile_first + it * NW) * ROWS;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Wait for this tile's slice (LDS-DMA), not for everything: vector-memory operations of a wave complete in issue order on gfx9, and
+        // the only ones issued after the slice (+ residual) request that can still be pending are the previous tile's RG * NB output stores
+        // (its gathers were consumed).  vmcnt(0) here made every tile wait for the previous tile's store round trip.
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RG * NB) : "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (it + 1 < n_iter) request_slice(it + 1);
+        f32x4 r_cur[RG][NB];
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) r_cur[g][nb] = residual ? r_next[g][nb] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (it + 1 < n_iter) {
+            request_slice(it + 1);
+            if (residual) request_residual(it + 1);
+        }
         const int *sl = s + (it & 1) * kSliceInts;
         bool valid[RG];
 #pragma unroll
@@ -88,7 +118,7 @@ __global__ void __launch_bounds__(NW * 64) spconv_f32_res16(const float *__restr
             f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (bias) bv = *reinterpret_cast<const f32x4 *>(bias + 16 * nb + 4 * lq);
 #pragma unroll
-            for (int g = 0; g < RG; ++g) acc[g][nb] = bv;
+            for (int g = 0; g < RG; ++g) acc[g][nb] = bv + r_cur[g][nb];
         }
         // taps that have a pair among this wave's rows (OR over the lanes' entries of the slice)
         unsigned mine = 0u;
@@ -163,7 +193,6 @@ __global__ void __launch_bounds__(NW * 64) spconv_f32_res16(const float *__restr
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 f32x4 v = acc[g][nb];
-                if (residual) v += *reinterpret_cast<const f32x4 *>(residual + rb + 16 * nb + 4 * lq);
                 if (relu) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
@@ -205,14 +234,14 @@ int spconv_f32_res16_dispatch(const float *in, const void *wp, const float *bias
     if (cout == 32 && fd::tuning(fd::kTuneF32ResRG) < 32) return 0;
     const unsigned in_bytes = (unsigned)(n_in_bound * 64);
     const int rg = fd::tuning(fd::kTuneF32ResRG);
-    const int nw = fd::tuning(fd::kTuneF32ResNW);  // 16: one 1024-thread workgroup per CU (round 3-5); default 14: two per CU (LDS 78.7 KB each)
+    const int nw = fd::tuning(fd::kTuneF32ResNW);  // waves per workgroup (A/B runs): 0 / 16 = one 1024-thread workgroup per CU; 14 / 12 = two per CU; 8 = three
 #define FD_RES(CO, RGV, NWV) launch_res16<CO, RGV, 4, NWV>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, n_expected, out, in_bytes, stream)
     if (cout == 16) {
         if (rg >= 2) return FD_RES(16, 2, 16);
-        if (nw == 16) return FD_RES(16, 1, 16);
+        if (nw == 14) return FD_RES(16, 1, 14);  // two workgroups per CU (28 waves): measured no faster than one of 16 (27.3 vs 29.4 us, round 6)
         if (nw == 12) return FD_RES(16, 1, 12);
         if (nw == 8) return FD_RES(16, 1, 8);
-        return FD_RES(16, 1, 14);
+        return FD_RES(16, 1, 16);
     }
     return FD_RES(32, 1, 16);
 #undef FD_RES
