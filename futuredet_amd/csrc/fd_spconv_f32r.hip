@@ -24,7 +24,7 @@ constexpr int kMaxTaps = 27;
 template <int COUT, int RG, int DEPTH, int NW>
 __global__ void __launch_bounds__(NW * 64) spconv_f32_res16(const float *__restrict__ in, const f32x4 *__restrict__ wp, const float *__restrict__ bias,
                                                          const float *__restrict__ residual, int relu, const int *__restrict__ nbr, int64_t nbr_stride,
-                                                         int K, int n_out, const int *__restrict__ n_out_dev, float *__restrict__ out, unsigned in_bytes) {
+                                                         int K, int n_out, const int *__restrict__ n_out_dev, float *__restrict__ out, unsigned in_bytes, int interleave) {
     constexpr int NB = COUT / 16, ROWS = 16 * RG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4 *s_w = reinterpret_cast<f32x4 *>(smem);                              // [K][NB][64]: fd_spconv_pack_weight's fp32 fragment order
@@ -43,13 +43,19 @@ __global__ void __launch_bounds__(NW * 64) spconv_f32_res16(const float *__restr
     const int n_tiles = (n_out + ROWS - 1) / ROWS;
     const int tpb = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t_lo = (int)lb * tpb, t_hi = t_lo + tpb < n_tiles ? t_lo + tpb : n_tiles;
-    const int tile_first = t_lo + wave;
-    const int n_iter = tile_first < t_hi ? (t_hi - tile_first + NW - 1) / NW : 0;
+    int tile_first = t_lo + wave;
+    int n_iter = tile_first < t_hi ? (t_hi - tile_first + NW - 1) / NW : 0;
+    int tile_step = NW;
+    if (interleave) {  // all workgroups sweep the row range together: tile = it * (grid * NW) + block * NW + wave
+        tile_first = (int)blockIdx.x * NW + wave;
+        tile_step = (int)gridDim.x * NW;
+        n_iter = tile_first < n_tiles ? (n_tiles - tile_first + tile_step - 1) / tile_step : 0;
+    }
 
     constexpr int NPRE = (kMaxTaps * ROWS + 63) / 64;
     static_assert(NPRE * 64 <= kSliceInts, "a slice buffer takes whole DMA instructions");
     auto request_slice = [&](int it) {
-        const int row0 = (tile_first + it * NW) * ROWS;
+        const int row0 = (tile_first + it * tile_step) * ROWS;
         int *dst = s + (it & 1) * kSliceInts;
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
@@ -71,7 +77,7 @@ __global__ void __launch_bounds__(NW * 64) spconv_f32_res16(const float *__restr
     // 16-row tile of a wave whose whole tile takes ~5 us.)
     f32x4 r_next[RG][NB];
     auto request_residual = [&](int it) {
-        const int row0 = (tile_first + it * NW) * ROWS;
+        const int row0 = (tile_first + it * tile_step) * ROWS;
 #pragma unroll
         for (int g = 0; g < RG; ++g) {
             const int row = row0 + 16 * g + lrow;
@@ -89,7 +95,7 @@ __global__ void __launch_bounds__(NW * 64) spconv_f32_res16(const float *__restr
     __syncthreads();
 
     for (int it = 0; it < n_iter; ++it) {
-        const int row0 = (tile_first + it * NW) * ROWS;
+        const int row0 = (tile_first + it * tile_step) * ROWS;
         // Wait for this tile's slice (LDS-DMA), not for everything: vector-memory operations of a wave complete in issue order on gfx9, and
         // the only ones issued after the slice (+ residual) request that can still be pending are the previous tile's RG * NB output stores
         // (its gathers were consumed).  vmcnt(0) here made every tile wait for the previous tile's store round trip.
@@ -218,7 +224,7 @@ int launch_res16(const float *in, const void *wp, const float *bias, const float
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, in, (const f32x4 *)wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev,
-                       out, in_bytes);
+                       out, in_bytes, fd::tuning(fd::kTuneV2Uniform) == 7 ? 1 : 0);
     return 1;
 }
 
@@ -235,7 +241,14 @@ int spconv_f32_res16_dispatch(const float *in, const void *wp, const float *bias
     const unsigned in_bytes = (unsigned)(n_in_bound * 64);
     const int rg = fd::tuning(fd::kTuneF32ResRG);
     const int nw = fd::tuning(fd::kTuneF32ResNW);  // waves per workgroup (A/B runs): 0 / 16 = one 1024-thread workgroup per CU; 14 / 12 = two per CU; 8 = three
-#define FD_RES(CO, RGV, NWV) launch_res16<CO, RGV, 4, NWV>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, n_expected, out, in_bytes, stream)
+#define FD_RESD(CO, RGV, NWV, DV) launch_res16<CO, RGV, DV, NWV>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, n_expected, out, in_bytes, stream)
+#define FD_RES(CO, RGV, NWV) FD_RESD(CO, RGV, NWV, 4)
+    const int dsel = fd::tuning(fd::kTuneV2Depth);  // gather ring depth (A/B runs: "v2_depth" = 8 | 12)
+    if (cout == 16 && rg < 2 && (nw == 0 || nw == 16)) {
+        if (dsel == 8) return FD_RESD(16, 1, 16, 8);
+        if (dsel == 12) return FD_RESD(16, 1, 16, 12);
+        if (dsel == 16) return FD_RESD(16, 1, 16, 16);
+    }
     if (cout == 16) {
         if (rg >= 2) return FD_RES(16, 2, 16);
         if (nw == 14) return FD_RES(16, 1, 14);  // two workgroups per CU (28 waves): measured no faster than one of 16 (27.3 vs 29.4 us, round 6)
@@ -245,5 +258,6 @@ int spconv_f32_res16_dispatch(const float *in, const void *wp, const float *bias
     }
     return FD_RES(32, 1, 16);
 #undef FD_RES
+#undef FD_RESD
 }
 }  // namespace fd
