@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfuturedet_hip.so")
-SOURCES = ["fd_error.hip", "fd_voxelize.hip", "fd_index.hip", "fd_spconv.hip", "fd_spconv_v2.hip", "fd_spconv_c32.hip", "fd_spconv_f32r.hip", "fd_spconv_tiles.hip", "fd_spconv_bf16.hip", "fd_spconv_bf16win.hip", "fd_densify.hip", "fd_conv2d.hip", "fd_conv2d_f32.hip", "fd_conv2d_wino.hip", "fd_conv2d_wino_pc.hip", "fd_decode.hip", "fd_sweeps.hip", "fd_pillars.hip", "fd_forecast.hip"]
+SOURCES = ["fd_error.hip", "fd_voxelize.hip", "fd_index.hip", "fd_spconv.hip", "fd_spconv_v2.hip", "fd_spconv_c32.hip", "fd_spconv_f32r.hip", "fd_spconv_bf16.hip", "fd_spconv_bf16win.hip", "fd_densify.hip", "fd_conv2d.hip", "fd_conv2d_f32.hip", "fd_conv2d_wino.hip", "fd_conv2d_wino_pc.hip", "fd_decode.hip", "fd_sweeps.hip", "fd_pillars.hip", "fd_forecast.hip"]
 # geometry / voxel membership follow the reference's operation order: no fma contraction there
 EXTRA = {"fd_decode.hip": ["-ffp-contract=off"], "fd_sweeps.hip": ["-ffp-contract=off"], "fd_forecast.hip": ["-ffp-contract=off"], "fd_voxelize.hip": ["-ffp-contract=off"]}
 

@@ -83,7 +83,7 @@ int device_cu_count();  // compute units of the current device, cached per devic
 bool ensure_dynamic_lds(const void *kernel, size_t bytes, std::atomic<uint64_t> &done);
 // Tuning / test knobs (fd_tuning_set; initial values are read ONCE from the FD_* environment variables when the
 // library is loaded).  0 = the built-in heuristic.
-enum TuneKey { kTuneSpconvRG = 0, kTuneSpconvV1, kTuneSpconvBf16V1, kTuneV2Depth, kTuneV2TM, kTuneV2LdsPad, kTuneConvNT, kTuneV2RangesPerCU, kTuneV2Uniform, kTuneV2RowCost, kTuneSpconvC32, kTuneBf16GP, kTuneBf16RG, kTuneBf16Depth, kTuneBf16NW, kTuneStrict, kTuneBf16Win, kTuneF32ResRG, kTuneConvStrip, kTuneF32ResNW, kTuneSpconvTiles, kTuneCount };
+enum TuneKey { kTuneSpconvRG = 0, kTuneSpconvV1, kTuneSpconvBf16V1, kTuneV2Depth, kTuneV2TM, kTuneV2LdsPad, kTuneConvNT, kTuneV2RangesPerCU, kTuneV2Uniform, kTuneV2RowCost, kTuneSpconvC32, kTuneBf16GP, kTuneBf16RG, kTuneBf16Depth, kTuneBf16NW, kTuneStrict, kTuneBf16Win, kTuneF32ResRG, kTuneConvStrip, kTuneF32ResNW, kTuneCount };
 int tuning(TuneKey key);
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

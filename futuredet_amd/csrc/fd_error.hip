@@ -57,7 +57,7 @@ struct TuneTable {
     std::atomic<int> v[kTuneCount];
     TuneTable() {
         static const char *const env[kTuneCount] = {"FD_SPCONV_RG", "FD_SPCONV_V1", "FD_SPCONV_BF16_V1", "FD_V2_DEPTH", "FD_V2_TM",
-                                                    "FD_V2_LDSPAD", "FD_CONV_NT", "FD_V2_RANGES_PER_CU", "FD_V2_UNIFORM", "FD_V2_ROWCOST", "FD_SPCONV_C32", "FD_BF16_GP", "FD_BF16_RG", "FD_BF16_DEPTH", "FD_BF16_NW", "FD_STRICT", "FD_BF16_WIN", "FD_F32_RES_RG", "FD_CONV_STRIP", "FD_F32_RES_NW", "FD_SPCONV_TILES"};
+                                                    "FD_V2_LDSPAD", "FD_CONV_NT", "FD_V2_RANGES_PER_CU", "FD_V2_UNIFORM", "FD_V2_ROWCOST", "FD_SPCONV_C32", "FD_BF16_GP", "FD_BF16_RG", "FD_BF16_DEPTH", "FD_BF16_NW", "FD_STRICT", "FD_BF16_WIN", "FD_F32_RES_RG", "FD_CONV_STRIP", "FD_F32_RES_NW"};
         for (int i = 0; i < kTuneCount; ++i) {
             const char *e = getenv(env[i]);
             v[i].store(e ? atoi(e) : 0, std::memory_order_relaxed);
@@ -68,7 +68,7 @@ TuneTable &tune_table() {
     static TuneTable t;  // constructed once, thread-safe (C++11); the environment is read here and nowhere else
     return t;
 }
-const char *const kTuneNames[kTuneCount] = {"spconv_rg", "spconv_v1", "spconv_bf16_v1", "v2_depth", "v2_tm", "v2_ldspad", "conv_nt", "v2_ranges_per_cu", "v2_uniform", "v2_rowcost", "spconv_c32", "bf16_gp", "bf16_rg", "bf16_depth", "bf16_nw", "strict", "bf16_win", "f32_res_rg", "conv_strip", "f32_res_nw", "spconv_tiles"};
+const char *const kTuneNames[kTuneCount] = {"spconv_rg", "spconv_v1", "spconv_bf16_v1", "v2_depth", "v2_tm", "v2_ldspad", "conv_nt", "v2_ranges_per_cu", "v2_uniform", "v2_rowcost", "spconv_c32", "bf16_gp", "bf16_rg", "bf16_depth", "bf16_nw", "strict", "bf16_win", "f32_res_rg", "conv_strip", "f32_res_nw"};
 }  // namespace
 
 int tuning(TuneKey key) { return tune_table().v[key].load(std::memory_order_relaxed); }

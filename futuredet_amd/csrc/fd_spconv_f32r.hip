@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(NW * 64) spconv_f32_res16(const float *__restr
     int tile_first = t_lo + wave;
     int n_iter = tile_first < t_hi ? (t_hi - tile_first + NW - 1) / NW : 0;
     int tile_step = NW;
-    if (interleave) {  // all workgroups sweep the row range together: tile = it * (grid * NW) + block * NW + wave
+    if (interleave) {  // all workgroups sweep the row range together: tile = it * (grid * NW) + block * NW + wave (44.0 -> 40.9 us on two clouds
+                       // against XCD-contiguous chunks per workgroup, round 6; "f32_res_nw" = 1 brings the chunks back for A/B runs)
         tile_first = (int)blockIdx.x * NW + wave;
         tile_step = (int)gridDim.x * NW;
         n_iter = tile_first < n_tiles ? (n_tiles - tile_first + tile_step - 1) / tile_step : 0;
@@ -224,7 +225,7 @@ int launch_res16(const float *in, const void *wp, const float *bias, const float
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, in, (const f32x4 *)wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev,
-                       out, in_bytes, fd::tuning(fd::kTuneV2Uniform) == 7 ? 1 : 0);
+                       out, in_bytes, fd::tuning(fd::kTuneF32ResNW) == 1 ? 0 : 1);
     return 1;
 }
 

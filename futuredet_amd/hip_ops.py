@@ -347,27 +347,6 @@ def pack_spconv_weight(w_kio, dtype=torch.float32):
     return host.to(dev)
 
 
-def tiles_for(nbr, n_out=None):
-    """Compressed tile-local form of a rulebook (fd_rulebook_tiles: one 64-byte record per 16 output rows + the packed input rows of the
-    pairs that exist), built once per rulebook tensor and shared by every convolution that reuses it.  -> (records uint8, packed int32)"""
-    cached = getattr(nbr, "tiles", None)
-    if cached is not None:
-        return cached
-    L = _lib.load()
-    K, nstride = nbr.shape
-    n_out = getattr(nbr, "n_out", None) or n_out or nstride
-    dev = nbr.device
-    records = torch.empty((L.fd_rulebook_tiles_record_bytes(nstride) + 64,), dtype=torch.uint8, device=dev)
-    off = (-records.data_ptr()) % 64
-    records = records[off:off + L.fd_rulebook_tiles_record_bytes(nstride)]
-    packed = torch.empty((K * nstride,), dtype=torch.int32, device=dev)
-    cursor = torch.empty((1,), dtype=torch.int32, device=dev)
-    check(L.fd_rulebook_tiles(_p(nbr), nstride, K, n_out, _p(getattr(nbr, "n_dev", None)), _p(records), _p(packed), packed.numel(), _p(cursor), _stream()),
-          "fd_rulebook_tiles")
-    nbr.tiles = (records, packed, cursor)
-    return nbr.tiles
-
-
 def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=False, out=None, balanced=None):
     L = _lib.load()
     feats = _dev(feats, "feats")
@@ -379,14 +358,6 @@ def spconv_apply(feats, wpacked, bias, nbr, n_out, cout, residual=None, relu=Fal
         out = torch.empty((max(n_out, 1), out_cols), dtype=out_dtype, device=feats.device)[:n_out]
     if residual is not None:
         _dev(residual, "residual", out_dtype)
-    if n_out > 0 and dt in (0, 1) and L.fd_spconv_tiles_supported(cin, cout, dt):
-        # the narrow levels (64-byte feature rows): compressed tile-local rulebook + compact LDS-DMA gather (fd_spconv_tiles.hip)
-        records, packed, _ = tiles_for(nbr, n_out)
-        wp = _dev(wpacked, "wpacked")
-        check(L.fd_spconv_apply_tiles(_p(feats), feats.shape[0], _p(wp), _p(bias), _p(residual), int(bool(relu)), _p(records), _p(packed), K, n_out,
-                                      _p(getattr(nbr, "n_dev", None)), int(getattr(nbr, "n_expected", 0) or 0), cin, cout, dt, _p(out), _stream()),
-              "fd_spconv_apply_tiles")
-        return out
     # fp32: the kernel walks row ranges.  The MFMA-bound SubM layers (Cout >= 64; their rulebook is shared by the 4-5
     # convolutions of a level) get equal-WORK ranges from fd_spconv_ranges; narrow layers and strided convolutions (rulebook
     # used once) take equal row counts -- see fd_spconv_num_ranges for the measurements.

@@ -62,11 +62,6 @@ SIGNATURES = {
     "fd_spconv_pack_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fd_spconv_apply": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_i64, c_void_p, c_int, c_int, c_i64,
                                 c_void_p, c_i64, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "fd_rulebook_tiles_record_bytes": (c_size_t, [c_i64]),
-    "fd_rulebook_tiles": (c_int, [c_void_p, c_i64, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
-    "fd_spconv_tiles_supported": (c_int, [c_int, c_int, c_int]),
-    "fd_spconv_apply_tiles": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_i64, c_int, c_int,
-                                      c_int, c_void_p, c_void_p]),
     "fd_spconv_num_ranges": (c_int, [c_i64, c_int, c_int, c_int]),
     "fd_spconv_wants_balanced_ranges": (c_int, [c_int, c_int, c_int]),
     "fd_spconv_ranges_workspace_bytes": (c_size_t, [c_i64]),

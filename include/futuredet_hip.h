@@ -29,7 +29,7 @@ extern "C" {
 typedef void *fd_stream_t; /* hipStream_t */
 
 int fd_abi_version(void); /* 7 (round 6: + fd_forecast_from_detections / fd_forecast_buffers; fd_sweep_assemble takes n_rows as an upper
-                             * bound -- rows past the last descriptor's row_end are dropped; fd_rulebook_compress ... see INTEGRATION.md) */
+                             * bound -- rows past the last descriptor's row_end are dropped) */
 const char *fd_last_error(void);
 /* Tuning / test knobs (no reference counterpart).  0 = built-in heuristic.  Names: "spconv_rg" (rows per wave of the
  * register sparse-conv kernel: 1|2|4), "spconv_v1" (1: fp32 on the register kernel instead of the compacting one),
@@ -275,31 +275,6 @@ int fd_rotated_nms(const float *boxes7, int n, float thresh, int64_t *keep, int3
                    void *workspace, size_t workspace_bytes, fd_stream_t stream);
 /* pairwise rotated BEV IoU, replaces boxes_iou_bev_gpu (iou3d_nms.cpp:49-69) */
 int fd_boxes_iou_bev(const float *a7, int na, const float *b7, int nb, float *out, fd_stream_t stream);
-
-/* ---------------------------------------------------------------------------------------------------
- * Compressed, tile-local rulebook and the sparse convolution that consumes it (ABI 7): the narrow levels, whose feature rows are
- * 64 bytes (16 fp32 channels: conv_input / conv1 and the strided 16 -> 32 convolution; 32 bf16 channels: conv2's 32 -> 32 layers --
- * det3d/models/backbones/scn.py:99-121).  Same arithmetic as fd_spconv_apply on the dense table (spconv 1.0's indice_conv /
- * indice_subm_conv + folded BatchNorm1d + residual + ReLU), bit-identical results; what changes is the rulebook's form and the gather.
- *   fd_rulebook_tiles        nbr [K][nbr_stride] (fd_rulebook) -> one 64-byte record per 16-row tile of the OUTPUT rows:
- *                              words 0..13   27 row masks, 16 bits each (bit r of mask t: row 16 tile + r has a neighbour under tap t)
- *                              word 14       pairs of the tile;   word 15   offset of the tile's pairs in `packed`
- *                            and packed[]: the input rows of the tile's pairs, tap-major inside the tile, rows ascending inside a tap.
- *                            records: fd_rulebook_tiles_record_bytes(nbr_stride) bytes, 64-byte aligned; packed: capacity >= K * n_out
- *                            int32 (what the pairs can be at most; what is written is 4 x pairs); cursor: device uint32[1] scratch.
- *                            Built once per indice_key, like the table it compresses (4 + 4 x pairs/row bytes per row instead of 108).
- *                            The order of the tiles' segments inside packed[] depends on the order the tiles were built in; nothing
- *                            computed from it does.
- *   fd_spconv_apply_tiles    out[o,:] = act(sum over the pairs of o: in[pair row,:] @ W[tap] + bias (+ residual[o,:])); wpacked / bias /
- *                            residual / relu / n_out_dev / n_expected / dtype as in fd_spconv_apply.  Shapes: fd_spconv_tiles_supported.
- * ------------------------------------------------------------------------------------------------- */
-size_t fd_rulebook_tiles_record_bytes(int64_t n_rows);
-int fd_rulebook_tiles(const int32_t *nbr, int64_t nbr_stride, int K, int64_t n_out, const int32_t *n_out_dev, void *records,
-                      int32_t *packed, int64_t packed_capacity, uint32_t *cursor, fd_stream_t stream);
-int fd_spconv_tiles_supported(int cin, int cout, int dtype);
-int fd_spconv_apply_tiles(const void *in_feats, int64_t n_in, const void *wpacked, const float *bias, const void *residual, int relu,
-                          const void *records, const int32_t *packed, int K, int64_t n_out, const int32_t *n_out_dev,
-                          int64_t n_expected, int cin, int cout, int dtype, void *out_feats, fd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Sweep assembly (the step in front of the voxelizer).  Replaces the NuScenes branch of
