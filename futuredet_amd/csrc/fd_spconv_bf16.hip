@@ -400,7 +400,10 @@ struct WsKernel {
         if (grid < 1) grid = 1;
         const size_t lds = ws_lds_bytes<CIN, COUT, RG, NW, RING>(a.K);
         hipLaunchKernelGGL((spconv_bf16_ws<CIN, COUT, RG, DEPTH, NW, RING>), dim3((unsigned)grid), dim3(NW * 64), lds, a.stream, (const unsigned short *)a.in, (const u32x4 *)a.wp, a.bias, (const unsigned short *)a.residual, a.relu, a.nbr, a.nbr_stride,
-                           a.K, a.n_out, a.n_out_dev, (unsigned short *)a.out, a.in_bytes, 0);
+                           a.K, a.n_out, a.n_out_dev, (unsigned short *)a.out, a.in_bytes, (!RING && fd::tuning(fd::kTuneBf16NW) != 1) ? 1 : 0);
+        // RESIDENT kernels: tiles interleaved over the grid -- all workgroups sweep the row range together (round 6, in the config-3 sweep: 32 -> 32
+        // 280.5 -> 274.2 us, 16 -> 16 88.5 -> 83.3, 32 -> 64 71.1 -> 67.7, 16 -> 32 46.8 -> 42.4 per two-cloud pass; "bf16_nw" = 1 brings the
+        // XCD-contiguous chunks back for A/B runs).  RING kernels keep their contiguous row ranges per workgroup.
         return true;
     }
 };
