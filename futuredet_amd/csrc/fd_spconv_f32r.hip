@@ -241,24 +241,11 @@ int spconv_f32_res16_dispatch(const float *in, const void *wp, const float *bias
     if (cout == 32 && fd::tuning(fd::kTuneF32ResRG) < 32) return 0;
     const unsigned in_bytes = (unsigned)(n_in_bound * 64);
     const int rg = fd::tuning(fd::kTuneF32ResRG);
-    const int nw = fd::tuning(fd::kTuneF32ResNW);  // waves per workgroup (A/B runs): 0 / 16 = one 1024-thread workgroup per CU; 14 / 12 = two per CU; 8 = three
-#define FD_RESD(CO, RGV, NWV, DV) launch_res16<CO, RGV, DV, NWV>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, n_expected, out, in_bytes, stream)
-#define FD_RES(CO, RGV, NWV) FD_RESD(CO, RGV, NWV, 4)
-    const int dsel = fd::tuning(fd::kTuneV2Depth);  // gather ring depth (A/B runs: "v2_depth" = 8 | 12)
-    if (cout == 16 && rg < 2 && (nw == 0 || nw == 16)) {
-        if (dsel == 8) return FD_RESD(16, 1, 16, 8);
-        if (dsel == 12) return FD_RESD(16, 1, 16, 12);
-        if (dsel == 16) return FD_RESD(16, 1, 16, 16);
-    }
-    if (cout == 16) {
-        if (rg >= 2) return FD_RES(16, 2, 16);
-        if (nw == 14) return FD_RES(16, 1, 14);  // two workgroups per CU (28 waves): measured no faster than one of 16 (27.3 vs 29.4 us, round 6)
-        if (nw == 12) return FD_RES(16, 1, 12);
-        if (nw == 8) return FD_RES(16, 1, 8);
-        return FD_RES(16, 1, 16);
-    }
-    return FD_RES(32, 1, 16);
+    // Measured and dropped in round 6 (profiles/round6_tiles_prototype.txt): gather ring depth 8 / 12 / 16 (24.6 -> 26.9 / 28.2 / 32.1 us), two workgroups of 14
+    // waves per CU (29.4 vs 27.3 us), two row groups per wave with interleaved tiles (43.6 vs 41.1 us on two clouds).
+#define FD_RES(CO, RGV) launch_res16<CO, RGV, 4, 16>(in, wp, bias, residual, relu, nbr, nbr_stride, K, n_out, n_out_dev, n_expected, out, in_bytes, stream)
+    if (cout == 16) return rg >= 2 ? FD_RES(16, 2) : FD_RES(16, 1);
+    return FD_RES(32, 1);
 #undef FD_RES
-#undef FD_RESD
 }
 }  // namespace fd

@@ -618,18 +618,6 @@ int spconv_f32_compact_dispatch(const float *in, const void *wp, const float *bi
         if (dd == 3) return FD_LAUNCH(CI, CO, 128, 3);               \
         return FD_LAUNCH(CI, CO, 128, 4);                            \
     }
-    // deeper gather rings for the narrow shapes (tuning knob "v2_depth" = 6 | 8 | 12; TM 128 only): the strided convolutions into levels 1 / 2 gather
-    // rows of the finer level (L2 misses) and their items carry 4 / 16 MFMAs -- the phase trace (profiles/round6_down_trace.txt) puts an item at
-    // 1150 / 1650 cycles for 128 / 512 cycles of MFMA
-#define FD_DEEP(CI, CO)                                                        \
-    if (cin == CI && cout == CO && (tsel == 0 || tsel == 128)) {               \
-        if (dsel == 6) return FD_LAUNCH(CI, CO, 128, 6);                       \
-        if (dsel == 8) return FD_LAUNCH(CI, CO, 128, 8);                       \
-        if (dsel == 12) return FD_LAUNCH(CI, CO, 128, 12);                     \
-    }
-    FD_DEEP(16, 32)
-    FD_DEEP(32, 64)
-#undef FD_DEEP
     FD_CASE(16, 16, 4, 128)
     FD_CASE(16, 32, 4, 128)
     FD_CASE(32, 32, 4, 128)

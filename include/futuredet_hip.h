@@ -37,8 +37,10 @@ const char *fd_last_error(void);
  * "v2_ranges_per_cu", "v2_uniform", "v2_rowcost", "spconv_c32", "bf16_gp", "bf16_rg", "bf16_depth", "bf16_nw",
  * "strict" (1: a bf16 sparse layer that the gather-pipeline kernels cannot take is an error instead of a fall-back to the register
  * kernels), "bf16_win" (-1: the 64 -> 64 / 128 -> 128 bf16 layers on the RING / RESIDENT kernels instead of the LDS-window
- * kernel of round 5), "f32_res_rg" (-1: 16-channel fp32 layers on the
- * pair-compacting kernel instead of the resident-weights one), "conv_strip" (1: stride-1 bf16 dense layers on strips of 128
+ * kernel of round 5; 2: such a layer on the window kernel even when it is not SubM-like), "bf16_nw" (1: RESIDENT bf16 kernels walk
+ * XCD-contiguous tile chunks instead of tiles interleaved over the grid; 4: four-wave window shapes), "f32_res_rg" (-1: 16-channel fp32
+ * layers on the pair-compacting kernel instead of the resident-weights one), "f32_res_nw" (1: that kernel on XCD-contiguous tile chunks
+ * instead of interleaved tiles), "conv_strip" (1: stride-1 bf16 dense layers on strips of 128
  * consecutive pixels instead of 8 x 16 tiles: faster alone, slower with several sweeps in flight; -1: the ragged grid of 8 x 16
  * tiles instead of the default mixed tiling -- whole 8 x 16 tiles plus edge tiles of other shapes; results identical in all three).  Initial
  * values come from the FD_SPCONV_RG, FD_SPCONV_V1, ... environment variables (FD_ + the upper-case name), read once when the
