@@ -139,7 +139,7 @@ def workload_key(args):
     return "%s/%s/%d/b%d" % (args.variant, args.dtype, args.points, args.batch)
 
 
-PMC_PROFILE = "round5_pmc.json"  # tools/pmc_round.sh -> tools/publish_profiles.py; keyed by workload, stamped with commit + source fingerprint
+PMC_PROFILE = "round6_pmc.json"  # tools/pmc_round.sh -> tools/publish_profiles.py; keyed by workload, stamped with commit + source fingerprint
 PROF_EVERY = 100  # instrumented steps of the timed region: the last one and every PROF_EVERY-th before it
 
 
