@@ -4,8 +4,9 @@ Constructor signature and state_dict keys follow the reference (shared_conv.{0,1
 rot,vel,hm}.{0,1,3}.*, tasks.{i}.forecast_conv.*, bev_conv.*).  Branches: "standard" (n0 / n3: one task, velocity split
 per timestep), "dense" (n3dtf / n3dtfm: one task per timestep, optional chained forecast features and BEV-map branch) and
 "classify" (the reference constructor's DEFAULT, center_head.py:253,329-330,589-595: one task per timestep with a three-class
-heat-map whose channel maximum is the score map); ``reverse`` / ``sparse`` / ``wide_head`` / ``dcn_head`` / ``two_stage`` are
-False in every shipped config and raise.  In eval mode on the device the head runs on the convolution plan of dense_bf16.py
+heat-map whose channel maximum is the score map); ``reverse`` (center_head.py:559: decoded exactly like the standard head -- the mode differs in
+the training targets only) and ``sparse`` (:322-324,572-587: a forward and a reverse task, each with a velocity pair per timestep; the forward
+task's steps first, then the reverse task's); ``wide_head`` / ``dcn_head`` / ``two_stage`` are False in every shipped config and raise.  In eval mode on the device the head runs on the convolution plan of dense_bf16.py
 (the only device path; a head it cannot take raises); predict() runs the HIP decode + rotated NMS (fd_centerpoint_decode) for
 all (sample, heat-map) groups in one call; the loss is training-only and out of scope of this path.
 """
@@ -76,7 +77,7 @@ class CenterHead(nn.Module):
                  two_stage=False, reverse=False, sparse=False, dense=False, bev_map=False, forecast_feature=False,
                  classify=True, wide_head=False):
         super().__init__()
-        unsupported = dict(dcn_head=dcn_head, two_stage=two_stage, reverse=reverse, sparse=sparse, wide_head=wide_head)
+        unsupported = dict(dcn_head=dcn_head, two_stage=two_stage, wide_head=wide_head)
         on = [k for k, v in unsupported.items() if v]
         if on:
             raise NotImplementedError("CenterHead options %s are False in every shipped centerpoint config and are not "
@@ -84,7 +85,7 @@ class CenterHead(nn.Module):
         self.two_stage, self.reverse, self.sparse, self.dense = two_stage, reverse, sparse, dense
         self.bev_map, self.forecast_feature, self.classify, self.wide_head = bev_map, forecast_feature, classify, wide_head
         self.target_timesteps = 7
-        self.standard = not (dense or classify)  # center_head.py:268-271
+        self.standard = not (reverse or sparse or dense or classify or wide_head)  # center_head.py:268-271
         num_classes = [len(t["class_names"]) for t in tasks]
         self.class_names = [t["class_names"] for t in tasks]
         self.code_weights = code_weights
@@ -98,6 +99,8 @@ class CenterHead(nn.Module):
         self.logger = logger or logging.getLogger("CenterHead")
         self.logger.info(f"num_classes: {num_classes}")
         self.tasks = nn.ModuleList()
+        if self.sparse:    # center_head.py:322-324: a forward and a reverse task
+            self.num_classes = 2 * [1]
         if self.dense:
             self.num_classes = self.timesteps * [1]
         if self.classify:  # center_head.py:329-330 (after the dense rule, as there)
@@ -113,7 +116,7 @@ class CenterHead(nn.Module):
         for i, num_cls in enumerate(self.num_classes):
             heads = copy.deepcopy(dict(common_heads))
             for head in heads.keys():
-                if self.standard and head in ["vel", "rvel"]:  # center_head.py:355
+                if not (self.dense or self.classify or self.wide_head) and head in ["vel", "rvel"]:  # center_head.py:355 (standard, reverse, sparse)
                     heads[head] = (self.timesteps * heads[head][0], heads[head][1])
             heads.update(dict(hm=(num_cls, num_hm_conv)))
             cin = 2 * share_conv_channel if (i != 0 and self.forecast_feature) else share_conv_channel
@@ -161,12 +164,16 @@ class CenterHead(nn.Module):
     # ----------------------------------------------------------------------------------------------- predict
     def _groups(self, preds_dicts):
         """-> (list of per-group source dicts, vel tensor per output step, step->group map, num_classes per step)."""
-        if self.standard:  # center_head.py:559-570
+        if self.standard or self.reverse:  # center_head.py:559-570
             pd = preds_dicts[0]
             vels = [pd["vel"][:, 2 * i:2 * i + 2] for i in range(self.timesteps)]
             if len(vels) == 1:
                 vels = self.target_timesteps * vels
-            return [pd], vels, [0] * len(vels), [1] * self.target_timesteps
+            return [pd], vels, [0] * len(vels), [1] * len(vels)  # (the reference writes [1] * target_timesteps and can only run 1 or 7 steps)
+        if self.sparse:  # center_head.py:572-587: the forward task's steps, then the reverse task's
+            fwd, rev = preds_dicts[0], preds_dicts[1]
+            vels = [fwd["vel"][:, 2 * i:2 * i + 2] for i in range(self.timesteps)] + [rev["vel"][:, 2 * i:2 * i + 2] for i in range(self.timesteps)]
+            return [fwd, rev], vels, [0] * self.timesteps + [1] * self.timesteps, [1] * (2 * self.timesteps)
         vels = [pd["vel"] for pd in preds_dicts]  # center_head.py:606-607 (dense), :589-595 (classify: one class per step after the channel max)
         return list(preds_dicts), vels, list(range(len(preds_dicts))), [1] * len(preds_dicts) if self.classify else list(self.num_classes)
 
@@ -184,7 +191,14 @@ class CenterHead(nn.Module):
         T, B, H, W, C = zbuf.shape
         hm_channels = where["hm"][1]
         assert hm_channels == 1 or self.classify, "multi-class heat-maps are decoded as their channel maximum only in the classify mode (center_head.py:589-595)"
-        if self.standard:  # center_head.py:559-570: one task, step s = its boxes + velocity channels 2s, 2s+1 (all steps share them when timesteps == 1)
+        if self.sparse:  # center_head.py:572-587: two tasks (forward, reverse), a velocity pair per timestep each; 2 T output steps
+            G = 2
+            S = 2 * self.timesteps
+            assert 2 * self.timesteps <= where["vel"][1], "velocity channels 2 s, 2 s + 1 must exist for every step"
+            step_group = [0] * self.timesteps + [1] * self.timesteps
+            step_vel = [2 * s for s in range(self.timesteps)] * 2
+            num_classes = [1] * S
+        elif self.standard or self.reverse:  # center_head.py:559-570: one task, step s = its boxes + velocity channels 2s, 2s+1 (all steps share them when timesteps == 1)
             G = 1
             # center_head.py:559-565 emits one step per velocity pair: ``timesteps`` of them when the head forecasts, else
             # ``target_timesteps`` copies of the single pair (the same rule as _groups above)

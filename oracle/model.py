@@ -176,15 +176,18 @@ class SepHead(nn.Module):  # center_head.py:81-174 (bn=True, final_kernel=3 as b
 
 class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from the shipped configs)
     def __init__(self, in_channels, tasks, common_heads, share_conv_channel=64, num_hm_conv=2, timesteps=1,
-                 dense=False, bev_map=False, forecast_feature=False, classify=False, **kw):
+                 dense=False, bev_map=False, forecast_feature=False, classify=False, reverse=False, sparse=False, **kw):
         super().__init__()
-        for flag in ("reverse", "sparse", "wide_head", "two_stage", "dcn_head"):
+        for flag in ("wide_head", "two_stage", "dcn_head"):
             assert not kw.get(flag, False), flag
         self.dense, self.bev_map, self.forecast_feature, self.classify = dense, bev_map, forecast_feature, classify
-        self.standard = not (dense or classify)  # :268-271
+        self.reverse, self.sparse = reverse, sparse
+        self.standard = not (reverse or sparse or dense or classify)  # :268-271
         self.timesteps = timesteps
         self.target_timesteps = 7
         self.num_classes = [len(t["class_names"]) for t in tasks]
+        if sparse:  # :322-324
+            self.num_classes = 2 * [1]
         if dense:
             self.num_classes = timesteps * [1]
         if classify:  # :329-330
@@ -200,7 +203,7 @@ class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from 
         self.tasks = nn.ModuleList()
         for i, num_cls in enumerate(self.num_classes):
             heads = copy.deepcopy(dict(common_heads))
-            if self.standard and "vel" in heads:  # :355
+            if not (dense or classify) and "vel" in heads:  # :355 (standard, reverse, sparse)
                 heads["vel"] = (timesteps * heads["vel"][0], heads["vel"][1])
             heads.update(dict(hm=(num_cls, num_hm_conv)))
             cin = 2 * share_conv_channel if (i != 0 and forecast_feature) else share_conv_channel
@@ -222,7 +225,14 @@ class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from 
     def predict(self, example, preds_dicts, test_cfg):
         post_range = torch.tensor(test_cfg["post_center_limit_range"], dtype=preds_dicts[0]["hm"].dtype)
         steps = []
-        if self.standard:  # :559-570
+        if self.sparse:  # :572-587: forward task's steps, then the reverse task's
+            num_classes = [1, 1] * self.target_timesteps
+            for src in (preds_dicts[0], preds_dicts[1]):
+                for i in range(self.timesteps):
+                    d = dict(src)
+                    d["vel"] = src["vel"][:, 2 * i:2 * i + 2]
+                    steps.append(d)
+        elif self.standard or self.reverse:  # :559-570
             pd = preds_dicts[0]
             vels = [pd["vel"][:, 2 * i:2 * i + 2] for i in range(self.timesteps)]
             if len(vels) == 1:
