@@ -4,6 +4,7 @@ VoxelNet.forward(example, return_loss) keeps the reference contract (voxelnet.py
 ``forward_points`` is the device-resident fast path the benchmark measures: raw point clouds (device tensors)
 -> fused voxelizer/mean -> sparse backbone -> neck -> head -> decode, with one host read of the five
 active-row counts and one of the final detections."""
+import contextlib
 import os
 
 import numpy as np
@@ -466,8 +467,6 @@ class FullSweepStep(StaticStep):
                 self.records[b].copy_(smp["records"], non_blocking=True)
 
     def _run(self, static):
-        import contextlib
-
         from .forecast import sweep_forecast
 
         scope = (lambda: hip_ops.workspace.scope(id(self))) if static else contextlib.nullcontext
@@ -478,8 +477,7 @@ class FullSweepStep(StaticStep):
         outs = StaticStep._run(self, static)
         if self.T >= 2:
             packed, counts = outs
-            self.forecast = sweep_forecast(packed, counts, self.time[:, :self.T - 1].contiguous() if self.time.shape[1] != self.T - 1 else self.time,
-                                           self.records, self.classname, out=self.forecast)
+            self.forecast = sweep_forecast(packed, counts, self.time, self.records, self.classname, out=self.forecast)
         return outs
 
     def __call__(self, samples, bev_map=None, check=True):

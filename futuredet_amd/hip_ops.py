@@ -822,9 +822,6 @@ class ForecastOutputs(object):
             setattr(self, name, self.blob[o:o + nbytes].view(dt).view(shape))
         self.c_struct = _lib.ForecastBuffers(**{name: getattr(self, name).data_ptr() for name, _, _ in self.FIELDS})
 
-    def tensors(self):
-        return [getattr(self, name) for name, _, _ in self.FIELDS]
-
     def views_of(self, blob_host):
         """the named arrays of a HOST copy of ``blob`` (numpy views, no copy)"""
         a = blob_host.numpy() if isinstance(blob_host, torch.Tensor) else np.asarray(blob_host)
