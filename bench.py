@@ -946,6 +946,7 @@ def main():
     #   config4_rank    BASELINE configs[3] as ONE rank of the 8 sees it: forecast_n3 bf16, its share (8 clouds) of the global batch of 64
     #                   per step, micro-batches of 4
     #   config5         BASELINE configs[4] on one GPU: pedestrian forecast_n3 bf16, 500k-point clouds, 0.05 m grid
+    #   n3dtf_bf16 / pointpillars_fp32   the 8f-4 rows: the dense forecasting head with chained features, the PointPillars reader + scatter path
     #   street_fp32 / street_bf16   the motion-compensated street profile (~60k voxels per 300k points, a few dozen detections)
     is_default = (world == 1 and args.dtype == "fp32" and args.variant == "forecast_n0" and args.points == 300000 and args.batch == 2 and
                   args.global_batch == 0 and args.scene == "dense" and args.class_name == "car" and not args.no_also)
@@ -965,6 +966,8 @@ def main():
             ("full_pipeline_plain", dict(pipeline="assembled"), "the plain pipeline on the clouds full_pipeline assembles (like-for-like partner: the difference is "
                                                                  "what assembly + forecast + the larger result copy cost)"),
             ("full_pipeline_bf16", dict(PRESETS[3], pipeline="full"), "FutureDet end to end on BASELINE configs[2] (forecast_n3, bf16)"),
+            ("n3dtf_bf16", dict(PRESETS[3], variant="forecast_n3dtf"), "the dense forecasting head with chained forecast features (forecast_n3dtf, SURVEY 8f-4), bf16"),
+            ("pointpillars_fp32", dict(variant="pp_n3dtf"), "the PointPillars config (PillarFeatureNet + PointPillarsScatter + RPN + n3dtf head, SURVEY 8f-4), fp32"),
             ("street_fp32", dict(scene="street"), "the headline workload on the street scene profile (fp32)"),
             ("street_bf16", dict(PRESETS[3], scene="street"), "BASELINE configs[2] on the street scene profile (bf16)"),
         ]
