@@ -259,6 +259,64 @@ inline double tile_cost(int Ho, int Wo, int B, int cout, const TileChoice &c, in
 // one float4 of packed weights per channel block (A operand, the fd_conv2d_f32_pack_weight layout with one tap), two
 // slices in flight.  Same epilogue as the direct kernel (bias, ReLU, channel-offset / pixel-stride / pixel-shuffle placement).
 // Measured (us): 128->256 at 180 x 180 47 (direct kernel with a 1x1 tap) -> 36; 256->256 at 90 x 90 35 -> 17 (MIOpen: 26 / 16).
+// Row-contiguous epilogue of the pointwise kernels (round 6).  The accumulators leave a wave as lane (pixel lm, quad lq) = four channels of one
+// pixel: a store instruction then touches 16 pixels with 64 bytes each.  Through a 16 x (16 NCB) LDS tile per wave the same values leave as
+// lane -> 16 consecutive bytes of a pixel's channel run: four pixels x 64 NCB bytes contiguous per instruction.  Taken when the wave's
+// 16 NCB channels are all real, 16-byte placed and inside one sub-convolution of a pixel shuffle; otherwise the element-wise epilogue runs.
+constexpr int kEpPitch = 68;  // floats per staged pixel row (64 + 4: 16-byte aligned, rows on different bank groups)
+template <int NPB, int NCB>
+__device__ inline bool pointwise_epilogue_rows(const f32x4 (&acc)[NPB][NCB], const ConvParamsF &p, const float *__restrict__ bias, float *__restrict__ y,
+                                               int64_t px0, int64_t n_px, int nb0, int lane, float *__restrict__ s_ep /* this wave's [16][kEpPitch] */) {
+    static_assert(16 * NCB <= 64, "tile width");
+    const int lm = lane & 15, lq = lane >> 4;
+    const int co_base = nb0 * 16;
+    if (((p.cout_total | p.co_off) & 3) != 0 || co_base + 16 * NCB > p.Cout_real) return false;
+    int co_out_base = co_base, ooy = p.ooy, oox = p.oox;
+    if (p.cout_sub > 0) {
+        const int sub = co_base / p.cout_sub;
+        if ((co_base + 16 * NCB - 1) / p.cout_sub != sub) return false;
+        co_out_base = co_base - sub * p.cout_sub;
+        ooy = sub / p.osx;
+        oox = sub - ooy * p.osx;
+    }
+    float4 bv[NCB];
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) bv[j] = bias ? *reinterpret_cast<const float4 *>(bias + co_out_base + 16 * j + 4 * lq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
+    constexpr int LPP = 4 * NCB;        // lanes per pixel when reading back (16-byte pieces of its 16 NCB channels)
+    constexpr int PPI = 64 / LPP;       // pixels per store instruction
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) {
+            float4 v = make_float4(acc[i][j][0] + bv[j].x, acc[i][j][1] + bv[j].y, acc[i][j][2] + bv[j].z, acc[i][j][3] + bv[j].w);
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4 *>(s_ep + lm * kEpPitch + 16 * j + 4 * lq) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int r = 0; r < 16 / PPI; ++r) {
+            const int pl = r * PPI + lane / LPP, c4 = lane % LPP;
+            const float4 v = *reinterpret_cast<const float4 *>(s_ep + pl * kEpPitch + 4 * c4);
+            const int64_t px = px0 + i * 16 + pl;
+            if (px < n_px) {
+                const int ox = (int)(px % p.Wo);
+                const int64_t t = px / p.Wo;
+                const int oy = (int)(t % p.Ho);
+                const int64_t b = t / p.Ho;
+                const int64_t yy = (int64_t)oy * p.osy + ooy, xx = (int64_t)ox * p.osx + oox;
+                *reinterpret_cast<float4 *>(y + ((b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co_out_base + 4 * c4) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    return true;
+}
+
 template <int NPB, int NCB>
 __global__ void __launch_bounds__(256) conv1x1_f32(const float *__restrict__ x, const float4 *__restrict__ wp, const float *__restrict__ bias,
                                                    float *__restrict__ y, ConvParamsF p) {
@@ -316,6 +374,253 @@ __global__ void __launch_bounds__(256) conv1x1_f32(const float *__restrict__ x, 
     }
 #undef FD_PW_STEP
     // epilogue: lane (pixel lm of block i, quad lq) holds channels 16 (nb0 + j) + 4 lq .. + 3 of its pixel
+    __shared__ __attribute__((aligned(16))) float s_ep[4][16 * kEpPitch];
+    if (pointwise_epilogue_rows<NPB, NCB>(acc, p, bias, y, px0, n_px, nb0, lane, s_ep[wave])) return;
+    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
+    const bool wide = ((p.cout_total | p.co_off) & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+        const int co = (nb0 + j) * 16 + lq * 4;
+        int co_out = co, limit = p.Cout_real, ooy = p.ooy, oox = p.oox;
+        if (co >= p.Cout_real) continue;
+        if (p.cout_sub > 0) {  // pixel shuffle: (sub-convolution, channel)
+            const int sub = co / p.cout_sub;
+            co_out = co - sub * p.cout_sub;
+            limit = p.cout_sub;
+            ooy = sub / p.osx;
+            oox = sub - ooy * p.osx;
+        }
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) {
+            bv.x = bias[co_out];
+            if (co_out + 1 < limit) bv.y = bias[co_out + 1];
+            if (co_out + 2 < limit) bv.z = bias[co_out + 2];
+            if (co_out + 3 < limit) bv.w = bias[co_out + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int64_t px = px0 + i * 16 + lm;
+            if (px >= n_px) continue;
+            const int ox = (int)(px % p.Wo);
+            const int64_t t = px / p.Wo;
+            const int oy = (int)(t % p.Ho);
+            const int64_t b = t / p.Ho;
+            float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const int64_t yy = (int64_t)oy * p.osy + ooy, xx = (int64_t)ox * p.osx + oox;
+            float *dst = y + ((b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co_out;
+            if (wide && co_out + 3 < limit) {
+                *reinterpret_cast<float4 *>(dst) = v;
+            } else {
+                dst[0] = v.x;
+                if (co_out + 1 < limit) dst[1] = v.y;
+                if (co_out + 2 < limit) dst[2] = v.z;
+                if (co_out + 3 < limit) dst[3] = v.w;
+            }
+        }
+    }
+}
+
+// The same GEMM with the pixel operand shared through LDS (round 6).  In conv1x1_f32 every wave loads the workgroup's pixels itself: 4 pixel +
+// 4 weight fragments of 1 KB per wave and 16-channel slice for 64 MFMAs -- 32 KB per 2048 MFMA cycles and CU, which is what the vector-memory
+// path delivers (16 B/clk): 45 % MFMA-busy.  Here the four waves stage the pixels once (1 KB each) and read them back from LDS: 5 KB per wave
+// and slice from memory instead of 8.  Same MFMA sequence per output element: bit-identical to conv1x1_f32 (the plan times both per layer).
+template <int NPB, int NCB>
+__global__ void __launch_bounds__(256) conv1x1_lds_f32(const float *__restrict__ x, const float4 *__restrict__ wp, const float *__restrict__ bias,
+                                                   float *__restrict__ y, ConvParamsF p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what derives from it stays in SGPRs
+    const int lm = lane & 15, lq = lane >> 4;
+    const int64_t n_px = (int64_t)p.B * p.Ho * p.Wo;
+    const int64_t px0 = (int64_t)blockIdx.x * (16 * NPB);
+    const int nb0 = ((int)blockIdx.y * 4 + wave) * NCB;  // first 16-channel block of this wave
+    const bool active = nb0 * 16 < p.Cout_pad;            // (an idle wave still stages pixels and meets the barriers)
+    const int nsl = p.Cin / 16;
+    // the workgroup's 16 * NPB pixels x 16 channels of a slice, staged ONCE per slice by all four waves (thread -> pixel tid / 4, piece tid % 4)
+    // instead of loaded by each of them: pixel pitch 80 bytes (the 16 pixels of a block land on distinct bank groups), two buffers
+    constexpr int kPitch = 20;  // floats
+    __shared__ __attribute__((aligned(16))) float s_x[2][16 * NPB * kPitch];
+    const int spx = tid >> 2, spc = tid & 3;
+    const float *xsrc = nullptr;
+    if (spx < 16 * NPB) {
+        int64_t px = px0 + spx;
+        px = px < n_px ? px : n_px - 1;
+        xsrc = x + px * p.cin_stride + spc * 4;
+    }
+    const float4 *wq[NCB];
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+        const int nb = nb0 + j < (p.Cout_pad >> 4) ? nb0 + j : (p.Cout_pad >> 4) - 1;
+        wq[j] = wp + (int64_t)nb * nsl * 64 + lane;
+    }
+    f32x4 acc[NPB][NCB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 a0[NCB], a1[NCB], xr;
+    auto load_w = [&](int s, float4(&aa)[NCB]) {
+        const int sc = s < nsl ? s : nsl - 1;
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) aa[j] = wq[j][(int64_t)sc * 64];
+    };
+    auto load_x = [&](int s) {
+        const int sc = s < nsl ? s : nsl - 1;
+        if (xsrc) xr = *reinterpret_cast<const float4 *>(xsrc + sc * 16);
+    };
+    auto stage_x = [&](int buf) {
+        if (xsrc) *reinterpret_cast<float4 *>(&s_x[buf][spx * kPitch + spc * 4]) = xr;
+    };
+#define FD_PW_STEP(BUF, AA)                                                                                            \
+    {                                                                                                                  \
+        float4 bb[NPB];                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NPB; ++i) bb[i] = *reinterpret_cast<const float4 *>(&s_x[BUF][(i * 16 + lm) * kPitch + lq * 4]); \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NPB; ++i) _Pragma("unroll") for (int j = 0; j < NCB; ++j) {              \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].x, bb[i].x, acc[i][j], 0, 0, 0);                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].y, bb[i].y, acc[i][j], 0, 0, 0);                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].z, bb[i].z, acc[i][j], 0, 0, 0);                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].w, bb[i].w, acc[i][j], 0, 0, 0);                    \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
+    load_x(0);
+    load_w(0, a0);
+    stage_x(0);
+    __syncthreads();
+    for (int s = 0; s < nsl; s += 2) {
+        load_x(s + 1);       // slice s + 1 travels under the MFMAs of slice s ...
+        load_w(s + 1, a1);
+        FD_PW_STEP(0, a0)
+        stage_x(1);          // ... and is handed over behind them (buffer 1 was last read in the previous iteration, before its barrier)
+        __syncthreads();
+        if (s + 1 >= nsl) break;
+        load_x(s + 2);
+        load_w(s + 2, a0);
+        FD_PW_STEP(1, a1)
+        stage_x(0);
+        __syncthreads();
+    }
+#undef FD_PW_STEP
+    if (!active) return;
+    // epilogue: lane (pixel lm of block i, quad lq) holds channels 16 (nb0 + j) + 4 lq .. + 3 of its pixel
+    __shared__ __attribute__((aligned(16))) float s_ep[4][16 * kEpPitch];
+    if (pointwise_epilogue_rows<NPB, NCB>(acc, p, bias, y, px0, n_px, nb0, lane, s_ep[wave])) return;
+    const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
+    const bool wide = ((p.cout_total | p.co_off) & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+        const int co = (nb0 + j) * 16 + lq * 4;
+        int co_out = co, limit = p.Cout_real, ooy = p.ooy, oox = p.oox;
+        if (co >= p.Cout_real) continue;
+        if (p.cout_sub > 0) {  // pixel shuffle: (sub-convolution, channel)
+            const int sub = co / p.cout_sub;
+            co_out = co - sub * p.cout_sub;
+            limit = p.cout_sub;
+            ooy = sub / p.osx;
+            oox = sub - ooy * p.osx;
+        }
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) {
+            bv.x = bias[co_out];
+            if (co_out + 1 < limit) bv.y = bias[co_out + 1];
+            if (co_out + 2 < limit) bv.z = bias[co_out + 2];
+            if (co_out + 3 < limit) bv.w = bias[co_out + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int64_t px = px0 + i * 16 + lm;
+            if (px >= n_px) continue;
+            const int ox = (int)(px % p.Wo);
+            const int64_t t = px / p.Wo;
+            const int oy = (int)(t % p.Ho);
+            const int64_t b = t / p.Ho;
+            float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const int64_t yy = (int64_t)oy * p.osy + ooy, xx = (int64_t)ox * p.osx + oox;
+            float *dst = y + ((b * Hy + yy) * Wy + xx) * p.cout_total + p.co_off + co_out;
+            if (wide && co_out + 3 < limit) {
+                *reinterpret_cast<float4 *>(dst) = v;
+            } else {
+                dst[0] = v.x;
+                if (co_out + 1 < limit) dst[1] = v.y;
+                if (co_out + 2 < limit) dst[2] = v.z;
+                if (co_out + 3 < limit) dst[3] = v.w;
+            }
+        }
+    }
+}
+
+// ... and with the WHOLE pixel rows staged once (round 6): the per-slice forms above fetch 64 bytes of each 4 Cin-byte pixel row per slice -- half
+// of every 128-byte line, eight times over -- and wait for it in every slice.  Here a workgroup copies its 16 NPB rows (all channels) to LDS with
+// fully coalesced 16-byte loads, one barrier, and the slice loop reads pixels from LDS and only the weights from memory.  LDS = 16 NPB x (Cin + 4)
+// floats (+ the epilogue tile): launched only when that fits.  Same MFMA sequence: bit-identical.
+template <int NPB, int NCB>
+__global__ void __launch_bounds__(256) conv1x1_rows_f32(const float *__restrict__ x, const float4 *__restrict__ wp, const float *__restrict__ bias,
+                                                   float *__restrict__ y, ConvParamsF p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: what derives from it stays in SGPRs
+    const int lm = lane & 15, lq = lane >> 4;
+    const int64_t n_px = (int64_t)p.B * p.Ho * p.Wo;
+    const int64_t px0 = (int64_t)blockIdx.x * (16 * NPB);
+    const int nb0 = ((int)blockIdx.y * 4 + wave) * NCB;  // first 16-channel block of this wave
+    const bool active = nb0 * 16 < p.Cout_pad;            // (an idle wave still stages pixels and meets the barriers)
+    const int nsl = p.Cin / 16;
+    // the workgroup's 16 * NPB pixel rows, ALL input channels, staged once: lane -> 16 consecutive bytes of a row, so every load instruction
+    // moves whole 128-byte lines (the per-slice forms fetch 64 bytes of every pixel row per slice); row pitch Cin + 4 floats
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];
+    const int pitch = p.Cin + 4;
+    {
+        const int c4n = p.Cin / 4;
+        for (int t = tid; t < 16 * NPB * c4n; t += 256) {
+            const int pr = t / c4n, c4 = t - pr * c4n;
+            int64_t px = px0 + pr;
+            px = px < n_px ? px : n_px - 1;
+            *reinterpret_cast<float4 *>(&s_rows[pr * pitch + 4 * c4]) = *reinterpret_cast<const float4 *>(x + px * p.cin_stride + 4 * c4);
+        }
+    }
+    const float4 *wq[NCB];
+#pragma unroll
+    for (int j = 0; j < NCB; ++j) {
+        const int nb = nb0 + j < (p.Cout_pad >> 4) ? nb0 + j : (p.Cout_pad >> 4) - 1;
+        wq[j] = wp + (int64_t)nb * nsl * 64 + lane;
+    }
+    f32x4 acc[NPB][NCB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 a0[NCB], a1[NCB];
+    auto load_w = [&](int s, float4(&aa)[NCB]) {
+        const int sc = s < nsl ? s : nsl - 1;
+#pragma unroll
+        for (int j = 0; j < NCB; ++j) aa[j] = wq[j][(int64_t)sc * 64];
+    };
+#define FD_PW_STEP(S, AA)                                                                                              \
+    {                                                                                                                  \
+        float4 bb[NPB];                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NPB; ++i) bb[i] = *reinterpret_cast<const float4 *>(&s_rows[(i * 16 + lm) * pitch + (S) * 16 + lq * 4]); \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NPB; ++i) _Pragma("unroll") for (int j = 0; j < NCB; ++j) {              \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].x, bb[i].x, acc[i][j], 0, 0, 0);                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].y, bb[i].y, acc[i][j], 0, 0, 0);                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].z, bb[i].z, acc[i][j], 0, 0, 0);                    \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(AA[j].w, bb[i].w, acc[i][j], 0, 0, 0);                    \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
+    load_w(0, a0);
+    __syncthreads();
+    if (!active) return;  // (no barrier below)
+    for (int s = 0; s < nsl; s += 2) {
+        load_w(s + 1, a1);
+        FD_PW_STEP(s, a0)
+        if (s + 1 >= nsl) break;
+        load_w(s + 2, a0);
+        FD_PW_STEP(s + 1, a1)
+    }
+#undef FD_PW_STEP
+    // epilogue: lane (pixel lm of block i, quad lq) holds channels 16 (nb0 + j) + 4 lq .. + 3 of its pixel
+    __shared__ __attribute__((aligned(16))) float s_ep[4][16 * kEpPitch];
+    if (pointwise_epilogue_rows<NPB, NCB>(acc, p, bias, y, px0, n_px, nb0, lane, s_ep[wave])) return;
     const int64_t Hy = (int64_t)p.Ho * p.osy, Wy = (int64_t)p.Wo * p.osx;
     const bool wide = ((p.cout_total | p.co_off) & 3) == 0;
 #pragma unroll
@@ -362,18 +667,29 @@ __global__ void __launch_bounds__(256) conv1x1_f32(const float *__restrict__ x, 
 }
 
 // pointwise variants: (pixel blocks, channel blocks per wave); tile ids kNumTiles + 1 ...
-constexpr int kNumPointwise = 4;
+constexpr int kNumPointwise = 8;
 inline int launch_pointwise(const float *x, const void *wp, const float *bias, float *y, const ConvParamsF &p, int variant, hipStream_t stream) {
     const int64_t n_px = (int64_t)p.B * p.Ho * p.Wo;
     auto go = [&](auto kern, int npb, int ncb) {
         dim3 grid((unsigned)((n_px + 16 * npb - 1) / (16 * npb)), (unsigned)((p.Cout_pad / 16 + 4 * ncb - 1) / (4 * ncb)));
         hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, x, (const float4 *)wp, bias, y, p);
     };
+    auto go_rows = [&](auto kern, int npb, int ncb) -> int {
+        const size_t lds = (size_t)16 * npb * (p.Cin + 4) * sizeof(float);
+        if (lds > 46 * 1024) return 0;  // (next to the 17-KB epilogue tile: 64 KB of static + dynamic LDS at most, no opt-in needed)
+        dim3 grid((unsigned)((n_px + 16 * npb - 1) / (16 * npb)), (unsigned)((p.Cout_pad / 16 + 4 * ncb - 1) / (4 * ncb)));
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, x, (const float4 *)wp, bias, y, p);
+        return 1;
+    };
     switch (variant) {
         case 0: go(conv1x1_f32<4, 4>, 4, 4); break;  // 64 pixels x 256 channels per workgroup
         case 1: go(conv1x1_f32<2, 4>, 2, 4); break;  // 32 x 256
         case 2: go(conv1x1_f32<4, 2>, 4, 2); break;  // 64 x 128
         case 3: go(conv1x1_f32<2, 2>, 2, 2); break;  // 32 x 128
+        case 4: go(conv1x1_lds_f32<4, 4>, 4, 4); break;  // 64 x 256, pixels shared through LDS
+        case 5: go(conv1x1_lds_f32<2, 4>, 2, 4); break;  // 32 x 256, pixels shared through LDS
+        case 6: return go_rows(conv1x1_rows_f32<4, 4>, 4, 4);  // 64 x 256, whole pixel rows staged once
+        case 7: return go_rows(conv1x1_rows_f32<2, 4>, 2, 4);  // 32 x 256, whole pixel rows staged once
         default: return 0;
     }
     return 1;

@@ -716,14 +716,14 @@ def test_conv2d_bf16_strip_kernel_matches_tile_kernel_and_torch(hip, cfg):
 F32_CONV_CASES = [(3, 1, 64, 128, 37, 45, 0), (3, 2, 32, 128, 40, 33, 0), (3, 1, 128, 64, 20, 20, 0), (3, 1, 96, 11, 19, 35, 0),
                   (1, 1, 128, 256, 23, 18, 0), (3, 1, 256, 256, 16, 16, 0), (3, 1, 384, 23, 30, 26, 0)] + \
                  [(3, 1, 48, 70, 29, 31, k) for k in range(1, 17)] + [(3, 2, 16, 130, 33, 27, k) for k in (1, 3, 9, 12, 14)] + \
-                 [(1, 1, 80, 40, 21, 22, k) for k in (2, 10, 13, 17, 18, 19, 20)] + [(1, 1, 48, 300, 9, 7, k) for k in (0, 17, 20)]
+                 [(1, 1, 80, 40, 21, 22, k) for k in (2, 10, 13, 17, 18, 19, 20, 21, 22, 23, 24)] + [(1, 1, 48, 300, 9, 7, k) for k in (0, 17, 20, 21, 22, 23, 24)]
 
 
 @pytest.mark.parametrize("cfg", F32_CONV_CASES, ids=lambda c: "k%ds%d_%d-%d_%dx%d_t%d" % c)
 def test_conv2d_nhwc_f32_vs_torch(hip, cfg):
     """Hand-written fp32 MFMA conv vs torch conv2d in float64 on the host: partial tiles, stride 2, 1x1, Cout that is not
     a multiple of 16 / 64, channel-offset (concat) writes, every tile shape of the dispatcher (tile = 1..16 selects one,
-    17..20 the pointwise GEMM variants of a 1x1 convolution; 0 = the library heuristic).  fp32 FMA chains of <= 9 * 384 terms: |d| <= 1e-4 * max(1, |ref|)."""
+    17..24 the pointwise GEMM variants of a 1x1 convolution; 0 = the library heuristic).  fp32 FMA chains of <= 9 * 384 terms: |d| <= 1e-4 * max(1, |ref|)."""
     ks, stride, cin, cout, H, W, tile = cfg
     rng = np.random.default_rng(cin + cout + H + tile)
     x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32))
@@ -733,7 +733,7 @@ def test_conv2d_nhwc_f32_vs_torch(hip, cfg):
     wpk = hip.pack_conv2d_weight_f32(w).cuda()
     xn = x.cuda().permute(0, 2, 3, 1).contiguous()
     out = torch.full((2, ref.shape[2], ref.shape[3], cout + 5), 7.0, dtype=torch.float32, device="cuda")
-    assert hip.conv2d_f32_num_tiles() == 20  # 16 direct-kernel tiles + 4 pointwise (1x1 only) variants
+    assert hip.conv2d_f32_num_tiles() == 24  # 16 direct-kernel tiles + 8 pointwise (1x1 only) variants (21, 22: pixels shared through LDS per slice; 23, 24: whole pixel rows staged once)
     hip.conv2d_nhwc_f32(xn, wpk, b.cuda(), cout, ks, stride, True, out=out, co_off=3, tile=tile)
     got = out[..., 3:3 + cout].permute(0, 3, 1, 2).cpu()
     assert_close("conv2d_nhwc_f32 k%d s%d %d->%d %dx%d tile %d" % cfg, got.numpy(), ref.numpy(), 1e-4)
@@ -762,6 +762,35 @@ def test_conv2d_wino_f32_vs_torch(hip, cfg):
     got = out[..., 3:3 + cout].permute(0, 3, 1, 2).cpu()
     assert_close("conv2d_wino_f32 %d->%d %dx%d tile %d" % cfg, got.numpy(), ref.numpy(), 2e-4)
     assert bool((out[..., :3] == 7).all()) and bool((out[..., 3 + cout:] == 7).all()), "writes outside the channel window"
+
+
+@pytest.mark.parametrize("tile", [0, 17, 18, 19, 20, 21, 22, 23, 24])
+def test_conv1x1_f32_row_contiguous_epilogue_vs_torch(hip, tile):
+    """The pointwise kernels' row-contiguous epilogue (round 6: accumulators leave through a per-wave LDS tile as 16-byte pieces of a pixel's
+    channel run) and the LDS-shared pixel operand (tiles 21 / 22) vs torch in float64: channel counts whose 64-channel wave blocks are all real
+    (256, 192) and one that mixes both epilogues (80: the last block is partial), into an aligned channel window of a wider tensor, partial pixel
+    blocks; and ConvTranspose2d(2, stride 2) as one 1x1 convolution + pixel shuffle with 128-channel sub-convolutions."""
+    rng = np.random.default_rng(tile)
+    for cin, cout, H, W in ((128, 256, 23, 18), (80, 192, 9, 31), (48, 80, 21, 22)):
+        x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32))
+        w = torch.from_numpy((rng.standard_normal((cout, cin, 1, 1)) * (2.0 / cin) ** 0.5).astype(np.float32))
+        b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+        ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double())).float()
+        out = torch.full((2, H, W, cout + 16), 7.0, dtype=torch.float32, device="cuda")
+        hip.conv2d_nhwc_f32(x.cuda().permute(0, 2, 3, 1).contiguous(), hip.pack_conv2d_weight_f32(w).cuda(), b.cuda(), cout, 1, 1, True, out=out, co_off=8, tile=tile)
+        assert_close("conv1x1_f32 %d->%d %dx%d tile %d (aligned window)" % (cin, cout, H, W, tile), out[..., 8:8 + cout].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), 1e-4)
+        assert bool((out[..., :8] == 7).all()) and bool((out[..., 8 + cout:] == 7).all()), "writes outside the channel window"
+    cin, cout, k, H, W = 64, 128, 2, 13, 21
+    x = torch.from_numpy(rng.standard_normal((2, cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((cin, cout, k, k)) * 0.1).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    ref = torch.relu(torch.nn.functional.conv_transpose2d(x.double(), w.double(), b.double(), stride=k)).float()
+    wv = w.permute(2, 3, 1, 0).reshape(-1, cin)[:, :, None, None].contiguous()
+    out = torch.full((2, H * k, W * k, cout + 8), 7.0, device="cuda")
+    hip.conv2d_shuffle_nhwc_f32(x.cuda().permute(0, 2, 3, 1).contiguous(), hip.pack_conv2d_weight_f32(wv).cuda(), b.cuda(), cout, k, True, out=out, co_off=4,
+                                tile=tile)
+    assert_close("conv2d_shuffle_f32 %d->%d k%d tile %d" % (cin, cout, k, tile), out[..., 4:4 + cout].permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), 1e-4)
+    assert bool((out[..., :4] == 7).all()) and bool((out[..., 4 + cout:] == 7).all())
 
 
 def test_conv2d_shuffle_and_grouped_f32_vs_torch(hip):
