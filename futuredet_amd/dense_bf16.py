@@ -65,14 +65,16 @@ class _Conv(object):
         best, best_ms = default, float("inf")
         for cand in cands:
             try:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 self._run(cand, x, out, co_off, kw)
-                e0.record()
-                for _ in range(3):
-                    self._run(cand, x, out, co_off, kw)
-                e1.record()
-                e1.synchronize()
-                ms = e0.elapsed_time(e1)
+                ms = float("inf")
+                for _ in range(3):  # the best of three groups of four launches: one disturbed group must not decide the layer's tile
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(4):
+                        self._run(cand, x, out, co_off, kw)
+                    e1.record()
+                    e1.synchronize()
+                    ms = min(ms, e0.elapsed_time(e1))
             except hip_ops.FutureDetHipError:
                 continue
             if ms < best_ms * 0.98:  # ties go to the earlier candidate
