@@ -498,52 +498,120 @@ __global__ void __launch_bounds__(256) block_work_kernel(const int *__restrict__
 
 // single workgroup: prefix over the block works, range j = blocks whose work midpoint falls into the j-th of n_ranges
 // equal slices of the total.  Boundaries are multiples of 8 rows; a range may be empty (one block heavier than a slice).
+// Round 6: every pass over the works is coalesced -- the 16 waves own contiguous segments and walk them 64 blocks at a time with a
+// shuffle scan (the round 2-5 form gave each of the 1024 threads ~40 CONSECUTIVE blocks: 40 strided load instructions per thread, twice,
+// between two 1024-wide Hillis-Steele scans; 28 us per launch for a 150-KB table).  Same table bit for bit.
 __global__ void __launch_bounds__(1024) range_split_kernel(const unsigned *__restrict__ work, int n_out, const int *__restrict__ n_out_dev,
                                                            int n_ranges, int *__restrict__ ranges) {
     n_out = fd::device_count(n_out, n_out_dev);
     const int n_blocks = (n_out + kWorkRows - 1) / kWorkRows;
-    __shared__ unsigned long long s_part[1024];
+    __shared__ unsigned long long s_seg[16];
     __shared__ unsigned long long s_total;
-    const int tid = threadIdx.x;
-    const int per = (n_blocks + 1023) / 1024;
-    const int b0 = tid * per, b1 = min(n_blocks, b0 + per);
-    unsigned long long sum = 0;
-    for (int b = b0; b < b1; ++b) sum += work[b];
-    s_part[tid] = sum;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partial sums
-    for (int off = 1; off < 1024; off <<= 1) {
-        unsigned long long v = tid >= off ? s_part[tid - off] : 0ull;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n_blocks == 0) {
+        for (int j = tid; j <= n_ranges; j += 1024) ranges[j] = 0;
+        return;
     }
-    if (tid == 1023) s_total = s_part[1023];
+    const int seg = (((n_blocks + 15) / 16) + 63) & ~63;  // blocks per wave (whole 64-block steps)
+    const int b_lo = wave * seg, b_hi = min(n_blocks, b_lo + seg);
+    // ---- segment sums (coalesced), their exclusive scan, the total
+    constexpr int kU = 16;  // loads in flight per lane (a dependent load per 64 blocks costs a memory round trip each: 38 of them per pass before)
+    unsigned long long sum = 0;
+    for (int c0 = b_lo; c0 < b_hi; c0 += 64 * kU) {
+        unsigned wv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int bb = c0 + 64 * u + lane;
+            wv[u] = work[bb < b_hi ? bb : b_hi - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) sum += (c0 + 64 * u + lane < b_hi) ? wv[u] : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) s_seg[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int w = 0; w < 16; ++w) { const unsigned long long v = s_seg[w]; s_seg[w] = run; run += v; }
+        s_total = run;
+    }
     __syncthreads();
     const unsigned long long total = s_total > 0 ? s_total : 1ull;
-    unsigned long long run = s_part[tid] - sum;  // exclusive prefix of this thread's first block
     // range of a block = floor(midpoint * n_ranges / total), as one double multiply (monotone in the midpoint, the same function in
-    // every thread: all the table needs; the 64-bit division it replaces was 2 x 38 software divisions per thread, 34 us per launch --
-    // results do not depend on the ranges, tests/test_gpu_parity.py)
+    // every thread: all the table needs -- results do not depend on the ranges, tests/test_gpu_parity.py)
     const double scale = (double)n_ranges / (2.0 * (double)total);
     auto range_of = [&](unsigned long long ex, unsigned w) -> int {
         const int r = (int)((double)(2ull * ex + w) * scale);
         return r < n_ranges ? r : n_ranges - 1;
     };
-    int prev = -1;  // range of the block before b0 (-1 in front of block 0: every range up to the first one starts at row 0)
-    if (b0 > 0 && b0 < n_blocks) prev = range_of(run - work[b0 - 1], work[b0 - 1]);
-    for (int b = b0; b < b1; ++b) {
-        const unsigned w = work[b];
-        const int rg = range_of(run, w);
-        for (int j = prev + 1; j <= rg; ++j) ranges[j] = b * kWorkRows;
-        prev = rg;
-        run += w;
+    unsigned long long run = s_seg[wave];  // exclusive prefix of this wave's first block
+    int prev = -1;                         // range of the block in front of the current one (-1 in front of block 0)
+    if (b_lo > 0 && b_lo < n_blocks) {
+        const unsigned wp = work[b_lo - 1];
+        prev = range_of(run - wp, wp);
     }
-    if (b1 == n_blocks && b0 < n_blocks) {  // the thread owning the last block closes the table
-        for (int j = prev + 1; j <= n_ranges; ++j) ranges[j] = n_out;
+    // 512 blocks per step: loaded coalesced into this wave's LDS slice, then lane l walks blocks 8 l .. 8 l + 7 on its own -- one shuffle scan
+    // (of the lanes' 8-block sums) per 512 blocks instead of one per 64
+    constexpr int kB = 8;
+    __shared__ unsigned s_buf[16][64 * (kB + 1)];
+    unsigned *buf = s_buf[wave];
+    for (int c0 = b_lo; c0 < b_hi; c0 += 64 * kB) {
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+            const int e = 64 * u + lane, bb = c0 + e;
+            buf[(e / kB) * (kB + 1) + e % kB] = bb < b_hi ? work[bb] : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        unsigned w[kB];
+        unsigned tot = 0;
+#pragma unroll
+        for (int i = 0; i < kB; ++i) {
+            w[i] = buf[lane * (kB + 1) + i];
+            tot += w[i];
+        }
+        unsigned inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        unsigned long long ex = run + (inc - tot);
+        // the range of the block in front of this lane's first one: the previous lane's last block (lane 0: the carry)
+        const int first = c0 + lane * kB;
+        int last_rg = prev;
+        {
+            unsigned long long e2 = ex;
+#pragma unroll
+            for (int i = 0; i < kB; ++i) {
+                if (first + i < b_hi) last_rg = range_of(e2, w[i]);
+                e2 += w[i];
+            }
+        }
+        int before = __shfl_up(last_rg, 1);
+        if (lane == 0) before = prev;
+        // (a lane whose blocks all lie past the segment end keeps the carry: its last_rg is its predecessor's, handed on below)
+        if (first >= b_hi) last_rg = before;
+#pragma unroll
+        for (int i = 0; i < kB; ++i) {
+            const int bb = first + i;
+            if (bb < b_hi) {
+                const int rg = range_of(ex, w[i]);
+                for (int j = before + 1; j <= rg; ++j) ranges[j] = bb * kWorkRows;
+                before = rg;
+                if (bb == n_blocks - 1)  // the thread owning the last block closes the table
+                    for (int j = rg + 1; j <= n_ranges; ++j) ranges[j] = n_out;
+            }
+            ex += w[i];
+        }
+        // carry into the next step: the range of the step's last valid block, the step's total
+        const int n_valid = min(64 * kB, b_hi - c0);
+        prev = __shfl(last_rg, (n_valid - 1) / kB);
+        run += __shfl(inc, 63);
+        __builtin_amdgcn_wave_barrier();  // (the slice is rewritten by the next step)
     }
-    if (n_blocks == 0 && tid == 0)
-        for (int j = 0; j <= n_ranges; ++j) ranges[j] = 0;
 }
 
 }  // namespace

@@ -1190,7 +1190,7 @@ def test_spconv_ranges_partition_rows_and_balance_work(hip):
     whose ranges carry near-equal work on a rulebook with a strong density gradient, and the convolution must give the
     same bits with balanced ranges, equal-row ranges and one tile per workgroup."""
     rng = np.random.default_rng(5)
-    K, n_out, cin, cout = 27, 128 * 61 + 50, 32, 32
+    K, n_out, cin, cout = 27, 128 * 173 + 50, 32, 32   # 2775 work blocks: every wave of the range kernel owns a segment, the last one ragged
     stride = (n_out + 63) // 64 * 64
     nbr = np.full((K, stride), -1, np.int32)
     dens = np.linspace(0.05, 0.9, n_out)  # sparse rows first, dense rows last
@@ -1202,6 +1202,24 @@ def test_spconv_ranges_partition_rows_and_balance_work(hip):
     ranges, n = hip.ranges_for(t, cin, cout)
     r = ranges.cpu().numpy()
     assert len(r) == n + 1 and r[0] == 0 and r[-1] == n_out and np.all(np.diff(r) >= 0) and np.all(r[:-1] % 8 == 0)
+    # the table itself, restated: work of an 8-row block = 24 + 2 per pair + 1 per tap that has a pair in the block; range of a block =
+    # floor(work midpoint * n / total) (one float64 multiply); a range starts at the first block that reaches it
+    vb = nbr[:, :n_out] >= 0
+    nblk = (n_out + 7) // 8
+    padded = np.zeros((K, nblk * 8), bool)
+    padded[:, :n_out] = vb
+    per = padded.reshape(K, nblk, 8)
+    wblk = (24 + 2 * per.sum((0, 2)) + per.any(2).sum(0)).astype(np.uint64)
+    ex = np.concatenate([[0], np.cumsum(wblk)[:-1]]).astype(np.uint64)
+    scale = np.float64(n) / (np.float64(2.0) * np.float64(wblk.sum()))
+    rg = np.minimum((((2 * ex + wblk).astype(np.float64)) * scale).astype(np.int64), n - 1)
+    want = np.full(n + 1, n_out, np.int64)
+    prev = -1
+    for bidx in range(nblk):
+        for j in range(prev + 1, rg[bidx] + 1):
+            want[j] = bidx * 8
+        prev = int(rg[bidx])
+    assert np.array_equal(r, want), "fd_spconv_ranges: the table differs from its definition"
     pairs = (nbr[:, :n_out] >= 0).sum(0)
     work = np.array([pairs[a:b].sum() for a, b in zip(r[:-1], r[1:])], np.float64)
     rows = np.diff(r)
