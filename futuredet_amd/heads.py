@@ -6,7 +6,9 @@ per timestep), "dense" (n3dtf / n3dtfm: one task per timestep, optional chained 
 "classify" (the reference constructor's DEFAULT, center_head.py:253,329-330,589-595: one task per timestep with a three-class
 heat-map whose channel maximum is the score map); ``reverse`` (center_head.py:559: decoded exactly like the standard head -- the mode differs in
 the training targets only) and ``sparse`` (:322-324,572-587: a forward and a reverse task, each with a velocity pair per timestep; the forward
-task's steps first, then the reverse task's); ``wide_head`` / ``dcn_head`` / ``two_stage`` are False in every shipped config and raise.  In eval mode on the device the head runs on the convolution plan of dense_bf16.py
+task's steps first, then the reverse task's) and ``wide_head`` (:332-334,597-604: ONE task on a 512-channel shared convolution whose branches keep that
+width and whose heat-map has a channel per timestep; step s decodes channel s with the shared regression maps); ``dcn_head`` / ``two_stage`` are
+False in every shipped config and raise.  In eval mode on the device the head runs on the convolution plan of dense_bf16.py
 (the only device path; a head it cannot take raises); predict() runs the HIP decode + rotated NMS (fd_centerpoint_decode) for
 all (sample, heat-map) groups in one call; the loss is training-only and out of scope of this path.
 """
@@ -25,7 +27,7 @@ class SepHead(nn.Module):
     def __init__(self, in_channels, heads, head_conv=64, final_kernel=1, bn=False, init_bias=-2.19, two_stage=False,
                  forecast_feature=False, wide_head=False, **kwargs):
         super().__init__(**kwargs)
-        assert not two_stage and not wide_head, "two_stage / wide_head are False in every shipped config"
+        assert not two_stage, "two_stage is False in every shipped config"
         self.heads = heads
         self.forecast_feature = forecast_feature
         if self.forecast_feature:
@@ -34,6 +36,8 @@ class SepHead(nn.Module):
                 nn.ReLU(inplace=True),
                 nn.Conv2d(head_conv, head_conv, kernel_size=3, padding=1, bias=True), nn.BatchNorm2d(head_conv),
                 nn.ReLU(inplace=True))
+        if wide_head:  # center_head.py:127-128: the branches keep the width of the shared convolution
+            head_conv = in_channels
         for head in self.heads:
             classes, num_conv = self.heads[head]
             fc = Sequential()
@@ -77,7 +81,7 @@ class CenterHead(nn.Module):
                  two_stage=False, reverse=False, sparse=False, dense=False, bev_map=False, forecast_feature=False,
                  classify=True, wide_head=False):
         super().__init__()
-        unsupported = dict(dcn_head=dcn_head, two_stage=two_stage, wide_head=wide_head)
+        unsupported = dict(dcn_head=dcn_head, two_stage=two_stage)
         on = [k for k, v in unsupported.items() if v]
         if on:
             raise NotImplementedError("CenterHead options %s are False in every shipped centerpoint config and are not "
@@ -105,6 +109,9 @@ class CenterHead(nn.Module):
             self.num_classes = self.timesteps * [1]
         if self.classify:  # center_head.py:329-330 (after the dense rule, as there)
             self.num_classes = self.timesteps * [3]
+        if self.wide_head:  # center_head.py:332-334
+            self.num_classes = [7]
+            share_conv_channel = 512
         if self.bev_map:
             c = share_conv_channel
             self.bev_conv = nn.Sequential(
@@ -174,6 +181,10 @@ class CenterHead(nn.Module):
             fwd, rev = preds_dicts[0], preds_dicts[1]
             vels = [fwd["vel"][:, 2 * i:2 * i + 2] for i in range(self.timesteps)] + [rev["vel"][:, 2 * i:2 * i + 2] for i in range(self.timesteps)]
             return [fwd, rev], vels, [0] * self.timesteps + [1] * self.timesteps, [1] * (2 * self.timesteps)
+        if self.wide_head:  # center_head.py:597-604: step s = heat-map channel s of the one task, every other map shared
+            pd = preds_dicts[0]
+            srcs = [dict(pd, hm=pd["hm"][:, i:i + 1]) for i in range(self.timesteps)]
+            return srcs, [pd["vel"]] * self.timesteps, list(range(self.timesteps)), [1] * self.timesteps
         vels = [pd["vel"] for pd in preds_dicts]  # center_head.py:606-607 (dense), :589-595 (classify: one class per step after the channel max)
         return list(preds_dicts), vels, list(range(len(preds_dicts))), [1] * len(preds_dicts) if self.classify else list(self.num_classes)
 
@@ -182,6 +193,8 @@ class CenterHead(nn.Module):
         """Device-only decode straight from the convolution plan's NHWC output buffer: (packed [B,S,post,11] float32 rows
         x y z w l h vx vy yaw score label, counts [B,S] int32) -- five launches (keys + histogram, selection, rank + box decode, IoU mask,
         sweep + gather + assembly: fd_centerpoint_decode_packed), no torch kernel in between.  None when the maps did not come from the plan (torch path, bev_map head)."""
+        if self.wide_head:  # (its T groups differ in the heat-map channel only: decoded through the per-group path below)
+            return None
         raws = [getattr(pd, "raw", None) for pd in preds_dicts]
         if any(r is None for r in raws) or any(r[0] is not raws[0][0] or r[2] != raws[0][2] for r in raws):
             return None

@@ -147,7 +147,7 @@ class RPN(nn.Module):  # rpn.py:22-159
 
 
 class SepHead(nn.Module):  # center_head.py:81-174 (bn=True, final_kernel=3 as built at :361-368)
-    def __init__(self, in_channels, heads, head_conv=64, forecast_feature=False):
+    def __init__(self, in_channels, heads, head_conv=64, forecast_feature=False, wide_head=False):
         super().__init__()
         self.heads = heads
         self.forecast_feature = forecast_feature
@@ -155,6 +155,8 @@ class SepHead(nn.Module):  # center_head.py:81-174 (bn=True, final_kernel=3 as b
             self.forecast_conv = nn.Sequential(
                 nn.Conv2d(in_channels, head_conv, 3, padding=1), nn.BatchNorm2d(head_conv), nn.ReLU(),
                 nn.Conv2d(head_conv, head_conv, 3, padding=1), nn.BatchNorm2d(head_conv), nn.ReLU())
+        if wide_head:  # :127-128
+            head_conv = in_channels
         for head, (classes, num_conv) in heads.items():
             fc = Seq()
             for _ in range(num_conv - 1):
@@ -176,13 +178,13 @@ class SepHead(nn.Module):  # center_head.py:81-174 (bn=True, final_kernel=3 as b
 
 class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from the shipped configs)
     def __init__(self, in_channels, tasks, common_heads, share_conv_channel=64, num_hm_conv=2, timesteps=1,
-                 dense=False, bev_map=False, forecast_feature=False, classify=False, reverse=False, sparse=False, **kw):
+                 dense=False, bev_map=False, forecast_feature=False, classify=False, reverse=False, sparse=False, wide_head=False, **kw):
         super().__init__()
-        for flag in ("wide_head", "two_stage", "dcn_head"):
+        for flag in ("two_stage", "dcn_head"):
             assert not kw.get(flag, False), flag
         self.dense, self.bev_map, self.forecast_feature, self.classify = dense, bev_map, forecast_feature, classify
-        self.reverse, self.sparse = reverse, sparse
-        self.standard = not (reverse or sparse or dense or classify)  # :268-271
+        self.reverse, self.sparse, self.wide_head = reverse, sparse, wide_head
+        self.standard = not (reverse or sparse or dense or classify or wide_head)  # :268-271
         self.timesteps = timesteps
         self.target_timesteps = 7
         self.num_classes = [len(t["class_names"]) for t in tasks]
@@ -192,6 +194,9 @@ class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from 
             self.num_classes = timesteps * [1]
         if classify:  # :329-330
             self.num_classes = timesteps * [3]
+        if wide_head:  # :332-334
+            self.num_classes = [7]
+            share_conv_channel = 512
         if bev_map:
             c = share_conv_channel
             self.bev_conv = nn.Sequential(
@@ -203,11 +208,11 @@ class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from 
         self.tasks = nn.ModuleList()
         for i, num_cls in enumerate(self.num_classes):
             heads = copy.deepcopy(dict(common_heads))
-            if not (dense or classify) and "vel" in heads:  # :355 (standard, reverse, sparse)
+            if not (dense or classify or wide_head) and "vel" in heads:  # :355 (standard, reverse, sparse)
                 heads["vel"] = (timesteps * heads["vel"][0], heads["vel"][1])
             heads.update(dict(hm=(num_cls, num_hm_conv)))
             cin = 2 * share_conv_channel if (i != 0 and forecast_feature) else share_conv_channel
-            self.tasks.append(SepHead(cin, heads, forecast_feature=forecast_feature))
+            self.tasks.append(SepHead(cin, heads, forecast_feature=forecast_feature, wide_head=wide_head))
 
     def forward(self, x, bev_map=None):
         rets = []
@@ -242,6 +247,10 @@ class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from 
                 d = dict(pd)
                 d["vel"] = v
                 steps.append(d)
+        elif self.wide_head:  # :597-604: step s = heat-map channel s of the one task
+            pd = preds_dicts[0]
+            steps = [dict(pd, hm=pd["hm"][:, i].unsqueeze(1)) for i in range(self.timesteps)]
+            num_classes = self.timesteps * [1]
         elif self.classify:  # :589-595: the class channels collapse to their maximum, one class per step afterwards
             steps = [dict(d, hm=torch.max(d["hm"], dim=1)[0].unsqueeze(1)) for d in preds_dicts]
             num_classes = self.timesteps * [1]

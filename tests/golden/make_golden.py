@@ -209,15 +209,16 @@ def gen_dense_nets():
     out["rpn_y"] = y.numpy()
     out["rpn_keys"] = np.array(sorted(neck.state_dict().keys()))
     # "cls3": the constructor's DEFAULT mode (classify=True, center_head.py:253): one task per timestep, three-class heat-maps
-    # "rev3" / "sp7": the reverse and sparse modes (center_head.py:559,572-587; no shipped config turns them on)
+    # "rev3" / "sp7" / "wide7": the reverse, sparse and wide-head modes (center_head.py:559,572-587,597-604; no shipped config turns them on)
     for name, T, dense, ff, classify in (("n0", 1, False, False, False), ("n3", 7, False, False, False), ("n3dtf", 7, True, True, False),
-                                         ("cls3", 3, False, False, True), ("rev3", 3, False, False, False), ("sp7", 7, False, False, False)):
+                                         ("cls3", 3, False, False, True), ("rev3", 3, False, False, False), ("sp7", 7, False, False, False),
+                                         ("wide7", 7, False, False, False)):
         head_cfg = dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])],
                         dataset="nuscenes", weight=0.25, code_weights=[1.0] * 10,
                         common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
                         share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=name == "rev3",
                         sparse=name == "sp7", dense=dense, bev_map=False, forecast_feature=ff, classify=classify,
-                        wide_head=False)
+                        wide_head=name == "wide7")
         if classify:  # exercise the default itself: the keyword is left out
             del head_cfg["classify"]
         head = build_head(dict(head_cfg)).eval()
@@ -246,7 +247,7 @@ def gen_predict():
     # "rev" / "sp": reverse (decoded like the standard head) and sparse (a forward and a reverse task, 2 x 7 output steps)
     for name, T, dense, H, W, B in (("n0", 1, False, 40, 48, 2), ("n3", 7, False, 40, 48, 2),
                                     ("n3dtf", 7, True, 24, 24, 1), ("n0big", 1, False, 180, 180, 1), ("cls", 3, False, 24, 28, 2),
-                                    ("rev", 7, False, 20, 28, 2), ("sp", 7, False, 28, 20, 2)):
+                                    ("rev", 7, False, 20, 28, 2), ("sp", 7, False, 28, 20, 2), ("wide", 7, False, 24, 20, 2)):
         classify = name == "cls"
         head = build_head(dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])],
                                dataset="nuscenes", weight=0.25, code_weights=[1.0] * 10,
@@ -254,17 +255,17 @@ def gen_predict():
                                              "vel": (2, 2)},
                                share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=name == "rev",
                                sparse=name == "sp", dense=dense, bev_map=False, forecast_feature=False, classify=classify,
-                               wide_head=False)).eval()
+                               wide_head=name == "wide")).eval()
         rng = np.random.default_rng(21 + T + H)
         ntask = T if (dense or classify) else (2 if name == "sp" else 1)
         preds = []
         for ti in range(ntask):
             # clustered heat-map so that NMS has real work: smooth blobs + noise, ~5-10 % of cells pass 0.1
-            hm = rng.standard_normal((B, 3 if classify else 1, H, W)).astype(np.float32) * 1.2 - (4.2 if classify else 3.6)
+            hm = rng.standard_normal((B, 3 if classify else (7 if name == "wide" else 1), H, W)).astype(np.float32) * 1.2 - (4.2 if classify else 3.6)
             pd = dict(reg=rng.uniform(0, 1, (B, 2, H, W)), height=rng.normal(-1, 0.5, (B, 1, H, W)),
                       dim=rng.normal([[[0.7]], [[1.5]], [[0.5]]], 0.15, (B, 3, H, W)),
                       rot=rng.standard_normal((B, 2, H, W)),
-                      vel=rng.standard_normal((B, 2 if (dense or classify) else 2 * T, H, W)), hm=hm)
+                      vel=rng.standard_normal((B, 2 if (dense or classify or name == "wide") else 2 * T, H, W)), hm=hm)
             preds.append({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in pd.items()})
         for ti, pd in enumerate(preds):
             for k, v in pd.items():

@@ -490,7 +490,7 @@ def _rows(res):
 
 
 @pytest.mark.parametrize("name,T,dense", [("n0", 1, False), ("n3", 7, False), ("n3dtf", 7, True), ("n0big", 1, False), ("cls", 3, False),
-                                          ("rev", 7, False), ("sp", 7, False)])
+                                          ("rev", 7, False), ("sp", 7, False), ("wide", 7, False)])
 def test_predict_matches_reference_golden(hip, golden, name, T, dense):
     """CenterHead.predict on HIP vs the reference's predict outputs (decode + rotated NMS through the compiled
     reference IoU).  Boxes within 1e-3; a detection may differ only if its score is within 1e-5 of the
@@ -503,7 +503,7 @@ def test_predict_matches_reference_golden(hip, golden, name, T, dense):
                            dataset="nuscenes", weight=0.25, code_weights=[1.0] * 10,
                            common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
                            share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=name == "rev", sparse=name == "sp",
-                           dense=dense, bev_map=False, forecast_feature=False, classify=name == "cls", wide_head=False)).cuda().eval()
+                           dense=dense, bev_map=False, forecast_feature=False, classify=name == "cls", wide_head=name == "wide")).cuda().eval()
     # "cls": the constructor's default mode, three-class heat-maps, channel max in the decode; "rev": the reverse mode (decoded like the
     # standard head, center_head.py:559); "sp": the sparse mode (forward + reverse task, 2 x 7 output steps, :572-587)
     ntask = T if (dense or name == "cls") else (2 if name == "sp" else 1)
@@ -920,7 +920,7 @@ def test_default_classify_head_on_the_plan_and_packed_decode(hip, golden):
         assert set(packed[b]["label_preds"].tolist()) <= {0, 1, 2}
 
 
-@pytest.mark.parametrize("mode,T", [("reverse", 3), ("sparse", 7)])
+@pytest.mark.parametrize("mode,T", [("reverse", 3), ("sparse", 7), ("wide_head", 7)])
 def test_reverse_and_sparse_heads_on_the_plan_and_packed_decode(hip, golden, mode, T):
     """CenterHead's ``reverse`` and ``sparse`` modes (center_head.py:322-324,559,572-587; no shipped config turns them on): the device path
     (convolution plan, fp32) reproduces the reference's forward (dense_nets.npz "rev3" / "sp7": one task / a forward and a reverse task, a
@@ -930,10 +930,10 @@ def test_reverse_and_sparse_heads_on_the_plan_and_packed_decode(hip, golden, mod
     from futuredet_amd.synth import seeded_state_dict
 
     g = golden("dense_nets.npz")
-    name = "rev3" if mode == "reverse" else "sp7"
+    name = {"reverse": "rev3", "sparse": "sp7", "wide_head": "wide7"}[mode]
     head = build_head(dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])], dataset="nuscenes", weight=0.25,
                            code_weights=[1.0] * 10, common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
-                           share_conv_channel=64, timesteps=T, classify=False, reverse=mode == "reverse", sparse=mode == "sparse"))
+                           share_conv_channel=64, timesteps=T, classify=False, reverse=mode == "reverse", sparse=mode == "sparse", wide_head=mode == "wide_head"))
     assert not head.standard and len(head.tasks) == (2 if mode == "sparse" else 1)
     head.load_state_dict(seeded_state_dict(head, 12), strict=False)
     head = head.cuda().eval()
@@ -942,7 +942,7 @@ def test_reverse_and_sparse_heads_on_the_plan_and_packed_decode(hip, golden, mod
         preds = head(y)
     assert head._plan[1] is not None and preds[0].raw is not None, "the convolution plan must be the path that ran"
     for ti, pd in enumerate(preds):
-        assert pd["vel"].shape[1] == 2 * T
+        assert pd["vel"].shape[1] == (2 if mode == "wide_head" else 2 * T)
         for k, v in pd.items():
             assert_close("%s head on the plan, task %d %s vs reference golden" % (mode, ti, k), v.float().cpu().numpy(), g["head_%s_t%d_%s" % (name, ti, k)], 1e-3)
     cfg = dict(TEST_CFG, score_threshold=0.01)

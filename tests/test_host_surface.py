@@ -133,12 +133,13 @@ def test_state_dict_keys_match_reference(golden):
                              us_num_filters=[32, 32], num_input_features=24, logger=logging.getLogger("RPN")))
     assert sorted(rpn.state_dict().keys()) == list(d["rpn_keys"])
     for name, T, dense, ff, classify in (("n0", 1, False, False, False), ("n3", 7, False, False, False), ("n3dtf", 7, True, True, False),
-                                         ("cls3", 3, False, False, True), ("rev3", 3, False, False, False), ("sp7", 7, False, False, False)):
+                                         ("cls3", 3, False, False, True), ("rev3", 3, False, False, False), ("sp7", 7, False, False, False),
+                                         ("wide7", 7, False, False, False)):
         kw = dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])], dataset="nuscenes",
                   weight=0.25, code_weights=[1.0] * 10,
                   common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
                   share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=name == "rev3", sparse=name == "sp7",
-                  dense=dense, bev_map=False, forecast_feature=ff, classify=False, wide_head=False)
+                  dense=dense, bev_map=False, forecast_feature=ff, classify=False, wide_head=name == "wide7")
         if classify:  # the reference constructor's DEFAULT (center_head.py:253): built without the keyword, as the golden was
             del kw["classify"]
         head = fa.build_head(kw)
@@ -164,12 +165,13 @@ def test_dense_modules_match_reference_golden_on_cpu(golden):
     np.testing.assert_allclose(y_fold.numpy(), d["rpn_y"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(y_mod.numpy(), d["rpn_y"], rtol=1e-4, atol=1e-4)
     for name, T, dense, ff, classify in (("n0", 1, False, False, False), ("n3", 7, False, False, False), ("n3dtf", 7, True, True, False),
-                                         ("cls3", 3, False, False, True), ("rev3", 3, False, False, False), ("sp7", 7, False, False, False)):
+                                         ("cls3", 3, False, False, True), ("rev3", 3, False, False, False), ("sp7", 7, False, False, False),
+                                         ("wide7", 7, False, False, False)):
         head = fa.build_head(dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])], dataset="nuscenes",
                                   weight=0.25, code_weights=[1.0] * 10,
                                   common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
                                   share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, reverse=name == "rev3", sparse=name == "sp7",
-                                  dense=dense, bev_map=False, forecast_feature=ff, classify=classify, wide_head=False)).eval()
+                                  dense=dense, bev_map=False, forecast_feature=ff, classify=classify, wide_head=name == "wide7")).eval()
         head.load_state_dict(seeded_state_dict(head, 12), strict=False)
         with torch.no_grad():
             preds = head(torch.from_numpy(d["rpn_y"]))

@@ -153,10 +153,11 @@ def test_oracle_dense_nets_match_reference_golden(golden):
         y = rpn(torch.from_numpy(g["rpn_x"]))
     np.testing.assert_allclose(y.numpy(), g["rpn_y"], rtol=1e-4, atol=1e-4)
     for name, T, dense, ff, classify in (("n0", 1, False, False, False), ("n3", 7, False, False, False), ("n3dtf", 7, True, True, False),
-                                         ("cls3", 3, False, False, True), ("rev3", 3, False, False, False), ("sp7", 7, False, False, False)):
+                                         ("cls3", 3, False, False, True), ("rev3", 3, False, False, False), ("sp7", 7, False, False, False),
+                                         ("wide7", 7, False, False, False)):
         head = omodel.CenterHead(64, [dict(num_class=1, class_names=["car"])],
                                  {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
-                                 timesteps=T, dense=dense, forecast_feature=ff, classify=classify, reverse=name == "rev3", sparse=name == "sp7").eval()
+                                 timesteps=T, dense=dense, forecast_feature=ff, classify=classify, reverse=name == "rev3", sparse=name == "sp7", wide_head=name == "wide7").eval()
         assert sorted(head.state_dict().keys()) == list(g["head_%s_keys" % name])
         head.load_state_dict(seeded_state_dict(head, 12), strict=False)
         with torch.no_grad():
@@ -172,13 +173,13 @@ TEST_CFG = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
 
 
 @pytest.mark.parametrize("name,T,dense", [("n0", 1, False), ("n3", 7, False), ("n3dtf", 7, True), ("n0big", 1, False), ("cls", 3, False),
-                                          ("rev", 7, False), ("sp", 7, False)])
+                                          ("rev", 7, False), ("sp", 7, False), ("wide", 7, False)])
 def test_oracle_predict_matches_reference_golden(golden, name, T, dense):
     g = golden("predict.npz")
     classify = name == "cls"  # the reference constructor's default mode (center_head.py:253,589-595)
     head = omodel.CenterHead(64, [dict(num_class=1, class_names=["car"])],
                              {"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)}, timesteps=T, dense=dense,
-                             classify=classify, reverse=name == "rev", sparse=name == "sp").eval()
+                             classify=classify, reverse=name == "rev", sparse=name == "sp", wide_head=name == "wide").eval()
     ntask = T if (dense or classify) else (2 if name == "sp" else 1)
     preds = [{k: torch.from_numpy(g["%s_in_t%d_%s" % (name, ti, k)]) for k in ("reg", "height", "dim", "rot", "vel", "hm")} for ti in range(ntask)]
     rets = head.predict({"metadata": [None] * preds[0]["hm"].shape[0]}, preds, TEST_CFG)
