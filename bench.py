@@ -233,8 +233,13 @@ def cpu_baseline(cfg, sd, cloud, gpu_rows, budget_s=(40.0, 12.0)):
         return dict(threads=threads, sec=float(np.median(times)), passes=len(times), warm=warm, t_vox=t_vox / len(times), n_vox=n_vox, res=res, cut_short=False)
 
     # >= 20 passes after 3 warm-ups where they fit the budget (~45 s for the all-core sample, ~15 s for the 64-thread one)
+    threads_before = torch.get_num_threads()
     allc = sample(ncpu, 3, budget_s[0], 20)
     s64 = sample(64, 1, budget_s[1], 10) if ncpu > 64 else None
+    # hand the host back to the launch thread: the measurements that follow in this process (the `also` legs) must not find 64 / 256-thread
+    # intra-op pools behind every small host-side tensor operation
+    torch.set_num_threads(max(1, min(threads_before, 8)))
+    oops.set_threads(1)
     best = allc if (s64 is None or allc["sec"] <= s64["sec"]) else s64
     res, n_vox = best["res"], best["n_vox"]
 
