@@ -19,6 +19,13 @@ namespace {
 constexpr int kSelThreads = 1024;
 constexpr int kMaxPre = 4096;  // nms_pre_max_size bound (64 lanes x 64 bits in the sweep)
 
+// test_cfg.circular_nms (center_head.py:722-725, core/utils/circle_nms_jit.py): the suppression predicate of decode group g is
+// "squared centre distance <= r[g / per]" instead of the rotated IoU; per = 0: rotated NMS
+struct CircleCfg {
+    int per;
+    float r[16];
+};
+
 // ---------------------------------------------------------------- rotated BEV IoU
 // Same quantity as det3d/ops/iou3d_nms/src/iou3d_nms_kernel.cu:104-234 (overlap polygon of two rotated rectangles =
 // edge/edge crossing points + corners of one lying inside the other, ordered by angle around their mean, fan area),
@@ -368,7 +375,7 @@ __global__ void __launch_bounds__(kSelThreads) dec_select(const unsigned *__rest
             __syncthreads();
         }
     }
-    if (tid == 0) sel_count[g] = S;
+    if (tid == 0) { sel_count[g] = S; sel_count[gridDim.x + g] = M; }  // [G] taken, [G] valid candidates
     // box decode for the selected cells only
     for (int i = tid; i < S; i += kSelThreads) {
         const unsigned long long e = s_sort[i];
@@ -582,7 +589,7 @@ __global__ void __launch_bounds__(kSelThreads) dec_select_hist(const unsigned *_
             }
         }
     }
-    if (tid == 0) sel_count[g] = M < c.pre_max ? M : c.pre_max;
+    if (tid == 0) { sel_count[g] = M < c.pre_max ? M : c.pre_max; sel_count[gridDim.x + g] = M; }  // [G] taken, [G] valid candidates
     FD_DT(3);
     if (bsel < 0 || need <= 0 || all_in) return;  // (uniform)
     if (list) {
@@ -694,7 +701,7 @@ __global__ void __launch_bounds__(256) dec_rank_decode(const unsigned long long 
 // Pairs whose centres are farther apart than the two half-diagonals (+0.1 m, which covers the 1e-2 corner-inside
 // margin) cannot produce a crossing point or an inside corner, so their overlap is exactly 0; they skip the geometry.
 __global__ void __launch_bounds__(256) nms_mask(const float4 *__restrict__ planes, int64_t n_total, const int *__restrict__ counts, int n_max,
-                                                int col_blocks, float thr, unsigned long long *__restrict__ mask_all) {
+                                                int col_blocks, float thr, CircleCfg cc, unsigned long long *__restrict__ mask_all) {
     const int g = blockIdx.z, cb = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -705,7 +712,15 @@ __global__ void __launch_bounds__(256) nms_mask(const float4 *__restrict__ plane
     const int64_t base = (int64_t)g * n_max;
     const int col = cb * 64 + lane;
     bool hit = false;
-    if (col < n && col > row) {
+    if (cc.per > 0) {
+        // circle_nms_jit.py:21-25 on float32 scalars: dist = (x_i - x_j)**2 + (y_i - y_j)**2 (each product and the sum rounded, no fma:
+        // the file is compiled with -ffp-contract=off), suppressed when dist <= thresh -- the threshold is compared with the SQUARED distance
+        if (col < n && col > row) {
+            const float4 a = planes[2 * n_total + base + row], b = planes[2 * n_total + base + col];
+            const float dx = a.x - b.x, dy = a.y - b.y;
+            hit = dx * dx + dy * dy <= cc.r[g / cc.per];
+        }
+    } else if (col < n && col > row) {
         const Footprint cur = load_footprint(planes, n_total, base + row), oth = load_footprint(planes, n_total, base + col);
         const float dx = cur.cx - oth.cx, dy = cur.cy - oth.cy;
         const float reach = cur.reach + oth.reach + 0.1f;
@@ -718,7 +733,7 @@ __global__ void __launch_bounds__(256) nms_mask(const float4 *__restrict__ plane
 // ---------------------------------------------------------------- stage 4: greedy sweep, one wave per group
 __global__ void __launch_bounds__(64) nms_sweep(const unsigned long long *__restrict__ mask_all, const int *__restrict__ counts, int n_max,
                                                 int col_blocks, int post_max, int *__restrict__ keep_all /*[G,post_cap]*/, int post_cap,
-                                                int *__restrict__ out_count) {
+                                                int *__restrict__ out_count, const int *__restrict__ totals) {
     const int g = blockIdx.x, lane = threadIdx.x;
     const int n = counts ? counts[g] : n_max;
     const unsigned long long *mask = mask_all + (int64_t)g * n_max * col_blocks;
@@ -749,7 +764,9 @@ __global__ void __launch_bounds__(64) nms_sweep(const unsigned long long *__rest
             if (lane < col_blocks && lane > blk) remv |= mask[(int64_t)(blk * 64 + t) * col_blocks + lane];
         }
     }
-    if (lane == 0) out_count[g] = kept;
+    // circular NMS has no pre-NMS cut in the reference: a group with more candidates than were taken is decided only if post_max rows were
+    // kept among the taken ones (greedy in score order: the first post_max kept rows do not depend on later candidates); else count = -1
+    if (lane == 0) out_count[g] = (totals && totals[g] > n_max && kept < post_max) ? -1 : kept;
 }
 
 __global__ void __launch_bounds__(128) dec_gather(const int *__restrict__ keep_all, const int *__restrict__ kept_count, int post_max, int pre_max,
@@ -804,7 +821,7 @@ __global__ void __launch_bounds__(1024) nms_sweep_tail(const unsigned long long 
                                                        int post_max, const float *__restrict__ sel_boxes, const float *__restrict__ sel_scores,
                                                        const int *__restrict__ sel_cell, float *__restrict__ out_boxes, float *__restrict__ out_scores,
                                                        int *__restrict__ out_cell, int *__restrict__ out_count, MapView vel, AsmSteps st, int B,
-                                                       float *__restrict__ packed, int *__restrict__ counts_out) {
+                                                       float *__restrict__ packed, int *__restrict__ counts_out, const int *__restrict__ totals) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *s_mask = reinterpret_cast<unsigned long long *>(smem);              // [n_max][col_blocks]
     int *s_keep = reinterpret_cast<int *>(s_mask + (size_t)n_max * col_blocks);             // [128] kept rows, [128] = their number
@@ -887,8 +904,10 @@ __global__ void __launch_bounds__(1024) nms_sweep_tail(const unsigned long long 
     }
     __syncthreads();
     FD_DT(13);
-    const int kept = s_keep[128];
-    if (tid == 0) out_count[g] = kept;
+    const bool undecided = totals && totals[g] > n_max && s_keep[128] < post_max;  // (see nms_sweep: circular NMS only) -> count -1, no rows
+    const int kept = undecided ? 0 : s_keep[128];
+    const int kept_out = undecided ? -1 : kept;
+    if (tid == 0) out_count[g] = kept_out;
     for (int k = tid; k < post_max; k += 1024) {
         const int64_t o = (int64_t)g * post_max + k;
         if (k < kept) {
@@ -906,7 +925,7 @@ __global__ void __launch_bounds__(1024) nms_sweep_tail(const unsigned long long 
     const int grp = g / B, b = g - grp * B;  // decode groups are group-major: [G][B]
     for (int s_i = 0; s_i < st.S; ++s_i) {
         if (st.group[s_i] != grp) continue;
-        if (tid == 0) counts_out[b * st.S + s_i] = kept;
+        if (tid == 0) counts_out[b * st.S + s_i] = kept_out;
         for (int k = tid; k < post_max; k += 1024) {
             float *o = packed + (((int64_t)b * st.S + s_i) * post_max + k) * 11;
             if (k < kept) {
@@ -943,7 +962,7 @@ DecWs dec_layout(int G, int HW, int pre_max, int post_max) {
     w.nms_boxes = take(sizeof(float) * 7 * (size_t)G * pre_max);
     w.sel_scores = take(sizeof(float) * (size_t)G * pre_max);
     w.sel_cell = take(sizeof(int) * (size_t)G * pre_max);
-    w.sel_count = take(sizeof(int) * (size_t)G);
+    w.sel_count = take(sizeof(int) * 2 * (size_t)G);  // taken [G] | valid candidates [G]
     w.mask = take(sizeof(unsigned long long) * (size_t)G * pre_max * w.col_blocks);
     w.keep = take(sizeof(int) * (size_t)G * post_max);
     w.foot = take(sizeof(Footprint) * (size_t)G * pre_max);
@@ -1016,6 +1035,19 @@ int decode_impl(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view
     c.pre_max = cfg->nms_pre_max; c.post_max = cfg->nms_post_max;
     c.hm_channels = cfg->hm_channels > 1 ? cfg->hm_channels : 1;
     FD_REQUIRE(c.hm_channels <= 16, "fd_centerpoint_decode: hm_channels must be <= 16");
+    CircleCfg cc;
+    cc.per = 0;
+    for (float &r : cc.r) r = 0.f;
+    FD_REQUIRE(cfg->nms_kind == 0 || cfg->nms_kind == 1, "fd_centerpoint_decode: nms_kind must be 0 (rotated) or 1 (circular), got %d", cfg->nms_kind);
+    if (cfg->nms_kind == 1) {
+        FD_REQUIRE(cfg->n_radius >= 1 && cfg->n_radius <= 16 && G % cfg->n_radius == 0,
+                   "fd_centerpoint_decode: circular NMS needs 1 <= n_radius <= 16 dividing G (got %d, G = %d)", cfg->n_radius, G);
+        cc.per = G / cfg->n_radius;
+        for (int i = 0; i < cfg->n_radius; ++i) {
+            FD_REQUIRE(cfg->circle_radius[i] >= 0.f, "fd_centerpoint_decode: circle_radius[%d] must be >= 0", i);  // (also refuses NaN)
+            cc.r[i] = cfg->circle_radius[i];
+        }
+    }
     DecWs w = dec_layout(G, c.HW, c.pre_max, c.post_max);
     if (!workspace || workspace_bytes < w.total) {
         fd::set_error("fd_centerpoint_decode: workspace %zu < required %zu", workspace_bytes, w.total);
@@ -1025,6 +1057,7 @@ int decode_impl(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view
     unsigned *keys = (unsigned *)(ws + w.keys);
     float *sel_boxes = (float *)(ws + w.sel_boxes), *nms_boxes = (float *)(ws + w.nms_boxes), *sel_scores = (float *)(ws + w.sel_scores);
     int *sel_cell = (int *)(ws + w.sel_cell), *sel_count = (int *)(ws + w.sel_count), *keep = (int *)(ws + w.keep);
+    const int *totals = cc.per > 0 ? sel_count + G : nullptr;
     unsigned long long *mask = (unsigned long long *)(ws + w.mask);
     float4 *foot = (float4 *)(ws + w.foot);
     const int64_t n_total = (int64_t)G * c.pre_max;
@@ -1052,7 +1085,7 @@ int decode_impl(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view
         hipLaunchKernelGGL(footprint_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, stream, nms_boxes, sel_count, c.pre_max, G, foot);
     }
     hipLaunchKernelGGL(nms_mask, dim3((c.pre_max + 3) / 4, w.col_blocks, G), dim3(256), 0, stream, foot, n_total, sel_count, c.pre_max, w.col_blocks,
-                       c.iou_thr, mask);
+                       c.iou_thr, cc, mask);
     // sweep + gather (+ packed assembly) in one launch when the group's mask words fit the LDS; else the round-4 kernels
     const size_t sweep_lds = (size_t)c.pre_max * w.col_blocks * 8 + 129 * 4 + 12;
     static std::atomic<uint64_t> lds_set{0};
@@ -1062,9 +1095,9 @@ int decode_impl(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view
     if (fused) {
         hipLaunchKernelGGL(nms_sweep_tail, dim3(G), dim3(1024), sweep_lds, stream, mask, sel_count, c.pre_max, w.col_blocks, c.post_max, sel_boxes, sel_scores,
                            sel_cell, out_boxes7, out_scores, out_cell, out_count, vel ? as_view(*vel) : MapView{nullptr, 0, 0, 0, 0}, steps ? *steps : none,
-                           B > 0 ? B : 1, vel ? packed : nullptr, counts_out);
+                           B > 0 ? B : 1, vel ? packed : nullptr, counts_out, totals);
     } else {
-        hipLaunchKernelGGL(nms_sweep, dim3(G), dim3(64), 0, stream, mask, sel_count, c.pre_max, w.col_blocks, c.post_max, keep, c.post_max, out_count);
+        hipLaunchKernelGGL(nms_sweep, dim3(G), dim3(64), 0, stream, mask, sel_count, c.pre_max, w.col_blocks, c.post_max, keep, c.post_max, out_count, totals);
         hipLaunchKernelGGL(dec_gather, dim3(G), dim3(128), 0, stream, keep, out_count, c.post_max, c.pre_max, sel_boxes, sel_scores, sel_cell, out_boxes7,
                            out_scores, out_cell);
         if (vel)
@@ -1162,8 +1195,8 @@ extern "C" int fd_rotated_nms(const float *boxes7, int n, float thresh, int64_t 
     int *keep32 = (int *)((char *)workspace + fd::align_up(sizeof(unsigned long long) * (size_t)n * cb, 256));
     float4 *foot = (float4 *)((char *)keep32 + fd::align_up(sizeof(int) * (size_t)n, 256));
     hipLaunchKernelGGL(footprint_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, boxes7, (const int *)nullptr, n, 1, foot);
-    hipLaunchKernelGGL(nms_mask, dim3((n + 3) / 4, cb, 1), dim3(256), 0, stream, foot, (int64_t)n, (const int *)nullptr, n, cb, thresh, mask);
-    hipLaunchKernelGGL(nms_sweep, dim3(1), dim3(64), 0, stream, mask, (const int *)nullptr, n, cb, n, keep32, n, out_count);
+    hipLaunchKernelGGL(nms_mask, dim3((n + 3) / 4, cb, 1), dim3(256), 0, stream, foot, (int64_t)n, (const int *)nullptr, n, cb, thresh, CircleCfg{0, {}}, mask);
+    hipLaunchKernelGGL(nms_sweep, dim3(1), dim3(64), 0, stream, mask, (const int *)nullptr, n, cb, n, keep32, n, out_count, (const int *)nullptr);
     hipLaunchKernelGGL(keep_to_i64, dim3((n + 255) / 256), dim3(256), 0, stream, keep32, out_count, n, (long long *)keep);
     return fd::check_launch("fd_rotated_nms");
 }

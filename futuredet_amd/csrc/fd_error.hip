@@ -129,7 +129,7 @@ int fd::fill_words(void *p, uint32_t value, size_t n_words, hipStream_t stream) 
 }
 
 extern "C" const char *fd_last_error(void) { return fd::g_err; }
-extern "C" int fd_abi_version(void) { return 7; }
+extern "C" int fd_abi_version(void) { return 8; }
 
 extern "C" int fd_tuning_set(const char *name, int value) {
     FD_REQUIRE(name, "fd_tuning_set: null name");

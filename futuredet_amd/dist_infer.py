@@ -186,6 +186,8 @@ def gather_results(packed, counts, n_samples=None):
 def unpack_results(packed, counts):
     """-> list (per sample) of dicts with box3d_lidar [K,9], scores [K], label_preds [K] (reference output keys)."""
     n, S, post, _ = packed.shape
+    if bool((counts < 0).any()):  # fd_decode_cfg, nms_kind 1: a group the circular NMS could not decide from the candidates it took
+        raise RuntimeError("a decode group reports count -1 (circular NMS, more candidates than the kernels take: see include/futuredet_hip.h)")
     valid = torch.arange(post, device=packed.device).view(1, 1, post) < counts.unsqueeze(-1).to(packed.device)
     out = []
     for i in range(n):

@@ -188,6 +188,28 @@ class CenterHead(nn.Module):
         vels = [pd["vel"] for pd in preds_dicts]  # center_head.py:606-607 (dense), :589-595 (classify: one class per step after the channel max)
         return list(preds_dicts), vels, list(range(len(preds_dicts))), [1] * len(preds_dicts) if self.classify else list(self.num_classes)
 
+    @staticmethod
+    def _circular(test_cfg):
+        """test_cfg.circular_nms (center_head.py:722-725).  ``per_class_nms`` has nothing to reproduce: the reference's branch is ``pass``
+        (:668-669), no task's result is collected and predict fails on ``rets[0]`` two lines later."""
+        if test_cfg.get("per_class_nms", False):
+            raise NotImplementedError("test_cfg.per_class_nms: the reference's branch is empty (center_head.py:668-669) and its predict fails on rets[0]")
+        return bool(test_cfg.get("circular_nms", False))
+
+    @staticmethod
+    def _group_radius(test_cfg, step_group, G):
+        """``test_cfg.min_radius[task_id]`` (center_head.py:724; task_id = output step, :609) per decode group; None when two steps of one
+        group differ.  A scalar ``min_radius`` (as every shipped config writes it) fails here as it does in the reference."""
+        radii = test_cfg["min_radius"]
+        per_step = [float(radii[s]) for s in range(len(step_group))]  # TypeError for a scalar, IndexError for a short list: the reference's own
+        out = [None] * G
+        for s, g in enumerate(step_group):
+            if out[g] is None:
+                out[g] = per_step[s]
+            elif out[g] != per_step[s]:
+                return None
+        return [0.0 if r is None else r for r in out]
+
     @torch.no_grad()
     def predict_packed(self, preds_dicts, test_cfg):
         """Device-only decode straight from the convolution plan's NHWC output buffer: (packed [B,S,post,11] float32 rows
@@ -198,8 +220,7 @@ class CenterHead(nn.Module):
         raws = [getattr(pd, "raw", None) for pd in preds_dicts]
         if any(r is None for r in raws) or any(r[0] is not raws[0][0] or r[2] != raws[0][2] for r in raws):
             return None
-        if test_cfg.get("per_class_nms", False) or test_cfg.get("circular_nms", False):
-            raise NotImplementedError("only rotated NMS is configured in the shipped test_cfg")
+        circular = self._circular(test_cfg)
         zbuf, _, where = raws[0]
         T, B, H, W, C = zbuf.shape
         hm_channels = where["hm"][1]
@@ -234,8 +255,13 @@ class CenterHead(nn.Module):
         ck = (zbuf.device, B, S, int(test_cfg["nms"]["nms_post_max_size"]))
         if ck not in cache:  # labels do not depend on the data (built in the eager set-up pass, before any graph capture)
             cache[ck] = torch.as_tensor(labels, dtype=torch.int64, device=zbuf.device).view(1, S, 1).expand(B, S, ck[3]).contiguous()
+        group_radius = None
+        if circular:
+            group_radius = self._group_radius(test_cfg, step_group, G)
+            if group_radius is None:  # steps that share a decode group ask for different radii: one group per step (predict_padded)
+                return None
         flat = zbuf[:G].reshape(G * B, H, W, C)
-        cfg = hip_ops.make_decode_cfg(H, W, test_cfg, hm_channels=hm_channels)
+        cfg = hip_ops.make_decode_cfg(H, W, test_cfg, hm_channels=hm_channels, group_radius=group_radius)
         views = [hip_ops.nhwc_channel_view(flat, where[k][0]) for k in ("hm", "reg", "height", "dim", "rot")]
         return hip_ops.centerpoint_decode_packed(views, hip_ops.nhwc_channel_view(flat, where["vel"][0]), G * B, B, cfg, zbuf.device, step_group, step_vel, labels)
 
@@ -248,14 +274,18 @@ class CenterHead(nn.Module):
             packed, counts = fused
             B, S, post, _ = packed.shape
             return packed[..., :9], packed[..., 9], self._lab_cache[(packed.device, B, S, post)], counts
-        if test_cfg.get("per_class_nms", False) or test_cfg.get("circular_nms", False):
-            raise NotImplementedError("only rotated NMS is configured in the shipped test_cfg")
         srcs, vels, step_group, num_classes = self._groups(preds_dicts)
+        group_radius = None
+        if self._circular(test_cfg):
+            group_radius = self._group_radius(test_cfg, step_group, len(srcs))
+            if group_radius is None:  # a decode group per output step, each with its step's radius
+                srcs, step_group = [srcs[g] for g in step_group], list(range(len(step_group)))
+                group_radius = self._group_radius(test_cfg, step_group, len(srcs))
         B, hm_channels, H, W = srcs[0]["hm"].shape
         assert all(s["hm"].shape[1] == hm_channels for s in srcs) and (hm_channels == 1 or self.classify), \
             "multi-class heat-maps are decoded as their channel maximum only in the classify mode (center_head.py:589-595)"
         f = lambda k: torch.cat([s[k].float() for s in srcs], 0).contiguous() if len(srcs) > 1 else srcs[0][k].float().contiguous()  # noqa: E731
-        cfg = hip_ops.make_decode_cfg(H, W, test_cfg, hm_channels=hm_channels)
+        cfg = hip_ops.make_decode_cfg(H, W, test_cfg, hm_channels=hm_channels, group_radius=group_radius)
         boxes7, scores, cell, count = hip_ops.centerpoint_decode(f("hm"), f("reg"), f("height"), f("dim"), f("rot"), cfg)
         post = cfg.nms_post_max
         G = len(srcs)
@@ -290,6 +320,9 @@ class CenterHead(nn.Module):
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
         boxes, scores, labels, counts = self.predict_padded(preds_dicts, test_cfg)
         B, S, post, _ = boxes.shape
+        if test_cfg.get("circular_nms", False) and bool((counts < 0).any()):
+            raise RuntimeError("circular NMS: a group holds more than %d candidates above the score threshold and keeps fewer than nms_post_max_size of "
+                               "them -- the reference's uncut result cannot be reproduced from the candidates taken (raise score_threshold)" % hip_ops.CIRCLE_PRE_MAX)
         valid = torch.arange(post, device=boxes.device).view(1, 1, post) < counts.unsqueeze(-1)
         metas = example.get("metadata") if isinstance(example, dict) else None
         ret = []

@@ -525,9 +525,14 @@ def conv2d_wino_f32_num_tiles():
 
 
 # ------------------------------------------------------------------------------------------------ decode / NMS
-def make_decode_cfg(H, W, test_cfg, hm_channels=1):
+CIRCLE_PRE_MAX = 4096  # candidates taken per group under circular NMS (the kernels' bound; the reference applies no cut there)
+
+
+def make_decode_cfg(H, W, test_cfg, hm_channels=1, group_radius=None):
     """``hm_channels`` > 1: the score of a cell is the maximum over that many heat-map channels (CenterHead's ``classify``
-    mode, center_head.py:589-595: torch.max(hm, dim=1) before the sigmoid)."""
+    mode, center_head.py:589-595: torch.max(hm, dim=1) before the sigmoid).  ``group_radius``: test_cfg.circular_nms
+    (center_head.py:722-725) -- one ``min_radius`` per decode group; the rotated-IoU predicate is replaced by the centre
+    distance and the pre-NMS cut by the kernels' maximum (see fd_decode_cfg in include/futuredet_hip.h)."""
     c = DecodeCfg()
     c.hm_channels = int(hm_channels)
     c.H, c.W = int(H), int(W)
@@ -541,6 +546,13 @@ def make_decode_cfg(H, W, test_cfg, hm_channels=1):
     c.nms_iou_threshold = float(nms["nms_iou_threshold"])
     c.nms_pre_max = int(nms["nms_pre_max_size"])
     c.nms_post_max = int(nms["nms_post_max_size"])
+    if group_radius is not None:
+        if not 1 <= len(group_radius) <= 16:
+            raise ValueError("circular NMS: 1..16 decode groups, got %d radii" % len(group_radius))
+        c.nms_kind, c.n_radius = 1, len(group_radius)
+        c.nms_pre_max = CIRCLE_PRE_MAX
+        for i, r in enumerate(group_radius):
+            c.circle_radius[i] = float(r)
     return c
 
 

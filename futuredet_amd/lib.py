@@ -23,10 +23,14 @@ class MapView(ctypes.Structure):
                 ("dtype", ctypes.c_int)]
 
 
-class DecodeCfg(ctypes.Structure):
+ABI_VERSION = 8  # include/futuredet_hip.h: fd_abi_version()
+
+
+class DecodeCfg(ctypes.Structure):  # struct fd_decode_cfg
     _fields_ = [("H", c_int), ("W", c_int), ("out_size_factor", c_float), ("voxel_x", c_float), ("voxel_y", c_float),
                 ("pc_x", c_float), ("pc_y", c_float), ("score_threshold", c_float), ("center_range", c_float * 6),
-                ("nms_iou_threshold", c_float), ("nms_pre_max", c_int), ("nms_post_max", c_int), ("hm_channels", c_int)]
+                ("nms_iou_threshold", c_float), ("nms_pre_max", c_int), ("nms_post_max", c_int), ("hm_channels", c_int),
+                ("nms_kind", c_int), ("n_radius", c_int), ("circle_radius", c_float * 16)]
 
 
 class IndexLevel(ctypes.Structure):  # struct fd_index_level
@@ -139,6 +143,9 @@ def load():
             fn = getattr(L, name)  # AttributeError = ABI mismatch, let it propagate
             fn.restype = res
             fn.argtypes = args
+        if L.fd_abi_version() != ABI_VERSION:  # a stale build would read the structs below with another layout
+            raise FutureDetHipError("%s reports ABI %d, these bindings are written for %d: rebuild it (python futuredet_amd/build.py --force)"
+                                    % (LIB_PATH, L.fd_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

@@ -28,8 +28,9 @@ extern "C" {
 
 typedef void *fd_stream_t; /* hipStream_t */
 
-int fd_abi_version(void); /* 7 (round 6: + fd_forecast_from_detections / fd_forecast_buffers; fd_sweep_assemble takes n_rows as an upper
-                             * bound -- rows past the last descriptor's row_end are dropped) */
+int fd_abi_version(void); /* 8 (round 6.  7: + fd_forecast_from_detections / fd_forecast_buffers; fd_sweep_assemble takes n_rows as an upper
+                             * bound -- rows past the last descriptor's row_end are dropped.  8: struct fd_decode_cfg grew by nms_kind /
+                             * n_radius / circle_radius (circular NMS) -- callers must zero-initialise the struct) */
 const char *fd_last_error(void);
 /* Tuning / test knobs (no reference counterpart).  0 = built-in heuristic.  Names: "spconv_rg" (rows per wave of the
  * register sparse-conv kernel: 1|2|4), "spconv_v1" (1: fp32 on the register kernel instead of the compacting one),
@@ -229,6 +230,17 @@ typedef struct fd_decode_cfg {
     float nms_iou_threshold;
     int nms_pre_max, nms_post_max;
     int hm_channels; /* 0 / 1: one heat-map channel; n > 1: score = max over n channels (center_head.py:589-595, the `classify` head) */
+    /* test_cfg.circular_nms (center_head.py:722-725 -> _circle_nms :750-758 -> core/utils/circle_nms_jit.py): nms_kind 1 replaces the
+     * rotated-IoU predicate by "squared centre distance <= min_radius" (the reference compares min_radius with the SQUARED distance, in
+     * float32); decode group g takes circle_radius[g / (G / n_radius)] (test_cfg.min_radius[task_id]: one entry per group, n_radius must
+     * divide G).  The reference applies no pre-NMS cut in this mode; here the nms_pre_max (<= 4096) best candidates are taken, which gives
+     * the reference's result whenever a group has no more candidates than that OR nms_post_max boxes are kept among them (the greedy
+     * order makes the first kept boxes independent of later candidates).  A group for which neither holds reports count -1 and no rows
+     * (out_count and counts_out): never a silently different answer.  Equal scores: the reference's order among them is numpy's
+     * unstable argsort reversed, here the lower cell index first. */
+    int nms_kind; /* 0: rotated BEV IoU > nms_iou_threshold (rotate_nms_pcdet); 1: circular */
+    int n_radius; /* nms_kind 1: entries of circle_radius in use, 1..16 */
+    float circle_radius[16];
 } fd_decode_cfg;
 
 /* A head map as the decode reads it: element (group g, channel ch, BEV cell) of a float32 (dtype 0) or bf16 (dtype 1) tensor at

@@ -278,7 +278,7 @@ class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from 
             ys = ys * test_cfg["out_size_factor"] * test_cfg["voxel_size"][1] + test_cfg["pc_range"][1]
             vel = pd["vel"].reshape(B, H * W, 2)
             boxes = torch.cat([xs, ys, hei, dim, vel, rot], dim=2)
-            rets.append(self.post_processing(boxes, hm, test_cfg, post_range))
+            rets.append(self.post_processing(boxes, hm, test_cfg, post_range, len(rets)))
         out = []
         for i in range(len(rets[0])):
             flag = 0
@@ -292,7 +292,7 @@ class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from 
         return out
 
     @staticmethod
-    def post_processing(batch_box_preds, batch_hm, test_cfg, post_range):  # :699-747
+    def post_processing(batch_box_preds, batch_hm, test_cfg, post_range, task_id=0):  # :699-747
         nms_cfg = test_cfg["nms"]
         res = []
         for i in range(len(batch_hm)):
@@ -301,11 +301,34 @@ class CenterHead(nn.Module):  # center_head.py:232-390 (branches reachable from 
             mask = (scores > test_cfg["score_threshold"]) \
                 & (box_preds[..., :3] >= post_range[:3]).all(1) & (box_preds[..., :3] <= post_range[3:]).all(1)
             box_preds, scores, labels = box_preds[mask], scores[mask], labels[mask]
-            sel = rotate_nms_pcdet(box_preds[:, [0, 1, 2, 3, 4, 5, -1]].float(), scores.float(),
-                                   nms_cfg["nms_iou_threshold"], nms_cfg["nms_pre_max_size"],
-                                   nms_cfg["nms_post_max_size"])
+            if test_cfg.get("circular_nms", False):  # :722-725, _circle_nms :750-758: no pre-NMS cut in this mode
+                dets = torch.cat([box_preds[:, [0, 1]], scores.view(-1, 1)], dim=1).numpy()
+                sel = torch.from_numpy(np.asarray(circle_nms(dets, test_cfg["min_radius"][task_id])[:nms_cfg["nms_post_max_size"]], np.int64))
+            else:
+                sel = rotate_nms_pcdet(box_preds[:, [0, 1, 2, 3, 4, 5, -1]].float(), scores.float(),
+                                       nms_cfg["nms_iou_threshold"], nms_cfg["nms_pre_max_size"],
+                                       nms_cfg["nms_post_max_size"])
             res.append({"box3d_lidar": box_preds[sel], "scores": scores[sel], "label_preds": labels[sel]})
         return res
+
+
+def circle_nms(dets, thresh):  # core/utils/circle_nms_jit.py:5-27, dets [n,3] float32 = x, y, score
+    """Greedy by descending score; a later box is suppressed when its SQUARED centre distance to a kept one is <= thresh (float32
+    products and sum, as numpy evaluates the reference's expression on float32 scalars when numba is an identity decorator -- which is how
+    tests/golden/make_golden.py runs it).  Vectorised per kept box; the visiting order and every comparison are the loop's."""
+    x, y = dets[:, 0], dets[:, 1]
+    order = dets[:, 2].argsort()[::-1]
+    alive = np.ones(len(dets), bool)
+    thr = np.float32(thresh)
+    keep = []
+    for pos, i in enumerate(order):
+        if not alive[i]:
+            continue
+        keep.append(int(i))
+        rest = order[pos + 1:]
+        dx, dy = x[i] - x[rest], y[i] - y[rest]
+        alive[rest[dx * dx + dy * dy <= thr]] = False
+    return keep
 
 
 def rotate_nms_pcdet(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):  # box_torch_ops.py:248-277

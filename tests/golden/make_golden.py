@@ -232,6 +232,11 @@ def gen_dense_nets():
     save("dense_nets.npz", **out)
 
 
+# circular-NMS cases of predict.npz: min_radius per output step (compared with the SQUARED centre distance).  "circ": one radius for the
+# standard head's shared boxes; "circv": a radius per step (the shared boxes go through NMS once per step); "circd": a task per step
+CIRCLE_RADII = {"circ": [6.0] * 7, "circv": [0.5, 1.0, 2.0, 3.0, 4.5, 0.25, 8.0], "circd": [4.0, 0.85, 1.0, 0.175, 2.0, 10.0, 12.0]}
+
+
 def gen_predict():
     """Reference CenterHead.predict (decode + rotated NMS through the compiled reference IoU)."""
     from det3d.models import build_head
@@ -247,7 +252,8 @@ def gen_predict():
     # "rev" / "sp": reverse (decoded like the standard head) and sparse (a forward and a reverse task, 2 x 7 output steps)
     for name, T, dense, H, W, B in (("n0", 1, False, 40, 48, 2), ("n3", 7, False, 40, 48, 2),
                                     ("n3dtf", 7, True, 24, 24, 1), ("n0big", 1, False, 180, 180, 1), ("cls", 3, False, 24, 28, 2),
-                                    ("rev", 7, False, 20, 28, 2), ("sp", 7, False, 28, 20, 2), ("wide", 7, False, 24, 20, 2)):
+                                    ("rev", 7, False, 20, 28, 2), ("sp", 7, False, 28, 20, 2), ("wide", 7, False, 24, 20, 2),
+                                    ("circ", 7, False, 36, 44, 2), ("circv", 7, False, 32, 36, 2), ("circd", 7, True, 28, 24, 1)):
         classify = name == "cls"
         head = build_head(dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])],
                                dataset="nuscenes", weight=0.25, code_weights=[1.0] * 10,
@@ -271,7 +277,11 @@ def gen_predict():
             for k, v in pd.items():
                 out["%s_in_t%d_%s" % (name, ti, k)] = v.numpy().copy()
         example = {"metadata": [None] * B}
-        rets = head.predict(example, [dict(p) for p in preds], test_cfg)
+        cfg_case = test_cfg
+        if name in CIRCLE_RADII:  # test_cfg.circular_nms (center_head.py:722-725): circle_nms_jit.py runs as plain Python under the numba stub
+            cfg_case = ConfigDict(dict(test_cfg, circular_nms=True, min_radius=CIRCLE_RADII[name]))
+            out["%s_min_radius" % name] = np.asarray(CIRCLE_RADII[name], np.float64)
+        rets = head.predict(example, [dict(p) for p in preds], cfg_case)
         for b, r in enumerate(rets):
             out["%s_out_b%d_boxes" % (name, b)] = r["box3d_lidar"].numpy()
             out["%s_out_b%d_scores" % (name, b)] = r["scores"].numpy()

@@ -520,6 +520,75 @@ def test_predict_matches_reference_golden(hip, golden, name, T, dense):
             assert_close("predict golden %s b%d rows in order" % (name, b), got, want, 1e-3)
 
 
+@pytest.mark.parametrize("name,T,dense", [("circ", 7, False), ("circv", 7, False), ("circd", 7, True)])
+def test_predict_circular_nms_matches_reference_golden(hip, golden, name, T, dense):
+    """test_cfg.circular_nms (center_head.py:722-725 -> circle_nms_jit.py): CenterHead.predict on HIP vs the reference's own predict with
+    circular_nms=True.  "circ": one radius for the standard head's shared boxes (one decode group); "circv": a radius per output step (the
+    shared boxes pass the NMS once per step: a decode group per step); "circd": a task per step, each with its radius.  The predicate is
+    float32 arithmetic on the box centres, which the decode reproduces bit for bit: rows equal in order."""
+    from futuredet_amd import build_head
+
+    g = golden("predict.npz")
+    head = build_head(dict(type="CenterHead", in_channels=64, tasks=[dict(num_class=1, class_names=["car"])], dataset="nuscenes", weight=0.25,
+                           code_weights=[1.0] * 10, common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
+                           share_conv_channel=64, dcn_head=False, timesteps=T, two_stage=False, dense=dense, bev_map=False, forecast_feature=False,
+                           classify=False)).cuda().eval()
+    preds = [{k: _dev(g["%s_in_t%d_%s" % (name, ti, k)]) for k in ("reg", "height", "dim", "rot", "vel", "hm")} for ti in range(T if dense else 1)]
+    B = preds[0]["hm"].shape[0]
+    cfg = dict(TEST_CFG, circular_nms=True, min_radius=[float(r) for r in g[name + "_min_radius"]])
+    rets = head.predict({"metadata": [None] * B}, preds, cfg)
+    for b, r in enumerate(rets):
+        want = np.concatenate([g["%s_out_b%d_boxes" % (name, b)], g["%s_out_b%d_scores" % (name, b)][:, None],
+                               g["%s_out_b%d_labels" % (name, b)][:, None].astype(np.float32)], 1)
+        got = _rows(r)
+        assert got.shape == want.shape, (name, b, got.shape, want.shape)
+        assert_close("predict golden %s b%d (circular NMS) rows in order" % (name, b), got, want, 1e-3)
+    # the reference's error behaviour: a scalar min_radius is not subscriptable (every shipped config writes min_radius=2), a short list runs out
+    with pytest.raises(TypeError):
+        head.predict({"metadata": [None] * B}, preds, dict(cfg, min_radius=2))
+    with pytest.raises(IndexError):
+        head.predict({"metadata": [None] * B}, preds, dict(cfg, min_radius=[2.0]))
+    with pytest.raises(NotImplementedError):  # center_head.py:668-669: the branch is `pass` and predict fails on rets[0]
+        head.predict({"metadata": [None] * B}, preds, dict(TEST_CFG, per_class_nms=True))
+
+
+@pytest.mark.parametrize("case", ["spread", "cluster", "below_cut"])
+def test_circular_nms_beyond_the_candidate_cut(hip, case):
+    """The reference applies no pre-NMS cut under circular_nms; the kernels take the 4096 best candidates of a group.  "spread": 32 400
+    candidates all over a 180 x 180 map -- nms_post_max_size boxes are kept long before the cut, the result is the uncut oracle's.
+    "cluster": the candidates beyond the cut could still be kept (everything taken lies inside a few circles, fewer than post_max kept):
+    the group reports count -1 and predict raises instead of returning a different answer.  "below_cut": 3000 candidates, all taken."""
+    from futuredet_amd import build_head
+    from oracle import model as omodel
+
+    rng = np.random.default_rng(5 + len(case))
+    H = W = 180
+    logit = rng.standard_normal((1, 1, H, W)).astype(np.float32)
+    radius = 3.0
+    if case == "cluster":
+        radius = 2.0e4  # one circle swallows the map: a single box is kept, 32 399 candidates lie beyond it
+    elif case == "below_cut":
+        logit -= 8.0
+        logit.reshape(-1)[rng.choice(H * W, 3000, replace=False)] += 9.0
+    preds = [dict(hm=logit, reg=rng.uniform(0, 1, (1, 2, H, W)).astype(np.float32), height=rng.normal(-1, 0.5, (1, 1, H, W)).astype(np.float32),
+                  dim=rng.normal(0.5, 0.1, (1, 3, H, W)).astype(np.float32), rot=rng.standard_normal((1, 2, H, W)).astype(np.float32),
+                  vel=rng.standard_normal((1, 2, H, W)).astype(np.float32))]
+    kw = dict(in_channels=64, tasks=[dict(num_class=1, class_names=["car"])], common_heads={"reg": (2, 2), "height": (1, 2), "dim": (3, 2), "rot": (2, 2), "vel": (2, 2)},
+              share_conv_channel=64, timesteps=1, classify=False)
+    head = build_head(dict(type="CenterHead", dataset="nuscenes", weight=0.25, code_weights=[1.0] * 10, **kw)).cuda().eval()
+    cfg = dict(TEST_CFG, circular_nms=True, min_radius=[radius] * 7)
+    dev = [{k: _dev(v) for k, v in preds[0].items()}]
+    if case == "cluster":
+        with pytest.raises(RuntimeError, match="circular NMS"):
+            head.predict({"metadata": [None]}, dev, cfg)
+        return
+    got = _rows(head.predict({"metadata": [None]}, dev, cfg)[0])
+    ohead = omodel.CenterHead(64, kw["tasks"], kw["common_heads"], timesteps=1, classify=False).eval()
+    want = _rows(ohead.predict({"metadata": [None]}, [{k: torch.from_numpy(v) for k, v in preds[0].items()}], cfg)[0])
+    assert got.shape == want.shape and len(got) == 7 * 83, (case, got.shape, want.shape)
+    assert_close("circular NMS, %s: %d candidates, rows in the oracle's order" % (case, int((logit > np.log(0.1 / 0.9)).sum())), got, want, 1e-3)
+
+
 @pytest.mark.parametrize("case", ["ties_across_cut", "all_equal", "pre_max_4096", "tiny_map", "few_valid"])
 def test_decode_selection_edge_cases(hip, case):
     """The pre-max selection of the decode (dec_keys_hist / dec_select_hist / dec_rank_decode, fd_decode.hip) against the definition --
@@ -953,6 +1022,16 @@ def test_reverse_and_sparse_heads_on_the_plan_and_packed_decode(hip, golden, mod
         assert len(packed[b]["scores"]) > 0
         assert np.array_equal(_rows(packed[b]), _rows(plain[b]))
         assert set(packed[b]["label_preds"].tolist()) <= set(range(steps))
+    # circular NMS through the packed decode (one launch set from the plan's NHWC buffer) = through the per-group path; a radius per output
+    # step: equal inside every decode group -> packed, different -> the head falls back to a decode group per step (same results either way)
+    for radii in ([1.5] * steps, [0.5 + 0.5 * s for s in range(steps)]):
+        ccfg = dict(cfg, circular_nms=True, min_radius=radii)
+        packed = head.predict({"metadata": [None] * y.shape[0]}, preds, ccfg)
+        plain = head.predict({"metadata": [None] * y.shape[0]}, [dict(pd) for pd in preds], ccfg)
+        for b in range(y.shape[0]):
+            assert len(packed[b]["scores"]) > 0
+            assert np.array_equal(_rows(packed[b]), _rows(plain[b]))
+    assert head.predict_packed(preds, dict(cfg, circular_nms=True, min_radius=[1.5] * steps)) is not None or mode == "wide_head"
 
 
 def test_unsupported_dense_stack_raises_instead_of_leaving_the_hip_path(hip):

@@ -193,9 +193,69 @@ def test_c_abi_exports_every_declared_symbol():
     nm = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (fd_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
-    assert L.fd_abi_version() == 7
+    assert L.fd_abi_version() == 8
     assert L.fd_index_num_cols(2, 180, 180) == 2 * 23 * 23 * 64
     assert L.fd_voxelize_workspace_bytes(1000, 100) > 0 and L.fd_nms_workspace_bytes(1000) >= 1000 * 16 * 8
+
+
+def test_ctypes_structs_mirror_the_header(tmp_path):
+    """The structs that cross the C ABI by pointer (fd_decode_cfg, fd_forecast_buffers, fd_index_level): the ctypes mirrors of lib.py hold
+    the header's members in the header's order and gcc gives them the same size -- a member added on one side only would shift every
+    field behind it without any symbol going missing."""
+    import ctypes
+
+    hdr = open(os.path.join(REPO, "include", "futuredet_hip.h")).read()
+    bare = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    pairs = {"fd_decode_cfg": lib.DecodeCfg, "fd_forecast_buffers": lib.ForecastBuffers, "fd_index_level": lib.IndexLevel}
+    prog = ['#include <stdio.h>', '#include "futuredet_hip.h"', "int main(void) {"]
+    for cname, mirror in pairs.items():
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), bare, flags=re.S).group(1)
+        members = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):  # "float out_size_factor, voxel_x" / "const void *words" / "float center_range[6]"
+                m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[(\d+)\])?\s*$", part.strip())
+                members.append((m.group(1), int(m.group(3)) if m.group(3) else None))
+        mine = [(n, getattr(t, "_length_", None)) for n, t in mirror._fields_]
+        assert mine == members, (cname, mine, members)
+        prog.append('    printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+    prog += ["    return 0;", "}"]
+    src = tmp_path / "sizes.c"
+    src.write_text("\n".join(prog) + "\n")
+    exe = str(tmp_path / "sizes")
+    subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), "-o", exe, str(src)])
+    sizes = dict(line.split() for line in subprocess.check_output([exe]).decode().splitlines())
+    for cname, mirror in pairs.items():
+        assert int(sizes[cname]) == ctypes.sizeof(mirror), (cname, sizes[cname], ctypes.sizeof(mirror))
+
+
+def test_circular_nms_configuration_follows_the_reference():
+    """test_cfg.circular_nms on the host side (no device work): min_radius is indexed by the output step like the reference's
+    ``test_cfg.min_radius[task_id]`` (center_head.py:609,724) -- a scalar is a TypeError there and here; steps that share a decode group
+    share its radius or the head decodes a group per step; the decode configuration takes the kernels' maximal candidate cut."""
+    from futuredet_amd import hip_ops
+    from futuredet_amd.heads import CenterHead
+
+    assert CenterHead._group_radius({"min_radius": [2.0] * 7}, [0] * 7, 1) == [2.0]
+    assert CenterHead._group_radius({"min_radius": [1.0, 1.0, 3.0, 3.0]}, [0, 0, 1, 1], 2) == [1.0, 3.0]
+    assert CenterHead._group_radius({"min_radius": [1.0, 2.0]}, [0, 0], 1) is None
+    with pytest.raises(TypeError):
+        CenterHead._group_radius({"min_radius": 2}, [0], 1)
+    with pytest.raises(IndexError):
+        CenterHead._group_radius({"min_radius": [2.0]}, [0, 0], 1)
+    assert CenterHead._circular({"circular_nms": True}) and not CenterHead._circular({})
+    with pytest.raises(NotImplementedError):
+        CenterHead._circular({"per_class_nms": True})
+    test_cfg = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0], nms=dict(nms_pre_max_size=1000, nms_post_max_size=83, nms_iou_threshold=0.2),
+                    score_threshold=0.1, pc_range=[-54, -54], out_size_factor=8, voxel_size=[0.075, 0.075])
+    c = hip_ops.make_decode_cfg(180, 180, test_cfg)
+    assert (c.nms_kind, c.n_radius, c.nms_pre_max) == (0, 0, 1000)
+    c = hip_ops.make_decode_cfg(180, 180, test_cfg, group_radius=[4.0, 0.85])
+    assert (c.nms_kind, c.n_radius, c.nms_pre_max) == (1, 2, hip_ops.CIRCLE_PRE_MAX) and list(c.circle_radius)[:3] == [4.0, np.float32(0.85), 0.0]
+    with pytest.raises(ValueError):
+        hip_ops.make_decode_cfg(180, 180, test_cfg, group_radius=[1.0] * 17)
 
 
 def test_product_path_fails_loudly_without_gpu_tensors():

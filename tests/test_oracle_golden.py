@@ -173,7 +173,8 @@ TEST_CFG = dict(post_center_limit_range=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
 
 
 @pytest.mark.parametrize("name,T,dense", [("n0", 1, False), ("n3", 7, False), ("n3dtf", 7, True), ("n0big", 1, False), ("cls", 3, False),
-                                          ("rev", 7, False), ("sp", 7, False), ("wide", 7, False)])
+                                          ("rev", 7, False), ("sp", 7, False), ("wide", 7, False),
+                                          ("circ", 7, False), ("circv", 7, False), ("circd", 7, True)])  # circ*: test_cfg.circular_nms
 def test_oracle_predict_matches_reference_golden(golden, name, T, dense):
     g = golden("predict.npz")
     classify = name == "cls"  # the reference constructor's default mode (center_head.py:253,589-595)
@@ -182,7 +183,10 @@ def test_oracle_predict_matches_reference_golden(golden, name, T, dense):
                              classify=classify, reverse=name == "rev", sparse=name == "sp", wide_head=name == "wide").eval()
     ntask = T if (dense or classify) else (2 if name == "sp" else 1)
     preds = [{k: torch.from_numpy(g["%s_in_t%d_%s" % (name, ti, k)]) for k in ("reg", "height", "dim", "rot", "vel", "hm")} for ti in range(ntask)]
-    rets = head.predict({"metadata": [None] * preds[0]["hm"].shape[0]}, preds, TEST_CFG)
+    cfg = TEST_CFG
+    if name + "_min_radius" in g:  # the reference's predict with circular_nms=True (center_head.py:722-725, circle_nms_jit.py)
+        cfg = dict(TEST_CFG, circular_nms=True, min_radius=[float(r) for r in g[name + "_min_radius"]])
+    rets = head.predict({"metadata": [None] * preds[0]["hm"].shape[0]}, preds, cfg)
     for b, r in enumerate(rets):
         assert np.array_equal(r["label_preds"].numpy(), g["%s_out_b%d_labels" % (name, b)])
         np.testing.assert_allclose(r["box3d_lidar"].numpy(), g["%s_out_b%d_boxes" % (name, b)], rtol=1e-6, atol=1e-6)
