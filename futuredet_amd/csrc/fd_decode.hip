@@ -78,9 +78,47 @@ __device__ inline bool inside_margin(const Footprint &f, float px, float py) {
 }
 
 constexpr int kMaxPoly = 24;  // 16 edge pairs can cross + 8 corners can be inside (never all at once)
+// The polygon's points and angles are indexed at run time (insertion sort over n points): they live in LDS -- element k of a thread at
+// [k * kPolyThreads + tid], conflict-free -- rather than in thread-private arrays, which would be scratch memory (208 bytes per lane).
+//
+// THIS FILE IS COMPILED WITH -fno-slp-vectorize (futuredet_amd/build.py).  With the SLP vectoriser on, the geometry below becomes ~500
+// packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32) per evaluation, and with several bf16 sweeps in flight 0.5-3 % of the sweeps came
+// back with a different detection list: single IoU decisions flipped far from the threshold (0.34 judged "no overlap", 0.02 judged
+// "overlap") while every tensor nms_mask reads was bit-identical.  A tuning build (-DFD_MASK_DEBUG) that pins the two footprints in
+// registers and evaluates every near pair again shows the two evaluations of one thread disagreeing 1.5e-3 of the time, ONLY in lanes
+// 48-63 of a wave, ONLY while waves of the bf16 3x3 dense convolution (v_mfma_f32_32x32x16_bf16) of another stream share the compute
+// unit -- never alone, never next to the fp32 kernels, the sparse convolutions or other decodes; self-checking loops of plain packed
+// arithmetic, divisions, branches, LDS arrays and atan2f (tools/probes/alu_probe.hip) do not reproduce it.  Without the packed
+// instructions: 0 of 8000 sweeps (4 in flight) and 0 of 1200 next to three looping RPN plans, where the packed build loses 46-80 of
+// 400.  Evidence and the way there: profiles/round6_determinism_soak.txt, tools/soak_determinism.py, tools/soak_pairs.py;
+// tests/test_gpu_parity.py::test_bf16_sweeps_in_flight_are_deterministic keeps it that way.
+constexpr int kPolyThreads = 128;                              // workgroup size of the kernels that call footprint_overlap
+constexpr int kPolyLdsFloats = 3 * kMaxPoly * kPolyThreads;    // px | py | ang: 36 KB
 
-__device__ float footprint_overlap(const Footprint &A, const Footprint &B) {
-    float px[kMaxPoly], py[kMaxPoly], ang[kMaxPoly];
+#ifdef FD_MASK_DEBUG  // tuning build (tools/probes/build_maskdbg.sh): digests of one evaluation, so two evaluations of the same inputs can be compared
+__device__ int g_maskdbg[8];
+__device__ int g_masklog_n;
+__device__ unsigned g_masklog[64 * 16];
+struct EvalDigest {
+    int n;                // points
+    unsigned pts, angs;   // xor over the points' / the angles' bit patterns
+    float area;
+    unsigned made;        // bit 4 i + j: edge pair (i, j) crossed; bit 16 + 2 k (+ 1): corner k of B (of A) inside the other
+    unsigned sides;       // xor over the four side values of every edge pair that passed the extent test
+};
+#define FD_DG_ARG , EvalDigest *dg = nullptr
+#define FD_DG(stmt) do { if (dg) { stmt; } } while (0)
+#define FD_DG_PT(x, y) FD_DG(dg->pts ^= __float_as_uint(x) * 3u ^ __float_as_uint(y))
+#else
+#define FD_DG_ARG
+#define FD_DG(stmt)
+#define FD_DG_PT(x, y)
+#endif
+__device__ float footprint_overlap(const Footprint &A, const Footprint &B, float *s_poly /* + threadIdx.x */ FD_DG_ARG) {
+    FD_DG(*dg = EvalDigest{});
+    auto px = [&](int k) -> float & { return s_poly[k * kPolyThreads]; };
+    auto py = [&](int k) -> float & { return s_poly[(kMaxPoly + k) * kPolyThreads]; };
+    auto ang = [&](int k) -> float & { return s_poly[(2 * kMaxPoly + k) * kPolyThreads]; };
     float sum_x = 0.f, sum_y = 0.f;
     int n = 0;
     // ---- crossing points, A's edges outer, B's edges inner
@@ -99,6 +137,7 @@ __device__ float footprint_overlap(const Footprint &A, const Footprint &B) {
             const float fx = bx1 - bx, fy = by1 - by;
             const float a0 = side_of(bx, by, ax, ay, ex, ey), a1 = side_of(bx1, by1, ax, ay, ex, ey);   // B's end points against A's edge
             const float b0 = side_of(ax, ay, bx, by, fx, fy), b1 = side_of(ax1, ay1, bx, by, fx, fy);   // A's end points against B's edge
+            FD_DG(dg->sides ^= (__float_as_uint(a0) * 3u) ^ (__float_as_uint(a1) * 5u) ^ (__float_as_uint(b0) * 7u) ^ (__float_as_uint(b1) * 11u) ^ (unsigned)(4 * i + j));
             if (!(a0 * (-a1) > 0.f && b0 * (-b1) > 0.f)) continue;  // both pairs strictly on opposite sides
             float qx, qy;
             const float den = a1 - a0;
@@ -112,7 +151,9 @@ __device__ float footprint_overlap(const Footprint &A, const Footprint &B) {
                 qx = (ma * cb - mb * ca) / det;
                 qy = (lb * ca - la * cb) / det;
             }
-            px[n] = qx; py[n] = qy; ++n;
+            px(n) = qx; py(n) = qy; ++n;
+            FD_DG_PT(qx, qy);
+            FD_DG(dg->made |= 1u << (4 * i + j));
             sum_x = sum_x + qx; sum_y = sum_y + qy;
         }
     }
@@ -121,37 +162,45 @@ __device__ float footprint_overlap(const Footprint &A, const Footprint &B) {
     for (int k = 0; k < 4; ++k) {
         if (inside_margin(A, B.vx[k], B.vy[k])) {
             sum_x = sum_x + B.vx[k]; sum_y = sum_y + B.vy[k];
-            px[n] = B.vx[k]; py[n] = B.vy[k]; ++n;
+            px(n) = B.vx[k]; py(n) = B.vy[k]; ++n;
+            FD_DG_PT(B.vx[k], B.vy[k]);
+            FD_DG(dg->made |= 1u << (16 + 2 * k));
         }
         if (inside_margin(B, A.vx[k], A.vy[k])) {
             sum_x = sum_x + A.vx[k]; sum_y = sum_y + A.vy[k];
-            px[n] = A.vx[k]; py[n] = A.vy[k]; ++n;
+            px(n) = A.vx[k]; py(n) = A.vy[k]; ++n;
+            FD_DG_PT(A.vx[k], A.vy[k]);
+            FD_DG(dg->made |= 1u << (17 + 2 * k));
         }
     }
+    FD_DG(dg->n = n);
     if (n < 3) return 0.f;  // no polygon (the fan below is empty or degenerate: area exactly 0)
     const float mx = sum_x / n, my = sum_y / n;
     // ---- angular order around the mean point: stable insertion sort, ascending, strict comparison
-    for (int k = 0; k < n; ++k) ang[k] = atan2f(py[k] - my, px[k] - mx);
+    for (int k = 0; k < n; ++k) ang(k) = atan2f(py(k) - my, px(k) - mx);
+    FD_DG(for (int k = 0; k < n; ++k) dg->angs ^= __float_as_uint(ang(k)) * (unsigned)(2 * k + 1));
     for (int k = 1; k < n; ++k) {
-        const float a = ang[k], x = px[k], y = py[k];
+        const float a = ang(k), x = px(k), y = py(k);
         int m = k;
-        while (m > 0 && ang[m - 1] > a) {
-            ang[m] = ang[m - 1]; px[m] = px[m - 1]; py[m] = py[m - 1];
+        while (m > 0 && ang(m - 1) > a) {
+            ang(m) = ang(m - 1); px(m) = px(m - 1); py(m) = py(m - 1);
             --m;
         }
-        ang[m] = a; px[m] = x; py[m] = y;
+        ang(m) = a; px(m) = x; py(m) = y;
     }
     // ---- fan around the first vertex
     float twice = 0.f;
+    const float x0 = px(0), y0 = py(0);
     for (int k = 0; k < n - 1; ++k) {
-        const float ux = px[k] - px[0], uy = py[k] - py[0], wx = px[k + 1] - px[0], wy = py[k + 1] - py[0];
+        const float ux = px(k) - x0, uy = py(k) - y0, wx = px(k + 1) - x0, wy = py(k + 1) - y0;
         twice += ux * wy - uy * wx;
     }
+    FD_DG(dg->area = fabsf(twice) * 0.5f);
     return fabsf(twice) * 0.5f;
 }
 
-__device__ inline float footprint_iou(const Footprint &A, const Footprint &B) {
-    const float ov = footprint_overlap(A, B);
+__device__ inline float footprint_iou(const Footprint &A, const Footprint &B, float *s_poly) {
+    const float ov = footprint_overlap(A, B, s_poly);
     return ov / fmaxf(A.area + B.area - ov, 1e-8f);
 }
 
@@ -700,11 +749,61 @@ __global__ void __launch_bounds__(256) dec_rank_decode(const unsigned long long 
 // single wave ballot.  The row's footprint is wave-uniform, the columns' footprints are four coalesced float4 loads.
 // Pairs whose centres are farther apart than the two half-diagonals (+0.1 m, which covers the 1e-2 corner-inside
 // margin) cannot produce a crossing point or an inside corner, so their overlap is exactly 0; they skip the geometry.
-__global__ void __launch_bounds__(256) nms_mask(const float4 *__restrict__ planes, int64_t n_total, const int *__restrict__ counts, int n_max,
-                                                int col_blocks, float thr, CircleCfg cc, unsigned long long *__restrict__ mask_all) {
+#ifdef FD_MASK_DEBUG
+// tuning build: every near pair is evaluated again from footprints PINNED in registers (the compiler cannot answer by loading them again), then
+// twice more with digests, then once from footprints loaded again; counters: [0] near pairs, [1] second evaluation differs, [2] third differs,
+// [3] re-loaded footprints differ bit-wise, [4..7] first digest field that differs (point count, point set, angles, area); the first 64
+// disagreements are logged with lane / block / HW_ID (tools/soak_determinism.py prints them)
+__device__ inline void mask_pin(Footprint &f) {
+    for (int k = 0; k < 4; ++k) { asm volatile("" : "+v"(f.vx[k])); asm volatile("" : "+v"(f.vy[k])); }
+    asm volatile("" : "+v"(f.cx)); asm volatile("" : "+v"(f.cy)); asm volatile("" : "+v"(f.co)); asm volatile("" : "+v"(f.si));
+    asm volatile("" : "+v"(f.hx)); asm volatile("" : "+v"(f.hy)); asm volatile("" : "+v"(f.area)); asm volatile("" : "+v"(f.reach));
+}
+__device__ inline void mask_self_check(const float4 *planes, int64_t n_total, int64_t base, int g, int row, int col, const Footprint &cur, const Footprint &oth,
+                                       float *s_poly, float thr, bool hit) {
+    const bool hit2 = footprint_iou(cur, oth, s_poly) > thr;
+    EvalDigest d1, d2;
+    (void)footprint_overlap(cur, oth, s_poly, &d1);
+    (void)footprint_overlap(cur, oth, s_poly, &d2);
+    if (d1.n != d2.n || d1.pts != d2.pts || d1.made != d2.made || d1.sides != d2.sides) {
+        const int slot = atomicAdd(&g_masklog_n, 1);
+        if (slot < 64) {
+            unsigned *o = g_masklog + slot * 16;
+            o[0] = (unsigned)g; o[1] = (unsigned)row; o[2] = (unsigned)col; o[3] = (unsigned)d1.n; o[4] = (unsigned)d2.n; o[5] = d1.made; o[6] = d2.made;
+            o[7] = d1.sides; o[8] = d2.sides; o[9] = d1.pts; o[10] = d2.pts; o[11] = __float_as_uint(d1.area); o[12] = __float_as_uint(d2.area);
+            o[13] = (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+            o[14] = (unsigned)(threadIdx.x); o[15] = (unsigned)blockIdx.x;
+        }
+    }
+    if (d1.n != d2.n) atomicAdd(&g_maskdbg[4], 1);
+    else if (d1.pts != d2.pts) atomicAdd(&g_maskdbg[5], 1);
+    else if (d1.angs != d2.angs) atomicAdd(&g_maskdbg[6], 1);
+    else if (__float_as_uint(d1.area) != __float_as_uint(d2.area)) atomicAdd(&g_maskdbg[7], 1);
+    const Footprint cur3 = load_footprint(planes, n_total, base + row), oth3 = load_footprint(planes, n_total, base + col);
+    const bool hit3 = footprint_iou(cur3, oth3, s_poly) > thr;
+    bool same_bits = true;
+    for (int k = 0; k < 4; ++k) same_bits = same_bits && __float_as_uint(cur3.vx[k]) == __float_as_uint(cur.vx[k]) && __float_as_uint(oth3.vx[k]) == __float_as_uint(oth.vx[k]) &&
+                                            __float_as_uint(cur3.vy[k]) == __float_as_uint(cur.vy[k]) && __float_as_uint(oth3.vy[k]) == __float_as_uint(oth.vy[k]);
+    same_bits = same_bits && __float_as_uint(cur3.area) == __float_as_uint(cur.area) && __float_as_uint(oth3.area) == __float_as_uint(oth.area) &&
+                __float_as_uint(cur3.cx) == __float_as_uint(cur.cx) && __float_as_uint(oth3.cx) == __float_as_uint(oth.cx);
+    atomicAdd(&g_maskdbg[0], 1);
+    if (hit2 != hit) atomicAdd(&g_maskdbg[1], 1);
+    if (hit3 != hit) atomicAdd(&g_maskdbg[2], 1);
+    if (!same_bits) atomicAdd(&g_maskdbg[3], 1);
+}
+#define FD_MASK_PIN(f) mask_pin(f)
+#define FD_MASK_SELF_CHECK() mask_self_check(planes, n_total, base, g, row, col, cur, oth, s_poly + threadIdx.x, thr, hit)
+#else
+#define FD_MASK_PIN(f)
+#define FD_MASK_SELF_CHECK()
+#endif
+constexpr int kMaskRows = kPolyThreads / 64;  // rows (waves) per workgroup of nms_mask
+__global__ void __launch_bounds__(kPolyThreads) nms_mask(const float4 *__restrict__ planes, int64_t n_total, const int *__restrict__ counts, int n_max,
+                                                         int col_blocks, float thr, CircleCfg cc, unsigned long long *__restrict__ mask_all) {
+    __shared__ float s_poly[kPolyLdsFloats];
     const int g = blockIdx.z, cb = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * kMaskRows + (threadIdx.x >> 6);
     const int n = counts ? counts[g] : n_max;
     if (row >= n) return;
     const int rb = row >> 6;
@@ -721,10 +820,14 @@ __global__ void __launch_bounds__(256) nms_mask(const float4 *__restrict__ plane
             hit = dx * dx + dy * dy <= cc.r[g / cc.per];
         }
     } else if (col < n && col > row) {
-        const Footprint cur = load_footprint(planes, n_total, base + row), oth = load_footprint(planes, n_total, base + col);
+        Footprint cur = load_footprint(planes, n_total, base + row), oth = load_footprint(planes, n_total, base + col);
+        FD_MASK_PIN(cur); FD_MASK_PIN(oth);
         const float dx = cur.cx - oth.cx, dy = cur.cy - oth.cy;
         const float reach = cur.reach + oth.reach + 0.1f;
-        if (dx * dx + dy * dy <= reach * reach) hit = footprint_iou(cur, oth) > thr;
+        if (dx * dx + dy * dy <= reach * reach) {
+            hit = footprint_iou(cur, oth, s_poly + threadIdx.x) > thr;
+            FD_MASK_SELF_CHECK();
+        }
     }
     const unsigned long long t = __ballot(hit);
     if (lane == 0) mask_all[((int64_t)g * n_max + row) * col_blocks + cb] = t;
@@ -793,13 +896,14 @@ __global__ void __launch_bounds__(256) keep_to_i64(const int *__restrict__ keep,
     if (i < n) out[i] = i < count[0] ? (long long)keep[i] : 0ll;
 }
 
-__global__ void __launch_bounds__(256) iou_pairs(const float *__restrict__ a, int na, const float *__restrict__ b, int nb, float *__restrict__ out) {
+__global__ void __launch_bounds__(kPolyThreads) iou_pairs(const float *__restrict__ a, int na, const float *__restrict__ b, int nb, float *__restrict__ out) {
+    __shared__ float s_poly[kPolyLdsFloats];
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)na * nb) return;
     int i = (int)(t / nb), j = (int)(t - (int64_t)i * nb);
     float ba[7], bb[7];
     for (int d = 0; d < 7; ++d) { ba[d] = a[i * 7 + d]; bb[d] = b[j * 7 + d]; }
-    out[t] = footprint_iou(make_footprint(ba), make_footprint(bb));
+    out[t] = footprint_iou(make_footprint(ba), make_footprint(bb), s_poly + threadIdx.x);
 }
 
 // Final assembly of predict's output (center_head.py:559-570,606-607,672-697): output step s takes the boxes of group
@@ -1084,7 +1188,7 @@ int decode_impl(const fd_map_view *hm, const fd_map_view *reg, const fd_map_view
                            sel_count);
         hipLaunchKernelGGL(footprint_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, stream, nms_boxes, sel_count, c.pre_max, G, foot);
     }
-    hipLaunchKernelGGL(nms_mask, dim3((c.pre_max + 3) / 4, w.col_blocks, G), dim3(256), 0, stream, foot, n_total, sel_count, c.pre_max, w.col_blocks,
+    hipLaunchKernelGGL(nms_mask, dim3((c.pre_max + kMaskRows - 1) / kMaskRows, w.col_blocks, G), dim3(kPolyThreads), 0, stream, foot, n_total, sel_count, c.pre_max, w.col_blocks,
                        c.iou_thr, cc, mask);
     // sweep + gather (+ packed assembly) in one launch when the group's mask words fit the LDS; else the round-4 kernels
     const size_t sweep_lds = (size_t)c.pre_max * w.col_blocks * 8 + 129 * 4 + 12;
@@ -1195,7 +1299,7 @@ extern "C" int fd_rotated_nms(const float *boxes7, int n, float thresh, int64_t 
     int *keep32 = (int *)((char *)workspace + fd::align_up(sizeof(unsigned long long) * (size_t)n * cb, 256));
     float4 *foot = (float4 *)((char *)keep32 + fd::align_up(sizeof(int) * (size_t)n, 256));
     hipLaunchKernelGGL(footprint_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, boxes7, (const int *)nullptr, n, 1, foot);
-    hipLaunchKernelGGL(nms_mask, dim3((n + 3) / 4, cb, 1), dim3(256), 0, stream, foot, (int64_t)n, (const int *)nullptr, n, cb, thresh, CircleCfg{0, {}}, mask);
+    hipLaunchKernelGGL(nms_mask, dim3((n + kMaskRows - 1) / kMaskRows, cb, 1), dim3(kPolyThreads), 0, stream, foot, (int64_t)n, (const int *)nullptr, n, cb, thresh, CircleCfg{0, {}}, mask);
     hipLaunchKernelGGL(nms_sweep, dim3(1), dim3(64), 0, stream, mask, (const int *)nullptr, n, cb, n, keep32, n, out_count, (const int *)nullptr);
     hipLaunchKernelGGL(keep_to_i64, dim3((n + 255) / 256), dim3(256), 0, stream, keep32, out_count, n, (long long *)keep);
     return fd::check_launch("fd_rotated_nms");
@@ -1206,6 +1310,11 @@ extern "C" int fd_boxes_iou_bev(const float *a7, int na, const float *b7, int nb
     if (na == 0 || nb == 0) return FD_OK;
     FD_REQUIRE(a7 && b7 && out, "fd_boxes_iou_bev: null argument");
     int64_t total = (int64_t)na * nb;
-    hipLaunchKernelGGL(iou_pairs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, fd::as_stream(stream), a7, na, b7, nb, out);
+    hipLaunchKernelGGL(iou_pairs, dim3((unsigned)((total + kPolyThreads - 1) / kPolyThreads)), dim3(kPolyThreads), 0, fd::as_stream(stream), a7, na, b7, nb, out);
     return fd::check_launch("fd_boxes_iou_bev");
 }
+
+#ifdef FD_MASK_DEBUG
+extern "C" int fd_debug_mask_log(unsigned *out1024) { return hipMemcpyFromSymbol(out1024, HIP_SYMBOL(g_masklog), 4096) == hipSuccess ? 0 : -1; }
+extern "C" int fd_debug_mask_counters(int *out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_maskdbg), 32) == hipSuccess ? 0 : -1; }
+#endif

@@ -243,10 +243,15 @@ class VoxelNet(SingleStageDetector):
         else:
             x, _ = bb.run_fused(idx, feats0, fork=static and _FORK)
             mark_stage("sparse_backbone")
+            taps = self.__dict__.get("debug_taps")  # tools/soak_determinism.py: a dict that keeps the stages' tensors (static memory inside a capture)
+            if taps is not None:
+                taps.update(mean=mean, coors=coors, num_points=npts, num_voxels=nvox, feats0=feats0, bev=x, idx=idx)
             x = self.neck(x)
             mark_stage("rpn")
             preds = self.bbox_head(x, bev_map)
             mark_stage("head")
+            if taps is not None:
+                taps.update(neck=x, head=[getattr(pd, "raw", (None,))[0] for pd in preds][0], preds=preds)
         if padded == "packed":  # (packed [B,S,post,11], counts [B,S]): what the multi-GPU gather and the bench move
             out = self.bbox_head.predict_packed(preds, self.test_cfg)
             if out is None:

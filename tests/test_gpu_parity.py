@@ -634,6 +634,55 @@ def test_decode_selection_edge_cases(hip, case):
     report("decode selection edge case %s: %d selected, first %d in the reference order" % (case, len(order), n), 0.0, 0.0)
 
 
+def test_bf16_sweeps_in_flight_are_deterministic(hip):
+    """Four captured bf16 sweeps in flight on four streams (bench.py's shape), 120 rounds: every replay of a stream returns its first
+    replay's packed detections bit for bit.  Round 6 found this failing -- 0.5-3 % of the sweeps came back with another detection list:
+    rotated-IoU decisions flipped in nms_mask while its inputs were bit-identical, only in lanes 48-63, only next to the bf16 dense
+    convolution of another stream, only when the IoU geometry was compiled to packed-fp32 instructions (fd_decode.hip, the comment on
+    footprint_overlap; futuredet_amd/build.py: -fno-slp-vectorize; profiles/round6_determinism_soak.txt).  480 replays caught the old
+    build in every run of the soak (expected 2-14 differing replays)."""
+    from futuredet_amd import build_detector
+    from futuredet_amd.configs import centerpoint_config
+    from futuredet_amd.detectors import StaticStep
+    from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dims
+
+    cfg = centerpoint_config("forecast_n3")
+    net = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    net.load_state_dict(tame_box_dims(seeded_state_dict(net, 7)), strict=False)
+    net = net.cuda().eval()
+    net.set_precision(torch.bfloat16)
+    B, NS, rounds = 2, 4, 120
+    clouds = [[torch.from_numpy(synthetic_cloud(seed=10 * s + b, target_points=300000)).cuda() for b in range(B)] for s in range(NS)]
+    cap = max(c.shape[0] for cs in clouds for c in cs) + 1024
+    streams = [torch.cuda.Stream() for _ in range(NS)]
+    steps = []
+    with torch.no_grad():
+        for s, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                step = StaticStep(net, cfg.voxel_generator, cap, batch_size=B, ndim=5, packed=True, row_caps="auto")
+                step.warm_up(clouds[s])
+                step.capture()
+                steps.append(step)
+        torch.cuda.synchronize()
+        first, differing = [None] * NS, 0
+        for r in range(rounds):
+            snaps = []
+            for s, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    packed, counts = steps[s](clouds[s], check=False)
+                    snaps.append((packed.clone(), counts.clone(), steps[s].level_counts.clone()))
+            torch.cuda.synchronize()
+            for s, snap in enumerate(snaps):
+                assert not steps[s].overflowed(snap[2].cpu().tolist())
+                if first[s] is None:
+                    first[s] = snap
+                    assert int(snap[1].sum()) > 500
+                else:
+                    differing += not (torch.equal(snap[0], first[s][0]) and torch.equal(snap[1], first[s][1]))
+    report("bf16 sweeps, %d in flight x %d rounds: replays that differ from the stream's first" % (NS, rounds), float(differing), 0.0)
+    assert differing == 0
+
+
 # ------------------------------------------------------------------------------------------------ end to end
 @pytest.mark.parametrize("variant", ["forecast_n0", "forecast_n3", "pedestrian_n3_fine", "forecast_n3dtfm"])
 def test_voxelnet_end_to_end_vs_oracle(hip, variant):

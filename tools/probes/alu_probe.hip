@@ -1,0 +1,87 @@
+// Which instruction class goes wrong next to the bf16 3x3 dense convolution?  (tools/soak_alu.py; profiles/round6_determinism_soak.txt)
+// Every thread evaluates a function of its thread id twice, per iteration, from the same register inputs and counts the disagreements.
+//   mode 0  fused multiply-add chains (v_fma_f32)
+//   mode 1  packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32)
+//   mode 2  divisions (v_div_scale / v_rcp / v_div_fmas / v_div_fixup)
+//   mode 3  comparisons feeding a counter through divergent branches
+//   mode 4  a thread-private LDS array written and read back with run-time indices
+//   mode 5  atan2f
+// build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/probes/libalu_probe.so tools/probes/alu_probe.hip
+#include <hip/hip_runtime.h>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__device__ __noinline__ float eval(float a, float b, float c, float d, float *lds) {
+    if constexpr (MODE == 0) {
+        float x = a;
+        for (int i = 0; i < 64; ++i) x = __builtin_fmaf(x, b, c) * 0.5f + d;
+        return x;
+    } else if constexpr (MODE == 1) {
+        f32x2 x = {a, b}, y = {c, d};
+        for (int i = 0; i < 64; ++i) { x = x * y + y; y = y * f32x2{0.5f, 0.25f} + x * f32x2{0.125f, 0.0625f}; x = x - y * f32x2{0.75f, 0.5f}; }
+        return x.x + x.y + y.x + y.y;
+    } else if constexpr (MODE == 2) {
+        float x = a;
+        for (int i = 0; i < 32; ++i) x = (x * b - c) / (d + x * 0.001f + 3.0f) + a / (b + 2.0f + x * x);
+        return x;
+    } else if constexpr (MODE == 3) {
+        int n = 0;
+        float x = a, y = b;
+        for (int i = 0; i < 64; ++i) {
+            x = x * 1.0009765625f + c * 0.01f; y = y * 0.9990234375f - d * 0.01f;
+            if (fminf(x, y) <= fmaxf(c, d) && x * (-y) > 0.f) { ++n; x = -x * 0.5f; }
+            else if (fabsf(x - y) < 0.37f) { n += 3; y = y + 0.11f; }
+        }
+        return (float)n + x;
+    } else if constexpr (MODE == 4) {
+        int n = 0;
+        for (int i = 0; i < 24; ++i) { const float v = a * (float)(i + 1) + b; if (v - floorf(v) < 0.7f) { lds[n * 128] = v; ++n; } }
+        for (int k = 1; k < n; ++k) {  // insertion sort, as in the overlap polygon
+            const float v = lds[k * 128];
+            int m = k;
+            while (m > 0 && lds[(m - 1) * 128] > v) { lds[m * 128] = lds[(m - 1) * 128]; --m; }
+            lds[m * 128] = v;
+        }
+        float s = 0.f;
+        for (int k = 0; k < n; ++k) s = s * 1.000001f + lds[k * 128] * (float)(k + 1);
+        return s;
+    } else {
+        float s = 0.f;
+        for (int i = 0; i < 16; ++i) s += atan2f(a + (float)i * c, b - (float)i * d);
+        return s;
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(128) probe(int iters, unsigned long long *mismatch, float *sink) {
+    __shared__ float s_arr[24 * 128];
+    const int t = blockIdx.x * 128 + threadIdx.x;
+    float a = 0.37f + (float)(t % 977) * 0.0113f, b = 1.21f - (float)(t % 131) * 0.0071f, c = 0.05f + (float)(t % 17) * 0.031f, d = 0.9f + (float)(t % 29) * 0.013f;
+    unsigned long long bad = 0;
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        const float r1 = eval<MODE>(a, b, c, d, s_arr + threadIdx.x);
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        const float r2 = eval<MODE>(a, b, c, d, s_arr + threadIdx.x);
+        bad += __float_as_uint(r1) != __float_as_uint(r2);
+        acc += r1;
+        a += 0.001f;
+    }
+    if (bad) atomicAdd(mismatch, bad);
+    if (acc == 123.456f) sink[0] = acc;
+}
+
+extern "C" int alu_probe_run(int mode, int blocks, int iters, unsigned long long *mismatch, float *sink, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    switch (mode) {
+        case 0: probe<0><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 1: probe<1><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 2: probe<2><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 3: probe<3><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 4: probe<4><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        default: probe<5><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+    }
+    return (int)hipGetLastError();
+}

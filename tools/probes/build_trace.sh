@@ -8,8 +8,7 @@ srcs=$(python -c "import sys; sys.path.insert(0, 'futuredet_amd'); import build;
 objs=""
 mkdir -p tools/probes/_obj
 for s in $srcs; do
-  extra=""
-  case $s in fd_decode|fd_sweeps|fd_forecast|fd_voxelize) extra="-ffp-contract=off";; esac
+  extra=$(python -c "import sys; sys.path.insert(0, 'futuredet_amd'); import build; print(' '.join(build.EXTRA.get('$s.hip', [])))")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -DFD_V2_TRACE $extra -c futuredet_amd/csrc/$s.hip -o tools/probes/_obj/$s.o &
   objs="$objs tools/probes/_obj/$s.o"
 done
