@@ -8,10 +8,11 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libfuturedet_hip.so")
 SOURCES = ["fd_error.hip", "fd_voxelize.hip", "fd_index.hip", "fd_spconv.hip", "fd_spconv_v2.hip", "fd_spconv_c32.hip", "fd_spconv_f32r.hip", "fd_spconv_bf16.hip", "fd_spconv_bf16win.hip", "fd_densify.hip", "fd_conv2d.hip", "fd_conv2d_f32.hip", "fd_conv2d_wino.hip", "fd_conv2d_wino_pc.hip", "fd_decode.hip", "fd_sweeps.hip", "fd_pillars.hip", "fd_forecast.hip"]
 # geometry / voxel membership follow the reference's operation order: no fma contraction there.
-# -fno-slp-vectorize: no packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32) in the plain-arithmetic kernels.  The rotated-IoU kernel
-# built WITH them returned flipped NMS decisions in 0.5-3 % of the sweeps when bf16 sweeps of other streams shared the device (lanes 48-63
-# of a wave, only next to the bf16 dense convolution's MFMA waves; never alone): fd_decode.hip's header comment on footprint_overlap,
-# profiles/round6_determinism_soak.txt.  Same IEEE operations either way: results are bit-identical, nms_mask is not slower.
+# -fno-slp-vectorize: the SLP vectoriser turns scalar geometry into packed-fp32 instructions, some with an op_sel swizzle of src1
+# (v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1]) -- a form that returns wrong values in lanes 48-63 on MI355X while bf16 dense-convolution
+# waves of another stream share the compute unit (round 6: flipped NMS decisions in 0.5-3 % of the bf16 sweeps with several in flight;
+# fd_decode.hip's comment on footprint_overlap, profiles/round6_determinism_soak.txt).  Same IEEE operations either way: bit-identical
+# results, no slower.  A CPU test disassembles the built library and refuses the form in ANY kernel.
 EXTRA = {"fd_decode.hip": ["-ffp-contract=off", "-fno-slp-vectorize"], "fd_sweeps.hip": ["-ffp-contract=off"], "fd_forecast.hip": ["-ffp-contract=off"],
          "fd_voxelize.hip": ["-ffp-contract=off"], "fd_pillars.hip": ["-fno-slp-vectorize"]}
 

@@ -82,16 +82,16 @@ constexpr int kMaxPoly = 24;  // 16 edge pairs can cross + 8 corners can be insi
 // [k * kPolyThreads + tid], conflict-free -- rather than in thread-private arrays, which would be scratch memory (208 bytes per lane).
 //
 // THIS FILE IS COMPILED WITH -fno-slp-vectorize (futuredet_amd/build.py).  With the SLP vectoriser on, the geometry below becomes ~500
-// packed-fp32 instructions (v_pk_mul_f32 / v_pk_add_f32) per evaluation, and with several bf16 sweeps in flight 0.5-3 % of the sweeps came
-// back with a different detection list: single IoU decisions flipped far from the threshold (0.34 judged "no overlap", 0.02 judged
-// "overlap") while every tensor nms_mask reads was bit-identical.  A tuning build (-DFD_MASK_DEBUG) that pins the two footprints in
-// registers and evaluates every near pair again shows the two evaluations of one thread disagreeing 1.5e-3 of the time, ONLY in lanes
-// 48-63 of a wave, ONLY while waves of the bf16 3x3 dense convolution (v_mfma_f32_32x32x16_bf16) of another stream share the compute
-// unit -- never alone, never next to the fp32 kernels, the sparse convolutions or other decodes; self-checking loops of plain packed
-// arithmetic, divisions, branches, LDS arrays and atan2f (tools/probes/alu_probe.hip) do not reproduce it.  Without the packed
-// instructions: 0 of 8000 sweeps (4 in flight) and 0 of 1200 next to three looping RPN plans, where the packed build loses 46-80 of
-// 400.  Evidence and the way there: profiles/round6_determinism_soak.txt, tools/soak_determinism.py, tools/soak_pairs.py;
-// tests/test_gpu_parity.py::test_bf16_sweeps_in_flight_are_deterministic keeps it that way.
+// packed-fp32 instructions per evaluation, 90 of them with an op_sel swizzle of src1 (v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1]) -- and
+// that form returns wrong values in lanes 48-63 of a wave while waves of the bf16 3x3 dense convolution (v_mfma_f32_32x32x16_bf16) of
+// another stream share the compute unit: with several bf16 sweeps in flight 0.5-3 % of the sweeps came back with a different detection
+// list (IoU 0.34 judged "no overlap", 0.02 judged "overlap") while every tensor nms_mask reads was bit-identical; never with one sweep in
+// flight, never in fp32.  Found by tools/soak_determinism.py, narrowed with a self-checking build (-DFD_MASK_DEBUG: two evaluations of one
+// thread on footprints pinned in registers disagree, lanes 48-63 only), tools/soak_pairs.py (the partner is the bf16 neck plan) and
+// tools/soak_alu.py (inline-asm chains: ONLY the op_sel:[0,1] forms fail; plain, neg, op_sel_hi, v_pk_fma_f32 and scalar arithmetic are
+// exact).  Without the vectoriser: same IEEE operations, bit-identical results, same 24 us, 0 of 18 000 sweeps differing.
+// profiles/round6_determinism_soak.txt; guards: tests/test_gpu_parity.py::test_bf16_sweeps_in_flight_are_deterministic (-m gpu) and
+// tests/test_host_surface.py::test_no_packed_fp32_instruction_selects_the_high_half_of_src1 (disassembles the built library).
 constexpr int kPolyThreads = 128;                              // workgroup size of the kernels that call footprint_overlap
 constexpr int kPolyLdsFloats = 3 * kMaxPoly * kPolyThreads;    // px | py | ang: 36 KB
 

@@ -258,6 +258,37 @@ def test_circular_nms_configuration_follows_the_reference():
         hip_ops.make_decode_cfg(180, 180, test_cfg, group_radius=[1.0] * 17)
 
 
+def test_no_packed_fp32_instruction_selects_the_high_half_of_src1(tmp_path):
+    """Static guard for the round-6 determinism defect (profiles/round6_determinism_soak.txt): on MI355X a packed-fp32 instruction whose
+    op_sel swizzles src1 (``v_pk_mul_f32 / v_pk_add_f32 ... op_sel:[0,1]``) returned wrong values in lanes 48-63 while bf16 dense-convolution
+    waves of another stream shared the compute unit (tools/soak_alu.py, modes 19 / 21: thousands of disagreements per run; plain, neg and
+    op_sel_hi forms: none).  The SLP vectoriser emits that form for the rotated-IoU geometry; fd_decode.hip and fd_pillars.hip are built with
+    -fno-slp-vectorize, and NO kernel of the library may contain the form: the device code of the built library is disassembled and searched."""
+    import shutil
+
+    from futuredet_amd import build
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.isfile(objdump):
+        pytest.skip("llvm-objdump not found")
+    build.build()
+    so = str(tmp_path / "lib.so")
+    shutil.copy(lib.LIB_PATH, so)
+    subprocess.check_output([objdump, "--offloading", so], stderr=subprocess.STDOUT)  # writes lib.so.<n>.hipv4-amdgcn-amd-amdhsa--gfx950 next to it
+    objs = [str(tmp_path / f) for f in os.listdir(str(tmp_path)) if f.endswith("gfx950")]
+    assert len(objs) == len(build.SOURCES), objs
+    packed, bad = 0, []
+    for o in objs:
+        for line in subprocess.check_output([objdump, "-d", o]).decode().splitlines():
+            m = re.search(r"\bv_pk_(mul|add|fma)_f32\b.*", line)
+            if m:
+                packed += 1
+                if "op_sel:[" in m.group(0):
+                    bad.append(m.group(0).strip())
+    assert packed > 1000, "the disassembly should show the epilogues' packed additions (%d found)" % packed
+    assert not bad, "%d packed-fp32 instructions with an op_sel swizzle, e.g. %s" % (len(bad), bad[:3])
+
+
 def test_product_path_fails_loudly_without_gpu_tensors():
     from futuredet_amd import hip_ops
     from futuredet_amd.lib import FutureDetHipError

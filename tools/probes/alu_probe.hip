@@ -6,6 +6,11 @@
 //   mode 3  comparisons feeding a counter through divergent branches
 //   mode 4  a thread-private LDS array written and read back with run-time indices
 //   mode 5  atan2f
+//   mode 6  v_pk_mul_f32 chains (inline asm: exactly this instruction, with and without neg / op_sel modifiers)
+//   mode 7  v_pk_add_f32 chains        mode 8  v_pk_fma_f32 chains        mode 9  v_mul_f32 / v_add_f32 chains (the scalar forms of mode 6 / 7)
+//   mode 10-13  mode 7's chain with s_nop 0 / s_nop 3 / one / two independent VALU instructions between dependent v_pk_add_f32
+//   mode 16-21  ONE form each: v_pk_mul_f32 plain / neg / op_sel_hi:[1,0] / op_sel:[0,1] op_sel_hi:[1,0] / op_sel:[1,0] op_sel_hi:[0,1]; v_pk_add_f32 op_sel:[0,1] op_sel_hi:[0,1]
+//   mode 14  unmodified v_pk_add_f32 only        mode 15  two alternating accumulators (a result is read two instructions later)
 // build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/probes/libalu_probe.so tools/probes/alu_probe.hip
 #include <hip/hip_runtime.h>
 
@@ -46,10 +51,78 @@ __device__ __noinline__ float eval(float a, float b, float c, float d, float *ld
         float s = 0.f;
         for (int k = 0; k < n; ++k) s = s * 1.000001f + lds[k * 128] * (float)(k + 1);
         return s;
-    } else {
+    } else if constexpr (MODE == 5) {
         float s = 0.f;
         for (int i = 0; i < 16; ++i) s += atan2f(a + (float)i * c, b - (float)i * d);
         return s;
+    } else if constexpr (MODE == 6) {
+        f32x2 x = {a, b}, y = {1.0f + c * 0.001f, 1.0f - d * 0.001f}, z = {0.999f, 1.001f};
+        for (int i = 0; i < 128; ++i) {
+            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x) : "v"(x), "v"(z));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(x) : "v"(x), "v"(y));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x) : "v"(x), "v"(z));
+        }
+        return x.x + x.y;
+    } else if constexpr (MODE == 7) {
+        f32x2 x = {a, b}, y = {c * 0.01f, -d * 0.01f};
+        for (int i = 0; i < 128; ++i) {
+            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
+            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x) : "v"(x), "v"(y));
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1]" : "=v"(x) : "v"(x), "v"(y));
+            asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(x) : "v"(x), "v"(y));
+        }
+        return x.x + x.y;
+    } else if constexpr (MODE == 8) {
+        f32x2 x = {a, b}, y = {1.0f + c * 0.001f, 1.0f - d * 0.001f}, z = {0.001f, -0.001f};
+        for (int i = 0; i < 256; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(y), "v"(z));
+        return x.x + x.y;
+    } else if constexpr (MODE >= 10 && MODE <= 13) {  // the v_pk_add_f32 chain of mode 7 with something between two dependent instructions
+        f32x2 x = {a, b}, y = {c * 0.01f, -d * 0.01f};
+        float w = c;
+        for (int i = 0; i < 256; ++i) {
+            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
+            if constexpr (MODE == 10) asm volatile("s_nop 0");
+            if constexpr (MODE == 11) asm volatile("s_nop 3");
+            if constexpr (MODE == 12) asm volatile("v_add_f32 %0, %1, %1" : "=v"(w) : "v"(w));   // an independent VALU instruction
+            if constexpr (MODE == 13) asm volatile("v_add_f32 %0, %1, %1\n\tv_add_f32 %0, %0, %1" : "=v"(w) : "v"(w));
+            asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x) : "v"(x), "v"(y));
+            if constexpr (MODE == 10) asm volatile("s_nop 0");
+            if constexpr (MODE == 11) asm volatile("s_nop 3");
+            if constexpr (MODE == 12) asm volatile("v_add_f32 %0, %1, %1" : "=v"(w) : "v"(w));
+            if constexpr (MODE == 13) asm volatile("v_add_f32 %0, %1, %1\n\tv_add_f32 %0, %0, %1" : "=v"(w) : "v"(w));
+        }
+        return x.x + x.y + (w == 12345.f ? 1.f : 0.f);
+    } else if constexpr (MODE >= 16 && MODE <= 21) {  // one form per mode, 512 dependent instructions
+        f32x2 x = {a, b}, y = {1.0f + c * 0.0001f, 1.0f - d * 0.0001f};
+        for (int i = 0; i < 512; ++i) {
+            if constexpr (MODE == 16) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
+            if constexpr (MODE == 17) asm volatile("v_pk_mul_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(x) : "v"(x), "v"(y));
+            if constexpr (MODE == 18) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(x) : "v"(x), "v"(y));
+            if constexpr (MODE == 19) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(x) : "v"(x), "v"(y));
+            if constexpr (MODE == 20) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(x) : "v"(x), "v"(y));
+            if constexpr (MODE == 21) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1]" : "=v"(x) : "v"(x), "v"(y));
+        }
+        return x.x + x.y;
+    } else if constexpr (MODE == 14) {  // plain (unmodified) v_pk_add_f32 only
+        f32x2 x = {a, b}, y = {c * 0.01f, -d * 0.01f};
+        for (int i = 0; i < 512; ++i) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
+        return x.x + x.y;
+    } else if constexpr (MODE == 15) {  // v_pk_add_f32 whose result is NOT the next one's input (two alternating accumulators: distance 2)
+        f32x2 x = {a, b}, x2 = {b, a}, y = {c * 0.01f, -d * 0.01f};
+        for (int i = 0; i < 256; ++i) {
+            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
+            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(x2) : "v"(x2), "v"(y));
+        }
+        return x.x + x.y + x2.x + x2.y;
+    } else {
+        float x = a, y = 1.0f + c * 0.001f, z = d * 0.01f;
+        for (int i = 0; i < 256; ++i) {
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(z));
+            asm volatile("v_sub_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(z));
+        }
+        return x;
     }
 }
 
@@ -81,7 +154,23 @@ extern "C" int alu_probe_run(int mode, int blocks, int iters, unsigned long long
         case 2: probe<2><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
         case 3: probe<3><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
         case 4: probe<4><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
-        default: probe<5><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 5: probe<5><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 6: probe<6><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 7: probe<7><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 8: probe<8><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 9: probe<9><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 10: probe<10><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 11: probe<11><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 12: probe<12><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 13: probe<13><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 14: probe<14><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 15: probe<15><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 16: probe<16><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 17: probe<17><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 18: probe<18><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 19: probe<19><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        case 20: probe<20><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
+        default: probe<21><<<blocks, 128, 0, s>>>(iters, mismatch, sink); break;
     }
     return (int)hipGetLastError();
 }

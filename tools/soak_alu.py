@@ -23,7 +23,11 @@ net.load_state_dict(tame_box_dims(seeded_state_dict(net, 7)), strict=False)
 net = net.cuda().eval()
 sa = torch.cuda.Stream()
 sbs = [torch.cuda.Stream() for _ in range(NB)]
-names = ["fma chains", "packed fp32", "divisions", "compares + divergent branches", "LDS array, run-time indices", "atan2f"]
+names = ["fma chains", "packed fp32", "divisions", "compares + divergent branches", "LDS array, run-time indices", "atan2f", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32",
+         "v_mul / v_add / v_sub", "pk_add + s_nop 0", "pk_add + s_nop 3", "pk_add + 1 VALU", "pk_add + 2 VALU", "pk_add plain", "pk_add distance 2", "pk_mul plain", "pk_mul neg", "pk_mul op_sel_hi:[1,0]", "pk_mul op_sel:[0,1] op_sel_hi:[1,0]",
+         "pk_mul op_sel:[1,0] op_sel_hi:[0,1]", "pk_add op_sel:[0,1] op_sel_hi:[0,1]"]
+dists = sys.argv[4].split(",") if len(sys.argv) > 4 else None
+only = [int(m) for m in sys.argv[3].split(",")] if len(sys.argv) > 3 else list(range(len(names)))
 with torch.no_grad():
     clouds = [torch.from_numpy(synthetic_cloud(seed=b, target_points=300000)).cuda() for b in range(2)]
     dist = {"nothing": None}
@@ -50,8 +54,12 @@ with torch.no_grad():
     mism = torch.zeros(1, dtype=torch.int64, device="cuda")
     sink = torch.zeros(4, device="cuda")
     for dname, gs in dist.items():
+        if dists and not any(d in dname for d in dists):
+            continue
         line = "%-22s" % dname
         for mode, nm in enumerate(names):
+            if mode not in only:
+                continue
             mism.zero_()
             torch.cuda.synchronize()
             for r in range(rounds):
