@@ -146,6 +146,47 @@ __global__ void __launch_bounds__(128) probe(int iters, unsigned long long *mism
     if (acc == 123.456f) sink[0] = acc;
 }
 
+// ---- synthetic disturbers: waves that issue ONE kind of instruction back to back (no memory traffic), to find what the victim needs next to it
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int KIND>
+__global__ void __launch_bounds__(256) disturb(int iters, float *sink) {
+    const float t = (float)threadIdx.x * 1e-3f;
+    if constexpr (KIND == 0) {  // v_mfma_f32_32x32x16_bf16 (the bf16 dense convolution's)
+        bf16x8 a, b;
+        for (int k = 0; k < 8; ++k) { a[k] = (__bf16)(t + k); b[k] = (__bf16)(1.f - t * k); }
+        f32x16 c0 = {}, c1 = {};
+        for (int i = 0; i < iters; ++i) { c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0); }
+        if (c0[0] + c1[3] == 123.f) sink[0] = c0[1];
+    } else if constexpr (KIND == 1) {  // v_mfma_f32_16x16x32_bf16 (the bf16 sparse convolutions')
+        bf16x8 a, b;
+        for (int k = 0; k < 8; ++k) { a[k] = (__bf16)(t + k); b[k] = (__bf16)(1.f - t * k); }
+        f32x4v c0 = {}, c1 = {};
+        for (int i = 0; i < iters; ++i) { c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c1, 0, 0, 0); }
+        if (c0[0] + c1[3] == 123.f) sink[0] = c0[1];
+    } else if constexpr (KIND == 2) {  // v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (the fp32 kernels')
+        f32x16 c0 = {};
+        f32x4v c1 = {};
+        for (int i = 0; i < iters; ++i) { c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(t, 1.f - t, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f + t, t, c1, 0, 0, 0); }
+        if (c0[0] + c1[3] == 123.f) sink[0] = c0[1];
+    } else {  // plain VALU work (v_fma_f32 chains)
+        float x = t, y = 1.f - t;
+        for (int i = 0; i < iters * 8; ++i) { x = __builtin_fmaf(x, 0.999f, y); y = __builtin_fmaf(y, 1.001f, -x); }
+        if (x + y == 123.f) sink[0] = x;
+    }
+}
+extern "C" int alu_disturb_run(int kind, int blocks, int iters, float *sink, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    switch (kind) {
+        case 0: disturb<0><<<blocks, 256, 0, s>>>(iters, sink); break;
+        case 1: disturb<1><<<blocks, 256, 0, s>>>(iters, sink); break;
+        case 2: disturb<2><<<blocks, 256, 0, s>>>(iters, sink); break;
+        default: disturb<3><<<blocks, 256, 0, s>>>(iters, sink); break;
+    }
+    return (int)hipGetLastError();
+}
+
 extern "C" int alu_probe_run(int mode, int blocks, int iters, unsigned long long *mismatch, float *sink, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     switch (mode) {

@@ -1,7 +1,8 @@
 """Which part of a sweep disturbs nms_mask?  Stream A replays one whole captured sweep (the victim; with the -DFD_MASK_DEBUG build its
 nms_mask evaluates every near pair twice and counts disagreements); streams B.. replay, for the whole duration of it, one disturber
-component in a loop: whole sweeps, the sparse backbone, the neck + head plan, or decodes.
-    FD_LIB_PATH=tools/probes/libfd_maskdbg.so python tools/soak_pairs.py [rounds per disturber] [fp32|bf16] [disturber streams]"""
+component in a loop: whole sweeps, the sparse backbone, the neck + head plan, the neck plan's blocks / deblocks, or decodes.
+    FD_LIB_PATH=tools/probes/libfd_maskdbg.so python tools/soak_pairs.py [rounds per disturber] [fp32|bf16] [disturber streams] [name filter, comma separated]
+(every graph's inputs, weights and plans are kept alive for the whole run: a disturber whose inputs were freed faults, which is the harness, not the kernels)"""
 import ctypes
 import sys
 
@@ -101,21 +102,6 @@ with torch.no_grad():
                          ("neck deblock 0 (%s)" % rp.deblocks[0][0], 60, lambda: deblock(0, x1, 0)),
                          ("neck deblock 1 (%s)" % rp.deblocks[1][0], 30, lambda: deblock(1, x2, rp.deblocks[0][3]))):
         dist[nm] = ([capture(fn, sb, ("soak", nm, i))[0] for i, sb in enumerate(sbs)], reps)
-    if False:  # (the per-layer disturbers below kept their inputs alive only by accident: a faulting run was the harness, not the kernels)
-        pass
-    if dtype == torch.bfloat16 and len(sys.argv) > 5:  # single dense bf16 layers of the RPN / head shapes (graphs of 8 launches), and elementwise / copy traffic for contrast
-        for cin, cout, hw, ks, st in [(128, 128, 180, 3, 1), (256, 256, 90, 3, 1), (512, 64, 180, 3, 1), (64, 384, 180, 3, 1), (128, 256, 180, 3, 2), (128, 256, 180, 1, 1)]:
-            x = torch.randn(B, hw, hw, cin, device="cuda").bfloat16()
-            wp = hip_ops.pack_conv2d_weight(torch.randn(cout, cin, ks, ks) * 0.02).cuda()
-            bias = torch.randn(cout, device="cuda")
-
-            def layer(x=x, wp=wp, bias=bias, cout=cout, ks=ks, st=st):
-                for _ in range(8):
-                    y = hip_ops.conv2d_nhwc_bf16(x, wp, bias, cout, ks, st, True)
-                return y
-            dist["conv %d->%d @%d k%d s%d" % (cin, cout, hw, ks, st)] = ([capture(layer, sb, ("soak", "conv", cin, cout, ks, st, i))[0] for i, sb in enumerate(sbs)], 4)
-        big = torch.randn(64 << 20, device="cuda")
-        dist["torch copy 256 MB"] = ([capture(lambda: big.clone(), sb, ("soak", "copy", i))[0] for i, sb in enumerate(sbs)], 20)
     only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
     if only:
         dist = {k: v for k, v in dist.items() if any(o in k for o in only)}
