@@ -16,7 +16,11 @@ from futuredet_amd.synth import seeded_state_dict, synthetic_cloud, tame_box_dim
 dtype = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float32
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 variant = sys.argv[4] if len(sys.argv) > 4 else ("forecast_n3" if dtype == torch.bfloat16 else "forecast_n0")
-if variant == "config5":  # BASELINE configs[4]: pedestrian forecast_n3 on the 0.05 m grid, 500k-point clouds (BEV 270 x 270: the decode's streaming selection)
+IS_PP = variant == "pp"
+if IS_PP:  # the PointPillars configs (reader + scatter instead of the sparse backbone)
+    from futuredet_amd.configs import pointpillars_config
+    cfg = pointpillars_config("car")
+elif variant == "config5":  # BASELINE configs[4]: pedestrian forecast_n3 on the 0.05 m grid, 500k-point clouds (BEV 270 x 270: the decode's streaming selection)
     cfg = centerpoint_config("forecast_n3", "pedestrian", voxel_size=(0.05, 0.05, 0.2), max_voxel_num=(300000, 400000))
 else:
     cfg = centerpoint_config(variant)
@@ -48,13 +52,18 @@ with torch.no_grad():
     for s, st in enumerate(streams):
         with torch.cuda.stream(st):
             net.forward_points(clouds[s], cfg.voxel_generator, padded="packed")
-            step = StaticStep(net, cfg.voxel_generator, cap, batch_size=B, ndim=5, packed=True, row_caps="auto")
+            step = StaticStep(net, cfg.voxel_generator, cap, batch_size=B, ndim=5, packed=True, row_caps="datafree" if IS_PP else "auto")
             step.warm_up(clouds[s])
             hook, stage = LayerTaps(), {}
-            net.backbone.profile_hook, net.__dict__["debug_taps"] = hook, stage
+            if not IS_PP:
+                net.backbone.profile_hook, net.__dict__["debug_taps"] = hook, stage
             step.capture()
-            net.backbone.profile_hook, net.__dict__["debug_taps"] = None, None
+            if not IS_PP:
+                net.backbone.profile_hook, net.__dict__["debug_taps"] = None, None
             steps.append(step)
+            if IS_PP:
+                taps.append([])
+                continue
             ws_dec = hip_ops.workspace._bufs.get(("decode", torch.cuda.current_device(), ("scope", id(step))))
             named = ([("decode workspace", ws_dec)] if ws_dec is not None else []) + [(k, stage[k]) for k in ("mean", "coors", "num_points", "num_voxels", "feats0")] + \
                     [("%02d %s" % (i, t), y) for i, (t, y) in enumerate(hook.outs)] + [(k, stage[k]) for k in ("bev", "neck", "head") if stage.get(k) is not None]
@@ -67,10 +76,11 @@ with torch.no_grad():
         for s, st in enumerate(streams):
             with torch.cuda.stream(st):
                 packed, counts = steps[s](clouds[s], check=False)
-                snaps.append((packed.clone(), counts.clone(), steps[s].level_counts.clone()) + tuple(t.clone() for _, t in taps[s]))
+                lc = steps[s].level_counts if steps[s].level_counts is not None and torch.is_tensor(steps[s].level_counts) else torch.zeros(1, dtype=torch.int32, device="cuda")
+                snaps.append((packed.clone(), counts.clone(), lc.clone()) + tuple(t.clone() for _, t in taps[s]))
         torch.cuda.synchronize()
         for s, snap in enumerate(snaps):
-            assert not steps[s].overflowed(snap[2].cpu().tolist())
+            assert IS_PP or not steps[s].overflowed(snap[2].cpu().tolist())
             if first[s] is None:
                 first[s] = snap
                 assert int(snap[1].sum()) > 0
