@@ -1558,6 +1558,14 @@ def test_c_abi_reports_errors_instead_of_exiting(hip):
         assert status < 0, name
         msg = L.fd_last_error()
         assert msg and name.encode() in msg, (name, msg)
+    # the decode's NMS configuration (ABI 8): an unknown nms_kind, a radius table that does not divide the groups, a negative radius
+    maps = [torch.zeros((2, c, 16, 16), device="cuda") for c in (1, 2, 1, 3, 2)]
+    for kw in (dict(nms_kind=2), dict(nms_kind=1, n_radius=0), dict(nms_kind=1, n_radius=3), dict(nms_kind=1, n_radius=2, radius0=-1.0)):
+        cfg = hip.make_decode_cfg(16, 16, TEST_CFG)
+        cfg.nms_kind, cfg.n_radius = kw.get("nms_kind", 0), kw.get("n_radius", 0)
+        cfg.circle_radius[0] = kw.get("radius0", 1.0)
+        with pytest.raises(lib.FutureDetHipError, match="fd_centerpoint_decode"):
+            hip.centerpoint_decode(*maps, cfg)
     # workspace too small is its own code, and the library still works afterwards
     pts = torch.rand((100, 5), device="cuda")
     out = hip.voxelize(pts, [0.5, 0.5, 0.5], [0, 0, 0, 1, 1, 1], 4, 64)
