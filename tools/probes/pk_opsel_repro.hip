@@ -57,6 +57,33 @@ __global__ void __launch_bounds__(256) disturber(int iters, float *sink) {
     if (c16[0] + c4[3] == 123.f) sink[0] = c16[1];
 }
 
+// the same inside ONE kernel: waves 0-1 of a workgroup run the chain, waves 2-3 issue v_mfma_f32_16x16x32_bf16 back to back
+template <bool SWIZZLE>
+__global__ void __launch_bounds__(256) mixed(int iters, unsigned long long *mismatch) {
+    const int wave = threadIdx.x >> 6;
+    if (wave >= 2) {
+        const float t = (float)threadIdx.x * 1e-3f;
+        bf16x8 a, b;
+        for (int k = 0; k < 8; ++k) { a[k] = (__bf16)(t + k); b[k] = (__bf16)(1.f - t * k); }
+        f32x4 c4 = {};
+        for (int i = 0; i < iters * 700; ++i) { c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c4, 0, 0, 0); c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c4, 0, 0, 0); }
+        if (c4[3] == 123.f) mismatch[1] = 1;
+        return;
+    }
+    const int t = blockIdx.x * 128 + threadIdx.x;
+    float a = 0.37f + (float)(t % 977) * 0.0113f, b = 1.21f - (float)(t % 131) * 0.0071f, c = 0.05f + (float)(t % 17) * 0.031f, d = 0.9f + (float)(t % 29) * 0.013f;
+    unsigned long long bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        const float r1 = chain<SWIZZLE>(a, b, c, d);
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        const float r2 = chain<SWIZZLE>(a, b, c, d);
+        bad += __float_as_uint(r1) != __float_as_uint(r2);
+        a += 0.001f;
+    }
+    if (bad) atomicAdd(mismatch, bad);
+}
+
 int main() {
     hipStream_t sv, sd[3];
     hipStreamCreate(&sv);
@@ -89,5 +116,17 @@ int main() {
         printf("%-34s %10llu (%llu in lanes 48-63)   %10llu\n", dn[kind + 1], res[0][0], res[0][1], res[1][0]);
     }
     printf("(per cell: 100 rounds x 6 launches x 16384 threads x 24 double evaluations = 236 M)\n");
+    for (int sw = 0; sw < 2; ++sw) {  // one kernel, one stream: chain waves and MFMA waves in the same workgroups
+        hipMemset(cnt, 0, 16);
+        for (int round = 0; round < 100; ++round) {
+            if (sw == 0) mixed<true><<<1024, 256, 0, sv>>>(24, cnt);
+            else mixed<false><<<1024, 256, 0, sv>>>(24, cnt);
+            hipDeviceSynchronize();
+        }
+        unsigned long long r[2];
+        hipMemcpy(r, cnt, 16, hipMemcpyDeviceToHost);
+        printf("one kernel, waves 0-1 chain / waves 2-3 v_mfma_f32_16x16x32_bf16, %s chain: %llu mismatches of %llu double evaluations\n", sw == 0 ? "swizzled" : "plain", r[0],
+               100ull * 1024 * 128 * 24);
+    }
     return 0;
 }
